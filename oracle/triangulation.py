@@ -1,0 +1,124 @@
+"""Oracle (test infrastructure): multi-view triangulation in float64 NumPy.
+
+Restates ``/root/reference/lib/utils/triangulation.py``.  The reference delegates its linear
+algebra to OpenCV (not vendored; conda pin opencv=4.1.0, environment.yml:96):
+
+* ``cv2.solve(A, b, x, cv2.DECOMP_SVD)`` (triangulation.py:95,155) -- minimum-norm least squares
+  through the SVD (OpenCV ``cv::solve`` -> ``SVD::backSubst``).  Restated with ``np.linalg.lstsq``.
+* ``cv2.triangulatePoints`` (triangulation.py:22) -- per point the 4x4 matrix with rows
+  ``x*P[2]-P[0], y*P[2]-P[1]`` for both cameras, SVD, right-singular vector of the smallest singular
+  value (OpenCV ``cvTriangulatePoints``).  Restated with ``np.linalg.svd`` and generalised to V views.
+
+Not imported by the product.
+"""
+import numpy as np
+
+
+def lstsq_svd(a, b):
+    """Stand-in for cv2.solve(A, b, dst, DECOMP_SVD): min-norm LS via SVD, float64."""
+    return np.linalg.lstsq(a, b, rcond=None)[0]
+
+
+def _ls_rows(u, p):
+    """Rows of the inhomogeneous system for one camera.
+
+    triangulation.py:138-148: C = [[-1,0,u],[0,-1,v]];  A = C @ P[:, :3];  b = -(C @ P[:, 3]).
+    """
+    c = np.array([[-1.0, 0.0, u[0]], [0.0, -1.0, u[1]]])
+    return c @ p[:, :3], -(c @ p[:, 3])
+
+
+def linear_ls_triangulation(us, ps):
+    """triangulation.py:34-97 generalised from 2 to V views.
+
+    us: [V, N, 2] pixel coordinates, ps: [V, 3, 4].  Returns X [N, 3], status ones [N] (bool).
+    """
+    us = np.asarray(us, np.float64)
+    ps = np.asarray(ps, np.float64)
+    n_view, n_pt = us.shape[0], us.shape[1]
+    out = np.zeros((n_pt, 3))
+    for i in range(n_pt):
+        rows = [_ls_rows(us[v, i], ps[v]) for v in range(n_view)]
+        a = np.concatenate([r[0] for r in rows], axis=0)
+        b = np.concatenate([r[1] for r in rows], axis=0)
+        out[i] = lstsq_svd(a, b)
+    return out, np.ones(n_pt, dtype=bool)
+
+
+def iterative_ls_triangulation(us, ps, tolerance=3.0e-5, max_iter=10):
+    """triangulation.py:104-181 (Hartley & Sturm iterative re-weighting), V views (reference: V=2).
+
+    Exactly as the reference: depths start at 1 (:151); up to 10 solves (:153); stop when EVERY
+    view's depth moved by <= tolerance (absolute, :161-163); otherwise rows of A and b are scaled by
+    1/d_new CUMULATIVELY (:166-169).  Status (:176-179): 1 inlier / 0 not converged, minus 1 if
+    d_1<=0, minus 2 if d_2<=0 (the ``i < 10`` test at :176 is always true, so "converged" only
+    means "in front of all cameras").  For V>2 status = 1 if all depths > 0 else minus the bit mask
+    sum(2**v for d_v <= 0), which reduces to the reference's table at V=2.
+    """
+    us = np.asarray(us, np.float64)
+    ps = np.asarray(ps, np.float64)
+    n_view, n_pt = us.shape[0], us.shape[1]
+    out = np.zeros((n_pt, 3))
+    status = np.zeros(n_pt, dtype=np.int64)
+    for i in range(n_pt):
+        rows = [_ls_rows(us[v, i], ps[v]) for v in range(n_view)]
+        a = np.concatenate([r[0] for r in rows], axis=0)
+        b = np.concatenate([r[1] for r in rows], axis=0)
+        d = np.ones(n_view)
+        x = np.zeros(3)
+        d_new = d
+        for _ in range(max_iter):
+            x = lstsq_svd(a, b)
+            d_new = ps[:, 2, :3] @ x + ps[:, 2, 3]          # :158-159
+            if np.all(np.abs(d_new - d) <= tolerance):       # :161-163
+                break
+            w = np.repeat(1.0 / d_new, 2)                    # :166-169
+            a = a * w[:, None]
+            b = b * w
+            d = d_new
+        out[i] = x
+        behind = d_new <= 0
+        status[i] = 1 if np.all(d_new > 0) else -int(sum(2 ** v for v in range(n_view) if behind[v]))
+    return out, status
+
+
+def dlt_triangulation(us, ps, max_coordinate_value=1.0e16):
+    """triangulation.py:8-27 (linear-eigen == cv2.triangulatePoints), generalised to V views.
+
+    Homogeneous 2Vx4 system, smallest right-singular vector, dehomogenise (:24); status is the
+    finiteness test of :25.
+    """
+    us = np.asarray(us, np.float64)
+    ps = np.asarray(ps, np.float64)
+    n_view, n_pt = us.shape[0], us.shape[1]
+    out = np.zeros((n_pt, 3))
+    for i in range(n_pt):
+        m = np.empty((2 * n_view, 4))
+        for v in range(n_view):
+            m[2 * v] = us[v, i, 0] * ps[v, 2] - ps[v, 0]
+            m[2 * v + 1] = us[v, i, 1] * ps[v, 2] - ps[v, 1]
+        vt = np.linalg.svd(m)[2]
+        h = vt[-1]
+        out[i] = h[:3] / h[3]
+    with np.errstate(invalid="ignore"):
+        ok = np.max(np.abs(out), axis=1) <= max_coordinate_value
+    return out, ok
+
+
+def triangulate_pairs(kps, projection_matrices, n_view=2, method="iterative"):
+    """img_utils.py:193-209 ``triangulate``: sample i of view v sits at batch index v*G + i.
+
+    kps: [B, J, >=2], projection_matrices: [B, 3, 4].  Returns [B, J, 3] -- the group's 3-D pose is
+    repeated for each of its views (np.vstack at :208).
+    """
+    kps = np.asarray(kps, np.float64)
+    pm = np.asarray(projection_matrices, np.float64)
+    n_group = kps.shape[0] // n_view
+    fn = {"iterative": iterative_ls_triangulation, "ls": linear_ls_triangulation, "dlt": dlt_triangulation}[method]
+    pts = []
+    for g in range(n_group):
+        idx = [v * n_group + g for v in range(n_view)]
+        x, _ = fn(kps[idx][:, :, 0:2], pm[idx])
+        pts.append(x)
+    pts = np.asarray(pts)
+    return np.concatenate([pts] * n_view, axis=0)

@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by EXECUTING THE REFERENCE (``/root/reference``).
+
+Run in the build container only (the reference is not present on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Everything stored here is an output of the reference's own code on seeded inputs (see ref_shims.py for
+the third-party stubs).  Inputs are either stored next to the outputs or regenerated from the seeded
+helpers in det_weights.py / epipolarpose_amd.synthetic (an input checksum is stored in that case).
+"""
+import copy
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import ref_shims                                   # noqa: E402
+from det_weights import fill_state_dict, seeded_array   # noqa: E402
+from make_golden_cases import DLOGITS_STRIDE, INTEGRAL_CASES, NETWORK_CASES   # noqa: E402
+from epipolarpose_amd.synthetic import SyntheticScenes  # noqa: E402
+
+REF = ref_shims.load_reference()
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024.0))
+
+
+# --------------------------------------------------------------------------------------------------
+# 1. integral regression: soft-argmax, criteria, autograd gradients, decode
+# --------------------------------------------------------------------------------------------------
+
+def gen_integral():
+    il = REF.integral_loss
+    out = {}
+    for name, b, j, d, h, w, sc in INTEGRAL_CASES:
+        logits = seeded_array("logits/" + name, (b, j * d, h, w), scale=sc)
+        gt = seeded_array("gt/" + name, (b, 3 * j), scale=0.25)
+        wt = (np.abs(seeded_array("wt/" + name, (b, 3 * j))) > 0.15).astype(np.float32)   # ~12 % zeros
+        big = logits.size > 20000     # big inputs are regenerated from the seed; only a checksum is stored
+        if big:
+            out[name + "/logits_crc"] = np.uint32(zlib.crc32(logits.tobytes()))
+        else:
+            out[name + "/logits"] = logits
+        out[name + "/gt"] = gt
+        out[name + "/wt"] = wt
+        t = torch.from_numpy(logits)
+        out[name + "/xyz"] = il.softmax_integral_tensor(t, j, True, w, h, d).numpy()
+        for kind, fn, cls in (("l1", il.weighted_l1_loss, il.L1JointLocationLoss),
+                              ("smoothl1", il.weighted_smooth_l1_loss, il.SmoothL1JointLocationLoss),
+                              ("l2", il.weighted_mse_loss, None)):
+            for norm in (False, True):
+                tl = torch.from_numpy(logits).clone().requires_grad_(True)
+                if cls is not None:
+                    loss = cls(num_joints=j, norm=norm)(tl, torch.from_numpy(gt), torch.from_numpy(wt))
+                else:   # L2JointLocationLoss.forward is broken in the reference (integral_loss.py:110-112);
+                        # its pieces are not: compose them the way the class intends.
+                    pj = il.softmax_integral_tensor(tl, j, True, w, h, d)
+                    loss = fn(pj, torch.from_numpy(gt), torch.from_numpy(wt), True, norm)
+                loss.backward()
+                key = "%s/%s/norm%d" % (name, kind, int(norm))
+                out[key + "/loss"] = np.float32(loss.item())
+                g = tl.grad.numpy()
+                out[key + "/dlogits"] = g.reshape(-1)[::DLOGITS_STRIDE] if big else g
+        if d == w:   # get_joint_location_result infers D = W (integral_loss.py:191)
+            out[name + "/decode256"] = il.get_joint_location_result(256, 256, torch.from_numpy(logits))
+    # label codec
+    joints = np.random.default_rng(5).uniform(-100, 300, size=(17, 3))
+    lab, vis = il.generate_joint_location_label(256., 256., joints.copy(), np.ones((17, 3)))
+    out["label/joints"] = joints
+    out["label/label"] = lab
+    out["label/reverse"] = il.reverse_joint_location_label(256., 256., lab.copy())
+    save("integral.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+# 2. triangulation (reference control flow; cv2 primitives stubbed)
+# --------------------------------------------------------------------------------------------------
+def ref_camera(cam):
+    return REF.cameras.Camera((cam["R"], cam["T"], cam["f"], cam["c"], None, None, "synthetic"))
+
+
+def gen_triangulation():
+    tri = REF.triangulation
+    out = {}
+    sc = SyntheticScenes(n_group=3, n_view=4, num_joints=17, seed=11, noise_px=0.0)
+    ps = np.stack([ref_camera(c).projection_matrix for c in sc.cams])          # live cameras.py:126-131
+    out["P"] = ps
+    out["P_ours"] = np.stack([c["projection_matrix"] for c in sc.cams])
+    out["world"] = sc.world
+    rng = np.random.default_rng(3)
+    for noise in (0.0, 2.0):
+        u = np.stack([np.stack([REF_project(sc.world[g], sc.cams[v]) for g in range(3)]) for v in range(4)])
+        u = u + rng.normal(0, noise, size=u.shape) if noise > 0 else u         # [V,G,J,2]
+        out["u/noise%d" % int(noise)] = u
+        for (va, vb) in ((0, 1), (0, 3), (1, 2)):
+            for g in range(3):
+                tag = "noise%d/v%d%d/g%d" % (int(noise), va, vb, g)
+                x, st = tri.iterative_LS_triangulation(u[va, g], ps[va], u[vb, g], ps[vb])
+                out[tag + "/iter_x"], out[tag + "/iter_status"] = x, st
+                x, st = tri.linear_LS_triangulation(u[va, g], ps[va], u[vb, g], ps[vb])
+                out[tag + "/ls_x"] = x
+                x, st = tri.linear_eigen_triangulation(u[va, g], ps[va], u[vb, g], ps[vb])
+                out[tag + "/eigen_x"], out[tag + "/eigen_status"] = x, st
+    # points behind one / both cameras -> status codes -1, -2, -3 (triangulation.py:176-179)
+    cam0, cam1 = sc.cams[0], sc.cams[1]
+    pts = np.array([[0.0, 0.0, 900.0],
+                    cam0["T"].reshape(3) * 1.3,                     # behind camera 0
+                    cam1["T"].reshape(3) * 1.3,                     # behind camera 1
+                    (cam0["T"].reshape(3) + cam1["T"].reshape(3)) * 2.0 + [0, 0, 5000.0]])
+    u0 = REF_project(pts, cam0)
+    u1 = REF_project(pts, cam1)
+    x, st = tri.iterative_LS_triangulation(u0, ps[0], u1, ps[1])
+    out["behind/u0"], out["behind/u1"], out["behind/x"], out["behind/status"] = u0, u1, x, st
+    save("triangulation.npz", **out)
+
+
+def REF_project(x_world, cam):
+    """Pinhole projection through the reference's CamProj (prep_h36m.py:170-175)."""
+    xc = (x_world - cam["T"].reshape(3)) @ cam["R"].T
+    u, v = REF.prep_h36m.CamProj(xc[:, 0], xc[:, 1], xc[:, 2], cam["f"][0], cam["f"][1], cam["c"][0], cam["c"][1])
+    return np.stack([u, v], axis=1)
+
+
+# --------------------------------------------------------------------------------------------------
+# 3. crop affine, re-projection, full self_supervision
+# --------------------------------------------------------------------------------------------------
+def torch_meta(meta):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in meta.items()}
+
+
+def gen_geometry():
+    iu = REF.img_utils
+    out = {}
+    rng = np.random.default_rng(21)
+    params = []
+    for _ in range(12):
+        params.append([rng.uniform(300, 700), rng.uniform(300, 700), rng.uniform(250, 600), rng.uniform(250, 600),
+                       np.clip(rng.normal(), -1, 1) * 0.25 + 1.0,
+                       np.clip(rng.normal(), -2, 2) * 30.0 if rng.random() < 0.7 else 0.0])
+    params = np.asarray(params)
+    out["affine/params"] = params
+    out["affine/fwd"] = np.stack([iu.gen_trans_from_patch_cv(p[0], p[1], p[2], p[3], 256, 256, p[4], p[5], inv=False)
+                                  for p in params])
+    out["affine/inv"] = np.stack([iu.gen_trans_from_patch_cv(p[0], p[1], p[2], p[3], 256, 256, p[4], p[5], inv=True)
+                                  for p in params])
+    coords = np.concatenate([rng.uniform(0, 256, size=(12, 17, 2)), rng.uniform(-128, 128, size=(12, 17, 1)),
+                             np.ones((12, 17, 1))], axis=2)
+    out["decode/coords_patch"] = coords
+    out["decode/coords_img"] = np.stack([
+        iu.trans_coords_from_patch_to_org_3d(coords[i], p[0], p[1], p[2], p[3], 256, 256, 2000, 2000,
+                                             scale=p[4], rot=p[5]) for i, p in enumerate(params)])
+
+    for n_group, j, tag in ((3, 17, "h36m"), (2, 16, "mpii")):
+        sc = SyntheticScenes(n_group=n_group, n_view=2, num_joints=j, seed=31 + j, noise_px=0.0)
+        meta = torch_meta(sc.meta)
+        # world -> image joints (prep_h36m.py:177-204)
+        r = REF.prep_h36m.from_worldjt_to_imagejt(j, sc.meta["R"][0], sc.world[0], sc.meta["T"][0], sc.meta["f"][0],
+                                                  sc.meta["c"][0], 2000., 2000.)
+        out[tag + "/w2i/pt2d"], out[tag + "/w2i/pt3d"] = r[4], r[5]
+        out[tag + "/w2i/rect"] = np.array(r[0:4])
+        # labels from (exact) global coordinates == the generator's own labels
+        x_world = np.concatenate([sc.world] * 2, axis=0)
+        lab, wt = iu.get_batch_labels_from_global_coords(x_world, meta)
+        out[tag + "/labels_from_world/label"], out[tag + "/labels_from_world/weight"] = lab, wt
+        out[tag + "/scene_label"] = sc.label
+        # triangulate() on noisy decoded coordinates
+        cp = sc.patch_coords(noise_px=1.5, seed=7)
+        kps_img = np.stack([iu.trans_coords_from_patch_to_org_3d(
+            cp[n], sc.meta["center_x"][n], sc.meta["center_y"][n], sc.meta["width"][n], sc.meta["height"][n],
+            256, 256, 2000, 2000, scale=sc.meta["scale"][n], rot=sc.meta["rot"][n]) for n in range(sc.batch_size)])
+        out[tag + "/ss/coords_patch"] = cp
+        out[tag + "/ss/kps_img"] = kps_img
+        xw = iu.triangulate(kps_img, meta)
+        out[tag + "/ss/x_world"] = xw
+        lab, wt = iu.get_batch_labels_from_global_coords(xw, meta)
+        out[tag + "/ss/label"], out[tag + "/ss/weight"] = lab, wt
+
+    # full self_supervision(preds, meta) from logits: D = H = W = 16 (D must equal W, integral_loss.py:191)
+    sc = SyntheticScenes(n_group=2, n_view=2, num_joints=5, seed=77)
+    logits = sc.peaked_logits(depth=16, hm=16, gain=12.0, sigma=1.5)
+    logits = logits + seeded_array("ss/noise", logits.shape, scale=0.3)
+    out["ss_full/logits"] = logits.astype(np.float32)
+    lab, wt = iu.self_supervision(torch.from_numpy(logits.astype(np.float32)), torch_meta(sc.meta))
+    out["ss_full/label"], out["ss_full/weight"] = lab, wt
+    save("geometry.npz", **out)
+
+
+# --------------------------------------------------------------------------------------------------
+# 4. arg-max decode
+# --------------------------------------------------------------------------------------------------
+def gen_maxpreds():
+    hm = seeded_array("maxpreds", (3, 6, 8, 12))
+    hm[0, 0] = -np.abs(hm[0, 0])                 # all negative  -> masked to 0
+    hm[0, 1, 2, 3] = hm[0, 1, 5, 7] = 9.0        # tie -> first index wins
+    hm[1, 2] = 0.0                               # all zero -> idx 0, masked
+    preds, maxvals = REF.inference.get_max_preds(hm)
+    save("maxpreds.npz", heatmaps=hm, preds=preds, maxvals=maxvals)
+
+
+# --------------------------------------------------------------------------------------------------
+# 5. the network (reference PoseResNet, deterministic weights)
+# --------------------------------------------------------------------------------------------------
+
+def ref_cfg(layers, image, joints, depth):
+    cfg = copy.deepcopy(REF.config.config)
+    cfg.MODEL.NUM_JOINTS = joints
+    cfg.MODEL.DEPTH_RES = depth
+    cfg.MODEL.IMAGE_SIZE = [image, image]
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    return cfg
+
+
+def gen_network():
+    out = {}
+    for name, layers, image, j, d, b in NETWORK_CASES:
+        model = REF.pose3d_resnet.get_pose_net(ref_cfg(layers, image, j, d), is_train=True)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        out[name + "/keys"] = np.array(list(shapes.keys()))
+        out[name + "/shapes"] = np.array([str(s) for s in shapes.values()])
+        model.load_state_dict(fill_state_dict(shapes, seed=1))
+        x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image)))
+        gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2))
+        wt = torch.ones(b, 3 * j)
+        model.eval()
+        with torch.no_grad():
+            out[name + "/logits_eval"] = model(x).numpy()
+        model.train()
+        logits = model(x)
+        out[name + "/logits_train"] = logits.detach().numpy()
+        loss = REF.integral_loss.SmoothL1JointLocationLoss(num_joints=j)(logits, gt, wt)
+        loss.backward()
+        out[name + "/loss"] = np.float32(loss.item())
+        sd = model.state_dict()
+        out[name + "/bn1.running_mean"] = sd["bn1.running_mean"].numpy()
+        out[name + "/deconv_layers.7.running_var"] = sd["deconv_layers.7.running_var"].numpy()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.7.weight",
+                  "deconv_layers.0.weight", "conv1.weight"):
+            g = grads[k].numpy()
+            out[name + "/grad/" + k] = g if g.size <= 70000 else g.reshape(-1)[:: max(1, g.size // 50000)]
+        out[name + "/gradnorm"] = np.array([float(g.norm()) for g in grads.values()])
+    save("network.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network"]
+    for w in which:
+        globals()["gen_" + w]()
