@@ -1,0 +1,500 @@
+// Self-supervision geometry on the device: crop affine, patch->image decode, multi-view triangulation
+// (iterative LS / linear LS / homogeneous DLT) and re-projection into per-view pseudo labels.
+//
+// Replaces the host-side Python loops of the reference (four nested loops: pair x joint x <=10
+// iterations x cv2.solve, after a blocking D2H copy):
+//   lib/utils/img_utils.py:63-111,141-243, lib/utils/triangulation.py:8-181, lib/utils/prep_h36m.py:170-204.
+// One thread owns one (group, joint); the fused kernel keeps the whole SS step in ONE launch.
+#include "common.h"
+
+namespace epi {
+
+struct Aff { double a00, a01, a02, a10, a11, a12; };
+
+// img_utils.py:72-105 (gen_trans_from_patch_cv) with its float32 roundings (:82-83,87-99), then the exact
+// affine through the three point pairs (cv2.getAffineTransform) in closed form: the patch-side triple is
+// axis aligned, so  org = s0 + (px-dcx)/dhw * (s2-s0) + (py-dcy)/dhh * (s1-s0).
+__device__ __forceinline__ void patch_affines(double cx, double cy, double bw, double bh, double scale, double rot,
+                                              double pw, double ph, Aff* inv, Aff* fwd) {
+    const double rot_rad = 3.141592653589793 * rot / 180.0;
+    const double sn = sin(rot_rad), cs = cos(rot_rad);
+    const double hh = (double)(float)(bh * scale * 0.5);
+    const double hw = (double)(float)(bw * scale * 0.5);
+    const double dnx = (double)(float)(0.0 * cs - hh * sn), dny = (double)(float)(0.0 * sn + hh * cs);
+    const double rtx = (double)(float)(hw * cs - 0.0 * sn), rty = (double)(float)(hw * sn + 0.0 * cs);
+    const double s0x = (double)(float)cx, s0y = (double)(float)cy;
+    const double s1x = (double)(float)(cx + dnx), s1y = (double)(float)(cy + dny);
+    const double s2x = (double)(float)(cx + rtx), s2y = (double)(float)(cy + rty);
+    const float dcx = (float)(pw * 0.5), dcy = (float)(ph * 0.5);
+    const double dhw = (double)((dcx + (float)(pw * 0.5)) - dcx);
+    const double dhh = (double)((dcy + (float)(ph * 0.5)) - dcy);
+    const double exx = (s2x - s0x) / dhw, exy = (s2y - s0y) / dhw;     // image of the patch x axis
+    const double eyx = (s1x - s0x) / dhh, eyy = (s1y - s0y) / dhh;     // image of the patch y axis
+    Aff a;
+    a.a00 = exx; a.a01 = eyx; a.a02 = s0x - exx * (double)dcx - eyx * (double)dcy;
+    a.a10 = exy; a.a11 = eyy; a.a12 = s0y - exy * (double)dcx - eyy * (double)dcy;
+    if (inv) *inv = a;
+    if (fwd) {
+        const double det = a.a00 * a.a11 - a.a01 * a.a10;
+        const double i00 = a.a11 / det, i01 = -a.a01 / det, i10 = -a.a10 / det, i11 = a.a00 / det;
+        fwd->a00 = i00; fwd->a01 = i01; fwd->a02 = -(i00 * a.a02 + i01 * a.a12);
+        fwd->a10 = i10; fwd->a11 = i11; fwd->a12 = -(i10 * a.a02 + i11 * a.a12);
+    }
+}
+
+// Least squares of an (R x 3) system by Householder QR, in place (stand-in for cv2.solve(DECOMP_SVD),
+// triangulation.py:95,155 -- identical for full column rank).  Rows beyond the used views are zero.
+template <typename T, int R>
+__device__ __forceinline__ void qr_solve3(T (&A)[R][3], T (&b)[R], T (&x)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T nrm2 = 0;
+#pragma unroll
+        for (int i = k; i < R; ++i) nrm2 += A[i][k] * A[i][k];
+        const T nrm = sqrt(nrm2);
+        const T akk = A[k][k];
+        const T alpha = (akk > 0) ? -nrm : nrm;
+        const T vk = akk - alpha;
+        const T vn2 = nrm2 - akk * akk + vk * vk;       // |v|^2
+        const T inv = (vn2 > 0) ? (T)2 / vn2 : (T)0;
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            T dot = vk * A[k][j];
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) dot += A[i][k] * A[i][j];
+            const T f = dot * inv;
+            A[k][j] -= f * vk;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) A[i][j] -= f * A[i][k];
+        }
+        {
+            T dot = vk * b[k];
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) dot += A[i][k] * b[i];
+            const T f = dot * inv;
+            b[k] -= f * vk;
+#pragma unroll
+            for (int i = k + 1; i < R; ++i) b[i] -= f * A[i][k];
+        }
+        A[k][k] = alpha;
+    }
+    x[2] = b[2] / A[2][2];
+    x[1] = (b[1] - A[1][2] * x[2]) / A[1][1];
+    x[0] = (b[0] - A[0][1] * x[1] - A[0][2] * x[2]) / A[0][0];
+}
+
+// rows of the inhomogeneous system (triangulation.py:138-148): A = C P[:, :3], b = -(C P[:, 3])
+template <typename T, int NV>
+__device__ __forceinline__ void build_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&A)[2 * NV][3], T (&b)[2 * NV]) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool on = v < nv;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) A[2 * v + r][c] = on ? (u[v][r] * P[v][8 + c] - P[v][4 * r + c]) : (T)0;
+            b[2 * v + r] = on ? (P[v][4 * r + 3] - u[v][r] * P[v][11]) : (T)0;
+        }
+    }
+}
+
+template <typename T, int NV>
+__device__ __forceinline__ int tri_linear_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&x)[3]) {
+    T A[2 * NV][3], b[2 * NV];
+    build_ls<T, NV>(u, P, nv, A, b);
+    qr_solve3<T, 2 * NV>(A, b, x);
+    return 1;                                            // triangulation.py:97: status all True
+}
+
+// triangulation.py:104-181
+template <typename T, int NV>
+__device__ __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
+    T A[2 * NV][3], b[2 * NV], d[NV], dn[NV];
+    build_ls<T, NV>(u, P, nv, A, b);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { d[v] = 1; dn[v] = 1; }                         // :151
+    x[0] = x[1] = x[2] = 0;
+    for (int it = 0; it < max_iter; ++it) {                                     // :153
+        T Aw[2 * NV][3], bw[2 * NV];
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) { Aw[i][0] = A[i][0]; Aw[i][1] = A[i][1]; Aw[i][2] = A[i][2]; bw[i] = b[i]; }
+        qr_solve3<T, 2 * NV>(Aw, bw, x);                                         // :155
+        bool conv = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                dn[v] = P[v][8] * x[0] + P[v][9] * x[1] + P[v][10] * x[2] + P[v][11];   // :158-159
+                if (!(fabs(dn[v] - d[v]) <= tol)) conv = false;                 // :161-162
+            }
+        }
+        if (conv) break;                                                         // :163
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                const T w = (T)1 / dn[v];                                        // :166-169 (cumulative)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    A[2 * v + r][0] *= w; A[2 * v + r][1] *= w; A[2 * v + r][2] *= w; b[2 * v + r] *= w;
+                }
+                d[v] = dn[v];                                                    // :172-173
+            }
+        }
+    }
+    bool all_front = true;
+    int code = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+            if (!(dn[v] > 0)) all_front = false;
+            if (dn[v] <= 0) code -= (1 << v);                                    // :178-179
+        }
+    }
+    return all_front ? 1 : code;                                                 // :176-177
+}
+
+// triangulation.py:8-27 == cv2.triangulatePoints: homogeneous 2Vx4 system, right-singular vector of the
+// smallest singular value.  One-sided (Hestenes) Jacobi SVD in float64 on the columns of M.
+template <int NV>
+__device__ __forceinline__ int tri_dlt(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
+    double M[4][2 * NV];      // column-major: M[c][row]
+    double Vm[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const bool on = v < nv;
+            M[c][2 * v] = on ? (u[v][0] * P[v][8 + c] - P[v][c]) : 0.0;
+            M[c][2 * v + 1] = on ? (u[v][1] * P[v][8 + c] - P[v][4 + c]) : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vm[c][r] = (r == c) ? 1.0 : 0.0;     // Vm[c] = c-th column of V
+    }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int i = 0; i < 2 * NV; ++i) { al += M[p][i] * M[p][i]; be += M[q][i] * M[q][i]; ga += M[p][i] * M[q][i]; }
+                if (fabs(ga) > 4e-16 * sqrt(al * be)) {
+                    rotated = true;
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = ((zeta >= 0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int i = 0; i < 2 * NV; ++i) {
+                        const double mp = M[p][i], mq = M[q][i];
+                        M[p][i] = c * mp - s * mq;
+                        M[q][i] = s * mp + c * mq;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double vp = Vm[p][i], vq = Vm[q][i];
+                        Vm[p][i] = c * vp - s * vq;
+                        Vm[q][i] = s * vp + c * vq;
+                    }
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    int best = 0;
+    double bn = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double n2 = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) n2 += M[c][i] * M[c][i];
+        if (c == 0 || n2 < bn) { bn = n2; best = c; }
+    }
+    double h[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (c == best) { h[0] = Vm[c][0]; h[1] = Vm[c][1]; h[2] = Vm[c][2]; h[3] = Vm[c][3]; }
+    x[0] = h[0] / h[3]; x[1] = h[1] / h[3]; x[2] = h[2] / h[3];                 // :24
+    const double mx = fmax(fabs(x[0]), fmax(fabs(x[1]), fabs(x[2])));
+    return (mx <= 1.0e16) ? 1 : 0;                                               // :25 (NaN -> 0)
+}
+
+enum { TRI_ITER = 0, TRI_LS = 1, TRI_DLT = 2 };
+
+template <typename T, int NV, int METHOD>
+__device__ __forceinline__ int triangulate_one(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
+    if (METHOD == TRI_ITER) return tri_iterative_ls<T, NV>(u, P, nv, tol, max_iter, x);
+    if (METHOD == TRI_LS) return tri_linear_ls<T, NV>(u, P, nv, x);
+    double ud[NV][2], Pd[NV][12], xd[3];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        ud[v][0] = (double)u[v][0]; ud[v][1] = (double)u[v][1];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Pd[v][k] = (double)P[v][k];
+    }
+    const int st = tri_dlt<NV>(ud, Pd, nv, xd);
+    x[0] = (T)xd[0]; x[1] = (T)xd[1]; x[2] = (T)xd[2];
+    return st;
+}
+
+template <typename T, int NV, int METHOD>
+__global__ __launch_bounds__(256) void triangulate_kernel(const T* __restrict__ kps, int kstride, const T* __restrict__ Pm,
+                                                          int G, int V, int J, T tol, int max_iter, T* __restrict__ X,
+                                                          int* __restrict__ status) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)G * J) return;
+    const int g = (int)(t / J), j = (int)(t - (long long)g * J);
+    T u[NV][2], P[NV][12], x[3];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < V) {
+            const long long s = (long long)v * G + g;                  // img_utils.py:197-202
+            const T* kp = kps + (s * J + j) * kstride;
+            u[v][0] = kp[0]; u[v][1] = kp[1];
+            const T* pp = Pm + s * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P[v][k] = pp[k];
+        } else {
+            u[v][0] = u[v][1] = 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P[v][k] = 0;
+        }
+    }
+    const int st = triangulate_one<T, NV, METHOD>(u, P, V, tol, max_iter, x);
+    X[3 * t] = x[0]; X[3 * t + 1] = x[1]; X[3 * t + 2] = x[2];
+    if (status) status[t] = st;
+}
+
+struct MetaDev {
+    const double *cx, *cy, *w, *h, *scale, *rot, *R, *T, *f, *c, *P;
+};
+
+__global__ void decode_kernel(const float* __restrict__ xyz, int B, int J, MetaDev m, double pw, double ph, double rect3d,
+                              double* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * J) return;
+    const int n = (int)(t / J);
+    Aff inv;
+    patch_affines(m.cx[n], m.cy[n], m.w[n], m.h[n], m.scale[n], m.rot[n], pw, ph, &inv, nullptr);
+    // integral_loss.py:196-201: float32 coords -> float64, (x+.5)*pw, (y+.5)*ph, z*pw
+    const double px = ((double)xyz[3 * t] + 0.5) * pw, py = ((double)xyz[3 * t + 1] + 0.5) * ph, pz = (double)xyz[3 * t + 2] * pw;
+    out[3 * t] = inv.a00 * px + inv.a01 * py + inv.a02;                         // img_utils.py:108-111
+    out[3 * t + 1] = inv.a10 * px + inv.a11 * py + inv.a12;
+    out[3 * t + 2] = pz / pw * rect3d;                                          // img_utils.py:154
+}
+
+// prep_h36m.py:177-204 + img_utils.py:232-238 + integral_loss.py:170-177 for one (sample, joint)
+__device__ __forceinline__ void reproject_one(const double (&X)[3], const double (&Xroot)[3], const double* R, const double* T,
+                                              const double* f, const double* c, const Aff& fwd, double scale, double pw,
+                                              double ph, double rect3d, float* lab) {
+    const double dx = X[0] - T[0], dy = X[1] - T[1], dz = X[2] - T[2];
+    const double camx = R[0] * dx + R[1] * dy + R[2] * dz;
+    const double camy = R[3] * dx + R[4] * dy + R[5] * dz;
+    const double camz = R[6] * dx + R[7] * dy + R[8] * dz;
+    const double rz = R[6] * (Xroot[0] - T[0]) + R[7] * (Xroot[1] - T[1]) + R[8] * (Xroot[2] - T[2]);
+    const double iu = camx / camz * f[0] + c[0];                                // CamProj, prep_h36m.py:170-175
+    const double iv = camy / camz * f[1] + c[1];
+    const double z = camz - rz;                                                 // :200
+    const double pu = fwd.a00 * iu + fwd.a01 * iv + fwd.a02;                    // img_utils.py:235
+    const double pv = fwd.a10 * iu + fwd.a11 * iv + fwd.a12;
+    const double pz = z / (rect3d * scale) * pw;                                // img_utils.py:236
+    lab[0] = (float)(pu / pw - 0.5);                                            // integral_loss.py:171-173
+    lab[1] = (float)(pv / ph - 0.5);
+    lab[2] = (float)(pz / pw);
+}
+
+__global__ void reproject_kernel(const double* __restrict__ X, int G, int V, int J, MetaDev m, double pw, double ph,
+                                 double rect3d, int root, float* __restrict__ label, float* __restrict__ weight) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)G * V * J) return;
+    const int n = (int)(t / J), j = (int)(t - (long long)n * J);
+    const int g = n % G;
+    Aff fwd;
+    patch_affines(m.cx[n], m.cy[n], m.w[n], m.h[n], m.scale[n], m.rot[n], pw, ph, nullptr, &fwd);
+    double x[3], xr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { x[k] = X[((long long)g * J + j) * 3 + k]; xr[k] = X[((long long)g * J + root) * 3 + k]; }
+    float lab[3];
+    reproject_one(x, xr, m.R + 9LL * n, m.T + 3LL * n, m.f + 2LL * n, m.c + 2LL * n, fwd, m.scale[n], pw, ph, rect3d, lab);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { label[3 * t + k] = lab[k]; weight[3 * t + k] = 1.f; }   // img_utils.py:238 (vis = ones)
+}
+
+// img_utils.py:166-190 in one launch.  A workgroup owns GPB consecutive groups; LDS holds both crop
+// affines of every sample of those groups and the triangulated joints (the root joint is needed by all).
+constexpr int SS_THREADS = 256;
+
+template <int NV, int METHOD>
+__global__ __launch_bounds__(SS_THREADS) void self_supervision_kernel(const float* __restrict__ xyz, int G, int V, int J, int GPB,
+                                                                      MetaDev m, double pw, double ph, double rect3d, int root,
+                                                                      double tol, int max_iter, float* __restrict__ label,
+                                                                      float* __restrict__ weight, double* __restrict__ Xout) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Aff* inv_s = reinterpret_cast<Aff*>(smem_raw);                  // [GPB*V]
+    Aff* fwd_s = inv_s + GPB * V;                                   // [GPB*V]
+    double* Xs = reinterpret_cast<double*>(fwd_s + GPB * V);        // [GPB*J*3]
+    const int g0 = blockIdx.x * GPB;
+    const int ng = min(GPB, G - g0);
+    for (int s = threadIdx.x; s < ng * V; s += SS_THREADS) {
+        const int gl = s % ng, v = s / ng;
+        const long long n = (long long)v * G + g0 + gl;
+        patch_affines(m.cx[n], m.cy[n], m.w[n], m.h[n], m.scale[n], m.rot[n], pw, ph, &inv_s[gl * V + v], &fwd_s[gl * V + v]);
+    }
+    __syncthreads();
+    const int gl = threadIdx.x / J, j = threadIdx.x - gl * J;
+    const bool active = gl < ng;
+    if (active) {
+        double u[NV][2], P[NV][12], x[3];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < V) {
+                const long long n = (long long)v * G + g0 + gl;
+                const float* q = xyz + (n * J + j) * 3;
+                const double px = ((double)q[0] + 0.5) * pw, py = ((double)q[1] + 0.5) * ph;
+                const Aff a = inv_s[gl * V + v];
+                u[v][0] = a.a00 * px + a.a01 * py + a.a02;
+                u[v][1] = a.a10 * px + a.a11 * py + a.a12;
+                const double* pp = m.P + n * 12;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) P[v][k] = pp[k];
+            } else {
+                u[v][0] = u[v][1] = 0;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) P[v][k] = 0;
+            }
+        }
+        triangulate_one<double, NV, METHOD>(u, P, V, tol, max_iter, x);
+        double* xs = Xs + (gl * J + j) * 3;
+        xs[0] = x[0]; xs[1] = x[1]; xs[2] = x[2];
+        if (Xout) {
+            double* xo = Xout + ((long long)(g0 + gl) * J + j) * 3;
+            xo[0] = x[0]; xo[1] = x[1]; xo[2] = x[2];
+        }
+    }
+    __syncthreads();
+    if (active) {
+        double x[3], xr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { x[k] = Xs[(gl * J + j) * 3 + k]; xr[k] = Xs[(gl * J + root) * 3 + k]; }
+        for (int v = 0; v < V; ++v) {
+            const long long n = (long long)v * G + g0 + gl;
+            float lab[3];
+            reproject_one(x, xr, m.R + 9 * n, m.T + 3 * n, m.f + 2 * n, m.c + 2 * n, fwd_s[gl * V + v], m.scale[n], pw, ph, rect3d, lab);
+            float* lo = label + (n * J + j) * 3;
+            float* wo = weight + (n * J + j) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = lab[k]; wo[k] = 1.f; }
+        }
+    }
+}
+
+static inline bool meta_ok(const epi_view_meta* m, bool need_cam, bool need_p) {
+    if (!m || !m->center_x || !m->center_y || !m->width || !m->height || !m->scale || !m->rot) return false;
+    if (need_cam && (!m->R || !m->T || !m->f || !m->c)) return false;
+    if (need_p && !m->P) return false;
+    return true;
+}
+static inline MetaDev to_dev(const epi_view_meta* m) {
+    MetaDev d;
+    d.cx = m->center_x; d.cy = m->center_y; d.w = m->width; d.h = m->height; d.scale = m->scale; d.rot = m->rot;
+    d.R = m->R; d.T = m->T; d.f = m->f; d.c = m->c; d.P = m->P;
+    return d;
+}
+
+template <typename T, int METHOD>
+static int launch_tri(const void* kps, int kstride, const void* P, int G, int V, int J, double tol, int max_iter, void* X,
+                      int32_t* status, hipStream_t st) {
+    const long long total = (long long)G * J;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+#define EPI_TRI_LAUNCH(NVV)                                                                                               \
+    hipLaunchKernelGGL((triangulate_kernel<T, NVV, METHOD>), dim3(grid), dim3(256), 0, st, (const T*)kps, kstride, (const T*)P, \
+                       G, V, J, (T)tol, max_iter, (T*)X, (int*)status)
+    if (V == 2) EPI_TRI_LAUNCH(2);
+    else if (V <= 4) EPI_TRI_LAUNCH(4);
+    else EPI_TRI_LAUNCH(8);
+#undef EPI_TRI_LAUNCH
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+template <int METHOD>
+static int tri_entry(const void* kps, int kstride, const void* P, int dtype, int G, int V, int J, double tol, int max_iter,
+                     void* X, int32_t* status, epi_stream_t stream) {
+    if (!kps || !P || !X || G <= 0 || J <= 0 || kstride < 2) return EPI_ERR_INVALID_ARGUMENT;
+    if (V < 2 || V > 8) return EPI_ERR_UNSUPPORTED;
+    if ((long long)G * J > 0x7fffffffLL * 128) return EPI_ERR_UNSUPPORTED;
+    if (dtype == EPI_F64) return launch_tri<double, METHOD>(kps, kstride, P, G, V, J, tol, max_iter, X, status, (hipStream_t)stream);
+    if (dtype == EPI_F32) return launch_tri<float, METHOD>(kps, kstride, P, G, V, J, tol, max_iter, X, status, (hipStream_t)stream);
+    return EPI_ERR_UNSUPPORTED;
+}
+
+}  // namespace epi
+
+using namespace epi;
+
+extern "C" int epi_triangulate_iterls(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
+                                      double tolerance, int max_iter, void* X, int32_t* status, epi_stream_t stream) {
+    if (max_iter < 1) return EPI_ERR_INVALID_ARGUMENT;
+    return tri_entry<TRI_ITER>(kps, kps_stride, P, dtype, G, V, J, tolerance, max_iter, X, status, stream);
+}
+extern "C" int epi_triangulate_ls(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J, void* X,
+                                  int32_t* status, epi_stream_t stream) {
+    return tri_entry<TRI_LS>(kps, kps_stride, P, dtype, G, V, J, 0.0, 1, X, status, stream);
+}
+extern "C" int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J, void* X,
+                                   int32_t* status, epi_stream_t stream) {
+    return tri_entry<TRI_DLT>(kps, kps_stride, P, dtype, G, V, J, 0.0, 1, X, status, stream);
+}
+
+extern "C" int epi_decode_to_image(const float* xyz, int B, int J, const epi_view_meta* meta_host, double patch_w,
+                                   double patch_h, double rect3d, double* kps_img, epi_stream_t stream) {
+    if (!xyz || !kps_img || B <= 0 || J <= 0 || !meta_ok(meta_host, false, false)) return EPI_ERR_INVALID_ARGUMENT;
+    const long long total = (long long)B * J;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xyz, B, J,
+                       to_dev(meta_host), patch_w, patch_h, rect3d, kps_img);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_reproject_labels(const double* X, int G, int V, int J, const epi_view_meta* meta_host, double patch_w,
+                                    double patch_h, double rect3d, int root_joint, float* label, float* weight,
+                                    epi_stream_t stream) {
+    if (!X || !label || !weight || G <= 0 || V <= 0 || J <= 0 || root_joint < 0 || root_joint >= J ||
+        !meta_ok(meta_host, true, false))
+        return EPI_ERR_INVALID_ARGUMENT;
+    const long long total = (long long)G * V * J;
+    hipLaunchKernelGGL(reproject_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, G, V, J,
+                       to_dev(meta_host), patch_w, patch_h, rect3d, root_joint, label, weight);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+template <int NV>
+static int launch_ss(const float* xyz, int G, int V, int J, MetaDev m, double pw, double ph, double rect3d, int root, int method,
+                     double tol, int max_iter, float* label, float* weight, double* Xout, hipStream_t st) {
+    const int GPB = SS_THREADS / J;
+    const unsigned grid = (unsigned)((G + GPB - 1) / GPB);
+    const size_t lds = (size_t)GPB * V * 2 * sizeof(Aff) + (size_t)GPB * J * 3 * sizeof(double);
+#define EPI_SS_LAUNCH(M)                                                                                                   \
+    hipLaunchKernelGGL((self_supervision_kernel<NV, M>), dim3(grid), dim3(SS_THREADS), lds, st, xyz, G, V, J, GPB, m, pw, ph, \
+                       rect3d, root, tol, max_iter, label, weight, Xout)
+    if (method == TRI_ITER) EPI_SS_LAUNCH(TRI_ITER);
+    else if (method == TRI_LS) EPI_SS_LAUNCH(TRI_LS);
+    else EPI_SS_LAUNCH(TRI_DLT);
+#undef EPI_SS_LAUNCH
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_meta* meta_host, double patch_w,
+                                    double patch_h, double rect3d, int root_joint, int method, double tolerance, int max_iter,
+                                    float* label, float* weight, double* X_out, epi_stream_t stream) {
+    if (!xyz || !label || !weight || G <= 0 || J <= 0 || root_joint < 0 || root_joint >= J || !meta_ok(meta_host, true, true))
+        return EPI_ERR_INVALID_ARGUMENT;
+    if (method < 0 || method > 2 || max_iter < 1) return EPI_ERR_INVALID_ARGUMENT;
+    if (V < 2 || V > 8 || J > SS_THREADS) return EPI_ERR_UNSUPPORTED;
+    const MetaDev m = to_dev(meta_host);
+    hipStream_t st = (hipStream_t)stream;
+    if (V == 2) return launch_ss<2>(xyz, G, V, J, m, patch_w, patch_h, rect3d, root_joint, method, tolerance, max_iter, label, weight, X_out, st);
+    if (V <= 4) return launch_ss<4>(xyz, G, V, J, m, patch_w, patch_h, rect3d, root_joint, method, tolerance, max_iter, label, weight, X_out, st);
+    return launch_ss<8>(xyz, G, V, J, m, patch_w, patch_h, rect3d, root_joint, method, tolerance, max_iter, label, weight, X_out, st);
+}

@@ -1,0 +1,281 @@
+"""ctypes binding of libepipolar_hip.so (the C ABI declared in include/epipolar_hip.h).
+
+This is the only way the package reaches the device kernels.  There is NO CPU fallback: if the shared
+library is missing or a tensor is not on the GPU, the call raises.  PyTorch is used as plumbing only
+(device memory, the current HIP stream).
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libepipolar_hip.so")
+_lib = None
+
+EPI_F32, EPI_BF16, EPI_F64 = 0, 1, 2
+EPI_NCHW, EPI_NHWC = 0, 1
+LOSS_KINDS = {"l1": 0, "l2": 1, "smoothl1": 2}
+TRI_METHODS = {"iterative": 0, "ls": 1, "dlt": 2}
+
+_vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
+
+
+class EpiViewMeta(ctypes.Structure):
+    _fields_ = [(k, _vp) for k in ("center_x", "center_y", "width", "height", "scale", "rot", "R", "T", "f", "c", "P")]
+
+
+_SIGNATURES = {
+    "epi_version": (ctypes.c_char_p, []),
+    "epi_status_string": (ctypes.c_char_p, [_i]),
+    "epi_softargmax3d_workspace_bytes": (_sz, [_i] * 5),
+    "epi_softargmax3d_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "epi_softargmax3d_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epi_joint_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_argmax_workspace_bytes": (_sz, [_i, _i]),
+    "epi_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_decode_to_image": (_i, [_vp, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _vp, _vp]),
+    "epi_triangulate_iterls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp]),
+    "epi_triangulate_ls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
+    "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built (python -m epipolarpose_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("libepipolar_hip.so not found at %s -- build it with `python -m epipolarpose_amd.build` "
+                               "(there is no CPU fallback)" % _LIB_PATH)
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed: %s" % (what, load().epi_status_string(status).decode()))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (no CPU fallback in epipolarpose_amd)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _logits_format(logits):
+    """(dtype enum, layout enum, dense tensor) for a [B, C, H, W] logits tensor in either memory format."""
+    if logits.dim() != 4:
+        raise ValueError("logits must be [B, J*D, H, W]")
+    if logits.dtype == torch.float32:
+        dt = EPI_F32
+    elif logits.dtype == torch.bfloat16:
+        dt = EPI_BF16
+    else:
+        raise TypeError("logits must be float32 or bfloat16, got %s" % logits.dtype)
+    if logits.is_contiguous():
+        return dt, EPI_NCHW, logits
+    if logits.is_contiguous(memory_format=torch.channels_last):
+        return dt, EPI_NHWC, logits
+    return dt, EPI_NCHW, logits.contiguous()
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    """Per-(device, stream) scratch buffer, grown on demand (allocation is torch's caching allocator)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def softargmax3d_fwd(logits, num_joints):
+    """-> (xyz [B,3J] f32, row_max [B*J] f32, row_sum [B*J] f32).  Reference: integral_loss.py:71-86."""
+    lib = load()
+    _dev(logits, name="logits")
+    dt, layout, logits = _logits_format(logits)
+    b, c, h, w = logits.shape
+    if c % num_joints:
+        raise ValueError("channels %d not divisible by num_joints %d" % (c, num_joints))
+    d = c // num_joints
+    xyz = torch.empty((b, 3 * num_joints), dtype=torch.float32, device=logits.device)
+    rmax = torch.empty((b * num_joints,), dtype=torch.float32, device=logits.device)
+    rsum = torch.empty_like(rmax)
+    nbytes = lib.epi_softargmax3d_workspace_bytes(b, num_joints, d, h, w)
+    ws = _workspace(nbytes, logits.device)
+    with torch.cuda.device(logits.device):
+        _check(lib.epi_softargmax3d_fwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(xyz), _ptr(rmax), _ptr(rsum),
+                                        _ptr(ws), ws.numel(), _stream()), "epi_softargmax3d_fwd")
+    return xyz, rmax, rsum
+
+
+def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_scale=None):
+    """-> dlogits (same dtype / memory format as logits)."""
+    lib = load()
+    _dev(logits, name="logits")
+    dt, layout, logits = _logits_format(logits)
+    b, c, h, w = logits.shape
+    d = c // num_joints
+    grad_xyz = _dev(grad_xyz, torch.float32, "grad_xyz").contiguous()
+    dlogits = torch.empty_like(logits)      # preserves the memory format
+    with torch.cuda.device(logits.device):
+        _check(lib.epi_softargmax3d_bwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(row_max), _ptr(row_sum),
+                                        _ptr(xyz), _ptr(grad_xyz), _ptr(grad_scale), _ptr(dlogits), _stream()),
+               "epi_softargmax3d_bwd")
+    return dlogits
+
+
+def joint_loss(pred, target, weight, kind, norm=False, size_average=True, need_grad=True):
+    """-> (loss 0-dim f32, grad_pred [B,n] f32 or None).  Reference: integral_loss.py:7-47."""
+    lib = load()
+    pred = _dev(pred, torch.float32, "pred").contiguous()
+    target = _dev(target, name="target").to(torch.float32).contiguous()
+    weight = _dev(weight, name="weight").to(torch.float32).contiguous()
+    if pred.shape != target.shape or pred.shape != weight.shape or pred.dim() != 2:
+        raise ValueError("pred/target/weight must share a [B, n] shape")
+    b, n = pred.shape
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if need_grad else None
+    with torch.cuda.device(pred.device):
+        _check(lib.epi_joint_loss(_ptr(pred), _ptr(target), _ptr(weight), b, n, LOSS_KINDS[kind], int(bool(norm)),
+                                  int(bool(size_average)), _ptr(loss), _ptr(grad), _stream()), "epi_joint_loss")
+    return loss, grad
+
+
+def argmax_rows(x):
+    """x [rows, n] f32/bf16 -> (idx int64 [rows], val f32 [rows]); first maximum (inference.py:25-26)."""
+    lib = load()
+    _dev(x, name="x")
+    x = x.contiguous()
+    dt = EPI_F32 if x.dtype == torch.float32 else EPI_BF16 if x.dtype == torch.bfloat16 else None
+    if dt is None:
+        raise TypeError("argmax_rows: float32 or bfloat16 only")
+    rows, n = x.shape
+    idx = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    val = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    nbytes = lib.epi_argmax_workspace_bytes(rows, n)
+    ws = _workspace(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.epi_argmax_rows(_ptr(x), dt, rows, n, _ptr(idx), _ptr(val), _ptr(ws), ws.numel(), _stream()),
+               "epi_argmax_rows")
+    return idx, val
+
+
+class DeviceMeta:
+    """float64 device copies of the per-sample camera / crop arrays + the C struct that points at them."""
+
+    KEYS = ("center_x", "center_y", "width", "height", "scale", "rot", "R", "T", "f", "c", "projection_matrix")
+
+    def __init__(self, meta, device):
+        self.tensors = {}
+        for k in self.KEYS:
+            if k not in meta:
+                continue
+            v = meta[k]
+            t = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+            self.tensors[k] = t.to(device=device, dtype=torch.float64, non_blocking=True).contiguous()
+        self.batch = int(self.tensors["center_x"].shape[0])
+        s = EpiViewMeta()
+        for field, key in (("center_x", "center_x"), ("center_y", "center_y"), ("width", "width"), ("height", "height"),
+                           ("scale", "scale"), ("rot", "rot"), ("R", "R"), ("T", "T"), ("f", "f"), ("c", "c"),
+                           ("P", "projection_matrix")):
+            setattr(s, field, self.tensors[key].data_ptr() if key in self.tensors else None)
+        self.struct = s
+
+
+def decode_to_image(xyz, meta, patch_w=256.0, patch_h=256.0, rect3d=2000.0):
+    """xyz [B,3J] f32 -> kps_img [B,J,3] f64 (u, v, z_mm).  Reference: img_utils.py:141-155,171-185."""
+    lib = load()
+    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    b, j = xyz.shape[0], xyz.shape[1] // 3
+    out = torch.empty((b, j, 3), dtype=torch.float64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _check(lib.epi_decode_to_image(_ptr(xyz), b, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d, _ptr(out),
+                                       _stream()), "epi_decode_to_image")
+    return out
+
+
+def triangulate(kps, proj, n_view, method="iterative", tolerance=3.0e-5, max_iter=10):
+    """kps [B,J,>=2], proj [B,3,4] (f64 or f32, view-major batch) -> (X [G,J,3], status int32 [G,J])."""
+    lib = load()
+    _dev(kps, name="kps")
+    if kps.dtype not in (torch.float64, torch.float32) or proj.dtype != kps.dtype:
+        raise TypeError("kps and proj must both be float64 or both float32")
+    kps, proj = kps.contiguous(), _dev(proj, name="proj").contiguous()
+    b, j, stride = kps.shape
+    if b % n_view:
+        raise ValueError("batch %d is not a multiple of n_view %d" % (b, n_view))
+    g = b // n_view
+    dt = EPI_F64 if kps.dtype == torch.float64 else EPI_F32
+    x = torch.empty((g, j, 3), dtype=kps.dtype, device=kps.device)
+    status = torch.empty((g, j), dtype=torch.int32, device=kps.device)
+    with torch.cuda.device(kps.device):
+        if method == "iterative":
+            st = lib.epi_triangulate_iterls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, tolerance, max_iter, _ptr(x),
+                                            _ptr(status), _stream())
+        elif method == "ls":
+            st = lib.epi_triangulate_ls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
+        elif method == "dlt":
+            st = lib.epi_triangulate_dlt(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
+        else:
+            raise ValueError(method)
+    _check(st, "epi_triangulate_" + method)
+    return x, status
+
+
+def reproject_labels(x_world, meta, n_view, patch_w=256.0, patch_h=256.0, rect3d=2000.0, root_joint=0):
+    """X [G,J,3] f64 -> (label [B,3J] f32, weight [B,3J] f32).  Reference: img_utils.py:212-243."""
+    lib = load()
+    x_world = _dev(x_world, torch.float64, "x_world").contiguous()
+    g, j, _ = x_world.shape
+    b = g * n_view
+    label = torch.empty((b, 3 * j), dtype=torch.float32, device=x_world.device)
+    weight = torch.empty_like(label)
+    with torch.cuda.device(x_world.device):
+        _check(lib.epi_reproject_labels(_ptr(x_world), g, n_view, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d,
+                                        root_joint, _ptr(label), _ptr(weight), _stream()), "epi_reproject_labels")
+    return label, weight
+
+
+def self_supervision(xyz, meta, n_view, method="iterative", patch_w=256.0, patch_h=256.0, rect3d=2000.0, root_joint=0,
+                     tolerance=3.0e-5, max_iter=10, want_world=False):
+    """Fused decode -> triangulate -> re-project.  -> (label, weight[, X]).  Reference: img_utils.py:166-190."""
+    lib = load()
+    xyz = _dev(xyz, torch.float32, "xyz").contiguous()
+    b, j = xyz.shape[0], xyz.shape[1] // 3
+    if b % n_view:
+        raise ValueError("batch %d is not a multiple of n_view %d" % (b, n_view))
+    g = b // n_view
+    label = torch.empty((b, 3 * j), dtype=torch.float32, device=xyz.device)
+    weight = torch.empty_like(label)
+    xw = torch.empty((g, j, 3), dtype=torch.float64, device=xyz.device) if want_world else None
+    with torch.cuda.device(xyz.device):
+        _check(lib.epi_self_supervision(_ptr(xyz), g, n_view, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d,
+                                        root_joint, TRI_METHODS[method], tolerance, max_iter, _ptr(label), _ptr(weight),
+                                        _ptr(xw), _stream()), "epi_self_supervision")
+    return (label, weight, xw) if want_world else (label, weight)

@@ -1,0 +1,48 @@
+"""Two-view (and V-view) triangulation -- mirror of the reference's ``lib/utils/triangulation.py``.
+
+Same call signatures (``f(u1, P1, u2, P2) -> (X [N,3] float64, status [N])``), arithmetic on the GPU
+(``epi_triangulate_*``; float64, one thread per point) instead of per-point ``cv2.solve`` calls.
+"""
+import numpy as np
+import torch
+
+from .. import hip
+
+output_dtype = float
+
+
+def set_triangl_output_dtype(output_dtype_):
+    """triangulation.py:226-231."""
+    global output_dtype
+    output_dtype = output_dtype_
+
+
+def triangulate_views(us, ps, method="iterative", tolerance=3.e-5, max_iter=10, device=None):
+    """us [V,N,2], ps [V,3,4] (array-likes) -> (X [N,3] float64 ndarray, status [N] int32 ndarray)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    us = torch.as_tensor(np.asarray(us, dtype=np.float64), device=device)
+    ps = torch.as_tensor(np.asarray(ps, dtype=np.float64), device=device)
+    n_view, n_pt = us.shape[0], us.shape[1]
+    # one "group" whose J axis carries the N points: batch index = view
+    x, st = hip.triangulate(us.reshape(n_view, n_pt, 2), ps.reshape(n_view, 3, 4), n_view, method, tolerance, max_iter)
+    return x.reshape(n_pt, 3).cpu().numpy().astype(output_dtype), st.reshape(n_pt).cpu().numpy()
+
+
+def iterative_LS_triangulation(u1, P1, u2, P2, tolerance=3.e-5):
+    """triangulation.py:104-181.  status: 1 / 0 / -1 / -2 / -3 as the reference."""
+    x, st = triangulate_views(np.stack([u1, u2]), np.stack([P1[0:3, 0:4], P2[0:3, 0:4]]), "iterative", tolerance)
+    return x, st.astype(int)
+
+
+def linear_LS_triangulation(u1, P1, u2, P2):
+    """triangulation.py:34-97."""
+    x, _ = triangulate_views(np.stack([u1, u2]), np.stack([P1[0:3, 0:4], P2[0:3, 0:4]]), "ls")
+    return x, np.ones(len(u1), dtype=bool)
+
+
+def linear_eigen_triangulation(u1, P1, u2, P2, max_coordinate_value=1.e16):
+    """triangulation.py:8-27 (cv2.triangulatePoints)."""
+    x, _ = triangulate_views(np.stack([u1, u2]), np.stack([P1[0:3, 0:4], P2[0:3, 0:4]]), "dlt")
+    with np.errstate(invalid="ignore"):
+        status = np.max(np.abs(x), axis=1) <= max_coordinate_value
+    return x, status

@@ -1,0 +1,143 @@
+/*
+ * epipolar_hip.h -- C ABI of libepipolar_hip.so (MI355X / gfx950).
+ *
+ * The reference (mkocabas/EpipolarPose) is pure Python/PyTorch and has no FFI of its own; the drop-in
+ * boundary is the set of Python callables listed in SURVEY.md section 8(b).  This header declares the
+ * device entry points those callables bind to (through ctypes).  Each entry point
+ * names the reference code it replaces (path:line under the reference repository).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
+ *   - nothing is allocated, freed or synchronised inside; work is enqueued on `stream` (a hipStream_t
+ *     passed as void*, NULL = default stream); the library holds no global state and is re-entrant;
+ *   - return value: EPI_OK (0) or an epi_status error code (> 0); epi_status_string() names it;
+ *   - tensors are dense, row-major in the stated index order.
+ */
+#ifndef EPIPOLAR_HIP_H
+#define EPIPOLAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* epi_stream_t;
+
+enum epi_status {
+    EPI_OK = 0,
+    EPI_ERR_INVALID_ARGUMENT = 1,   /* NULL pointer, non-positive size, bad enum */
+    EPI_ERR_UNSUPPORTED = 2,        /* shape/dtype combination the kernels do not cover */
+    EPI_ERR_WORKSPACE = 3,          /* workspace too small */
+    EPI_ERR_LAUNCH = 4              /* hipGetLastError() != hipSuccess after a launch */
+};
+
+enum epi_dtype { EPI_F32 = 0, EPI_BF16 = 1, EPI_F64 = 2 };
+enum epi_layout {
+    EPI_NCHW = 0,   /* logits[b][j*D+d][h][w]  -- the reference layout (integral_loss.py:52)     */
+    EPI_NHWC = 1    /* logits[b][h][w][j*D+d]  -- torch channels_last / the MFMA head's output  */
+};
+enum epi_loss_kind { EPI_LOSS_L1 = 0, EPI_LOSS_L2 = 1, EPI_LOSS_SMOOTH_L1 = 2 };
+
+const char* epi_version(void);
+const char* epi_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Integral regression (soft-argmax) -- replaces lib/core/integral_loss.py:49-86
+ * (softmax_integral_tensor + generate_3d_integral_preds_tensor): global softmax over each joint's
+ * D*H*W voxels and the 3-D expectation, in ONE pass over the logits.
+ *   xyz      [B][3J]  (x,y,z per joint), x = E[w]/W - 0.5, y = E[h]/H - 0.5, z = E[d]/D - 0.5
+ *   row_max  [B*J]    max logit of each row      (saved for the backward pass)
+ *   row_sum  [B*J]    sum exp(logit - row_max)   (saved for the backward pass)
+ * workspace: epi_softargmax3d_workspace_bytes() bytes.
+ * ------------------------------------------------------------------------------------------------ */
+size_t epi_softargmax3d_workspace_bytes(int B, int J, int D, int H, int W);
+
+int epi_softargmax3d_fwd(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                         float* xyz, float* row_max, float* row_sum,
+                         void* workspace, size_t workspace_bytes, epi_stream_t stream);
+
+/* Backward of the above contracted with grad_xyz [B][3J] (what autograd produces in the reference
+ * through integral_loss.py:71-86): one read of the logits, one write of dlogits (same dtype/layout).
+ *   dlogit_i = p_i * ( gx*(w_i/W - (x+.5)) + gy*(h_i/H - (y+.5)) + gz*(d_i/D - (z+.5)) ) * grad_scale
+ * grad_scale: device scalar (upstream d loss) or NULL (= 1). */
+int epi_softargmax3d_bwd(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                         const float* row_max, const float* row_sum, const float* xyz,
+                         const float* grad_xyz, const float* grad_scale,
+                         void* dlogits, epi_stream_t stream);
+
+/* Weighted joint-location loss value and its gradient w.r.t. the predicted coordinates -- replaces
+ * lib/core/integral_loss.py:7-47 (weighted_mse_loss / weighted_l1_loss / weighted_smooth_l1_loss),
+ * including norm=True (whole-tensor L1 normalisation, :9-11) and the sum/len(input) reduction (:16).
+ *   pred, target, weight, grad_pred: [B][n]  (n = 3J);  loss: device scalar;  grad_pred may be NULL. */
+int epi_joint_loss(const float* pred, const float* target, const float* weight, int B, int n,
+                   int kind, int norm, int size_average, float* loss, float* grad_pred, epi_stream_t stream);
+
+/* Hard arg-max of each row -- the device half of lib/core/inference.py:12-40 (get_max_preds):
+ * first-maximum flat index (NumPy argmax tie rule, NaN counts as maximum) and the maximum.
+ *   x [rows][n] (dtype f32 or bf16);  idx [rows] int64;  val [rows] f32
+ * workspace: epi_argmax_workspace_bytes(rows, n). */
+size_t epi_argmax_workspace_bytes(int rows, int n);
+int epi_argmax_rows(const void* x, int dtype, int rows, int n, int64_t* idx, float* val,
+                    void* workspace, size_t workspace_bytes, epi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Self-supervision geometry -- replaces lib/utils/img_utils.py:141-243, lib/utils/triangulation.py,
+ * lib/utils/prep_h36m.py:170-204.  A batch of B = V*G samples is view-major: sample (view v, group g)
+ * sits at index v*G + g (img_utils.py:194-199: first half of the batch = view 1, second half = view 2).
+ * All per-sample camera / crop arrays are float64, as default_collate produces them from the
+ * reference's meta dict (lib/dataset/h36m.py:73-86).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct epi_view_meta {
+    const double* center_x;   /* [B] crop centre in the original image (px)                         */
+    const double* center_y;   /* [B]                                                                */
+    const double* width;      /* [B] crop box width before augmentation                             */
+    const double* height;     /* [B]                                                                */
+    const double* scale;      /* [B] scale augmentation                                             */
+    const double* rot;        /* [B] rotation augmentation, degrees                                 */
+    const double* R;          /* [B][3][3] world->camera rotation                                   */
+    const double* T;          /* [B][3]    camera centre in the world (X_c = R (X - T))             */
+    const double* f;          /* [B][2]    focal lengths                                            */
+    const double* c;          /* [B][2]    principal point                                          */
+    const double* P;          /* [B][3][4] projection matrix K [R | -R T] (cameras.py:126-131)      */
+} epi_view_meta;
+
+/* img_utils.py:141-155,171-185 (trans_coords_from_patch_to_org_3d): soft-argmax output -> original
+ * image pixels + depth in mm.  xyz [B][3J] f32 (normalised, as epi_softargmax3d_fwd writes it);
+ * kps_img [B][J][3] f64 (u, v, z_mm). patch = 256, rect3d = 2000 in the reference (:178-179). */
+int epi_decode_to_image(const float* xyz, int B, int J, const epi_view_meta* meta_host,
+                        double patch_w, double patch_h, double rect3d, double* kps_img, epi_stream_t stream);
+
+/* Triangulators.  kps [B][J][kps_stride] (first two entries = u, v), P [B][3][4]; dtype EPI_F64 or
+ * EPI_F32 selects storage AND arithmetic of kps/P/X.  X [G][J][3]; status [G][J] int32 or NULL.
+ *   iterls: triangulation.py:104-181 (iterative_LS_triangulation; V=2 is the reference, V>2 the same
+ *           iteration with one depth per view).  status: 1, 0, -1, -2, -3 as the reference (:176-179).
+ *   ls:     triangulation.py:34-97  (linear_LS_triangulation), V views.
+ *   dlt:    triangulation.py:8-27   (linear_eigen_triangulation == cv2.triangulatePoints), 2Vx4
+ *           homogeneous system, smallest right-singular vector by one-sided Jacobi in float64;
+ *           status = 1 where max|X| <= 1e16 (:25). */
+int epi_triangulate_iterls(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
+                           double tolerance, int max_iter, void* X, int32_t* status, epi_stream_t stream);
+int epi_triangulate_ls(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
+                       void* X, int32_t* status, epi_stream_t stream);
+int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
+                        void* X, int32_t* status, epi_stream_t stream);
+
+/* img_utils.py:212-243 + prep_h36m.py:177-204 (get_batch_labels_from_global_coords):
+ * world joints X [G][J][3] f64 -> per-view pseudo labels label [B][3J] f32, weight [B][3J] f32 (ones). */
+int epi_reproject_labels(const double* X, int G, int V, int J, const epi_view_meta* meta_host,
+                         double patch_w, double patch_h, double rect3d, int root_joint,
+                         float* label, float* weight, epi_stream_t stream);
+
+/* img_utils.py:166-190 (self_supervision) fused into ONE launch: decode -> triangulate -> re-project.
+ * method: 0 iterative LS (reference), 1 linear LS, 2 DLT.  X_out [G][J][3] f64 may be NULL. */
+int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_meta* meta_host,
+                         double patch_w, double patch_h, double rect3d, int root_joint,
+                         int method, double tolerance, int max_iter,
+                         float* label, float* weight, double* X_out, epi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPIPOLAR_HIP_H */

@@ -1,0 +1,71 @@
+"""CPU: the C-ABI shared library builds, loads and exports every symbol include/epipolar_hip.h declares
+(no compute calls without a GPU), and the product package has no route into the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from epipolarpose_amd import build, hip
+    build.build(verbose=False)
+    return hip.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "epipolar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(epi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    from epipolarpose_amd import hip
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "symbol %s declared in the header but not exported" % n
+    assert set(names) == set(hip.EXPORTED_SYMBOLS), "ctypes signature table and header disagree"
+
+
+def test_host_only_entry_points(lib):
+    assert b"gfx950" in lib.epi_version()
+    assert lib.epi_status_string(0) == b"ok"
+    assert lib.epi_status_string(3) == b"workspace too small"
+    # 544 rows x 1 chunk (scalar-fallback sizing: 262144 / 4096 = 64 chunks) x 32 B
+    assert lib.epi_softargmax3d_workspace_bytes(32, 17, 64, 64, 64) == 32 * 17 * 64 * 32
+    assert lib.epi_softargmax3d_workspace_bytes(0, 17, 64, 64, 64) == 0
+    assert lib.epi_argmax_workspace_bytes(4, 100) == 4 * 16
+    # argument validation happens before any device work
+    assert lib.epi_softargmax3d_fwd(None, 0, 0, 1, 1, 1, 1, 1, None, None, None, None, 0, None) == 1
+    assert lib.epi_joint_loss(None, None, None, 1, 3, 0, 0, 1, None, None, None) == 1
+    assert lib.epi_triangulate_dlt(None, 2, None, 2, 1, 2, 1, None, None, None) == 1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "epipolarpose_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|from\s+\.+\s*import\s+oracle|oracle/", src, flags=re.M):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
+    for f in ("bench.py",):
+        p = os.path.join(ROOT, f)
+        if os.path.exists(p):
+            src = open(p).read()
+            for m in re.finditer(r"^.*\boracle\b.*$", src, flags=re.M):
+                line = m.group(0)
+                assert "cpu_baseline" in src[max(0, m.start() - 3000):m.end()], "oracle used outside cpu_baseline: " + line
+
+
+def test_no_cpu_fallback():
+    import torch
+    from epipolarpose_amd import hip
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip.softargmax3d_fwd(torch.zeros(1, 8, 2, 2), 2)

@@ -1,0 +1,187 @@
+"""GPU parity: self-supervision geometry kernels (through the C ABI) vs. golden vectors / the oracle.
+Tolerances: triangulated 3-D <= 1e-2 mm abs for the fp32 path; the float64 path (the
+drop-in default, same precision as the reference) is held to 1e-6 mm."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as o_geo
+from oracle import triangulation as o_tri
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run through gpurun)"
+    from epipolarpose_amd import hip
+    hip.load()
+    return torch.device("cuda:0")
+
+
+def scene(n_group, j, seed, n_view=2, **kw):
+    from epipolarpose_amd.synthetic import SyntheticScenes
+    return SyntheticScenes(n_group=n_group, n_view=n_view, num_joints=j, seed=seed, **kw)
+
+
+def patch_to_xyz(cp):
+    return np.stack([cp[:, :, 0] / 256 - 0.5, cp[:, :, 1] / 256 - 0.5, cp[:, :, 2] / 256], axis=2).reshape(cp.shape[0], -1)
+
+
+def test_decode_to_image_golden(golden, dev):
+    from epipolarpose_amd import hip
+    g = golden("geometry")
+    p = g["affine/params"]
+    meta = {"center_x": p[:, 0], "center_y": p[:, 1], "width": p[:, 2], "height": p[:, 3], "scale": p[:, 4], "rot": p[:, 5]}
+    xyz = patch_to_xyz(g["decode/coords_patch"]).astype(np.float32)
+    out = hip.decode_to_image(torch.from_numpy(xyz).to(dev), hip.DeviceMeta(meta, dev)).cpu().numpy()
+    ref = g["decode/coords_img"][:, :, :3]
+    np.testing.assert_allclose(out, ref, atol=2e-4)          # input rounded to f32: 256 px * 2^-24 * |affine|
+    # exact check against the oracle fed the same float32 input
+    cp = np.ones(g["decode/coords_patch"].shape)
+    x64 = xyz.astype(np.float64).reshape(12, 17, 3)
+    cp[:, :, 0], cp[:, :, 1], cp[:, :, 2] = (x64[:, :, 0] + 0.5) * 256, (x64[:, :, 1] + 0.5) * 256, x64[:, :, 2] * 256
+    np.testing.assert_allclose(out, o_geo.decode_to_image(cp, meta)[:, :, :3], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float64, 1e-6), (torch.float32, 1e-2)], ids=["f64", "f32"])
+@pytest.mark.parametrize("noise", [0, 2])
+def test_two_view_triangulators_golden(golden, dev, dtype, atol, noise):
+    from epipolarpose_amd import hip
+    g = golden("triangulation")
+    u, ps = g["u/noise%d" % noise], g["P"]
+    for va, vb in ((0, 1), (0, 3), (1, 2)):
+        us = torch.from_numpy(np.concatenate([u[va], u[vb]])).to(dev, dtype)              # [2*G, J, 2] view-major
+        pp = torch.from_numpy(np.concatenate([np.repeat(ps[va][None], 3, 0), np.repeat(ps[vb][None], 3, 0)])).to(dev, dtype)
+        for method, key in (("iterative", "iter_x"), ("ls", "ls_x"), ("dlt", "eigen_x")):
+            x, st = hip.triangulate(us, pp, 2, method)
+            for grp in range(3):
+                tag = "noise%d/v%d%d/g%d" % (noise, va, vb, grp)
+                np.testing.assert_allclose(x[grp].double().cpu().numpy(), g[tag + "/" + key], atol=atol)
+                if method == "iterative":
+                    np.testing.assert_array_equal(st[grp].cpu().numpy(), g[tag + "/iter_status"])
+                if method == "dlt":
+                    np.testing.assert_array_equal(st[grp].cpu().numpy().astype(bool), g[tag + "/eigen_status"])
+
+
+def test_reference_signature_and_status_codes(golden, dev):
+    from epipolarpose_amd.utils import triangulation as tri
+    g = golden("triangulation")
+    x, st = tri.iterative_LS_triangulation(g["behind/u0"], g["P"][0], g["behind/u1"], g["P"][1])
+    np.testing.assert_array_equal(st, g["behind/status"])
+    np.testing.assert_allclose(x, g["behind/x"], rtol=1e-7, atol=1e-5)
+    assert x.dtype == np.float64
+    x, st = tri.linear_LS_triangulation(g["u/noise2"][0, 0], g["P"][0], g["u/noise2"][1, 0], g["P"][1])
+    np.testing.assert_allclose(x, g["noise2/v01/g0/ls_x"], atol=1e-6)
+    assert st.dtype == bool and st.all()
+    x, st = tri.linear_eigen_triangulation(g["u/noise2"][0, 0], g["P"][0], g["u/noise2"][1, 0], g["P"][1])
+    np.testing.assert_allclose(x, g["noise2/v01/g0/eigen_x"], atol=1e-6)
+
+
+@pytest.mark.parametrize("n_view", [2, 3, 4, 6])
+def test_multiview_vs_oracle(dev, n_view):
+    from epipolarpose_amd import hip
+    sc = scene(5, 17, 100 + n_view, n_view=n_view, noise_px=1.5)
+    kps = torch.from_numpy(sc.kps_img).to(dev)
+    pm = torch.from_numpy(sc.meta["projection_matrix"]).to(dev)
+    for method, fn in (("iterative", o_tri.iterative_ls_triangulation), ("ls", o_tri.linear_ls_triangulation),
+                       ("dlt", o_tri.dlt_triangulation)):
+        x, st = hip.triangulate(kps, pm, n_view, method)
+        x32, _ = hip.triangulate(kps.float(), pm.float(), n_view, method)
+        for grp in range(5):
+            idx = [v * 5 + grp for v in range(n_view)]
+            ref, rst = fn(sc.kps_img[idx], sc.meta["projection_matrix"][idx])
+            np.testing.assert_allclose(x[grp].cpu().numpy(), ref, atol=1e-6)
+            np.testing.assert_allclose(x32[grp].double().cpu().numpy(), ref, atol=1e-2)
+            if method == "iterative":
+                np.testing.assert_array_equal(st[grp].cpu().numpy(), rst)
+
+
+@pytest.mark.parametrize("tag,n_group,j", [("h36m", 3, 17), ("mpii", 2, 16)])
+def test_reprojection_and_fused_ss_golden(golden, dev, tag, n_group, j):
+    from epipolarpose_amd import hip
+    g = golden("geometry")
+    sc = scene(n_group, j, 31 + j)
+    meta = hip.DeviceMeta(sc.meta, dev)
+    lab, wt = hip.reproject_labels(torch.from_numpy(sc.world).to(dev), meta, 2)
+    np.testing.assert_allclose(lab.cpu().numpy(), g[tag + "/labels_from_world/label"], atol=1e-7)
+    np.testing.assert_array_equal(wt.cpu().numpy(), g[tag + "/labels_from_world/weight"])
+    # staged: decode -> triangulate -> re-project, against the reference's own intermediate results
+    xyz = torch.from_numpy(patch_to_xyz(g[tag + "/ss/coords_patch"]).astype(np.float32)).to(dev)
+    kps = hip.decode_to_image(xyz, meta)
+    np.testing.assert_allclose(kps.cpu().numpy(), g[tag + "/ss/kps_img"][:, :, :3], atol=2e-4)
+    x, st = hip.triangulate(kps, meta.tensors["projection_matrix"], 2, "iterative")
+    np.testing.assert_allclose(x.cpu().numpy(), g[tag + "/ss/x_world"][:n_group], atol=5e-3)   # f32-rounded input
+    lab2, _ = hip.reproject_labels(x, meta, 2)
+    np.testing.assert_allclose(lab2.cpu().numpy(), g[tag + "/ss/label"], atol=2e-6)
+    # fused single launch == staged
+    lab3, wt3, xw = hip.self_supervision(xyz, meta, 2, "iterative", want_world=True)
+    np.testing.assert_allclose(xw.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(lab3.cpu().numpy(), lab2.cpu().numpy(), rtol=0, atol=1e-7)
+    assert torch.equal(wt3, torch.ones_like(wt3))
+
+
+def test_self_supervision_from_logits_golden(golden, dev):
+    from epipolarpose_amd.utils import img_utils
+    g = golden("geometry")
+    sc = scene(2, 5, 77)
+    logits = torch.from_numpy(g["ss_full/logits"]).to(dev)
+    lab, wt = img_utils.self_supervision(logits, sc.meta)
+    assert lab.dtype == np.float32 and lab.shape == (4, 15)
+    np.testing.assert_allclose(lab, g["ss_full/label"], atol=5e-6)
+    np.testing.assert_array_equal(wt, g["ss_full/weight"])
+    lab_cl, _ = img_utils.self_supervision(logits.contiguous(memory_format=torch.channels_last), sc.meta)
+    np.testing.assert_allclose(lab_cl, g["ss_full/label"], atol=5e-6)
+
+
+def test_four_view_ss_vs_oracle_and_ground_truth(dev):
+    from epipolarpose_amd import hip
+    sc = scene(8, 17, 123, n_view=4)
+    xyz32 = sc.label.copy()
+    xyz32[:, 2::3] = xyz32[:, 2::3]          # z label has no -0.5 offset: decode uses z*pw, label z = pz/pw -> same
+    meta = hip.DeviceMeta(sc.meta, dev)
+    for method in ("iterative", "ls", "dlt"):
+        lab, wt, xw = hip.self_supervision(torch.from_numpy(xyz32).to(dev), meta, 4, method, want_world=True)
+        # exact 2-D in -> exact 3-D out (labels are f32: 256 px * 2^-24 -> ~1e-4 mm) -> labels reproduce themselves
+        np.testing.assert_allclose(xw.cpu().numpy(), sc.world, atol=5e-3)
+        np.testing.assert_allclose(lab.cpu().numpy(), sc.label, atol=2e-6)
+        cp = np.ones((32, 17, 4))
+        x64 = xyz32.astype(np.float64).reshape(32, 17, 3)
+        cp[:, :, 0], cp[:, :, 1], cp[:, :, 2] = (x64[:, :, 0] + 0.5) * 256, (x64[:, :, 1] + 0.5) * 256, x64[:, :, 2] * 256
+        olab, _, oxw, _ = o_geo.self_supervision(None, sc.meta, n_view=4, method=method, coords_patch=cp)
+        np.testing.assert_allclose(xw.cpu().numpy(), oxw[:8], atol=1e-6)
+        np.testing.assert_allclose(lab.cpu().numpy(), olab, atol=1e-7)
+
+
+def test_bulk_properties(dev):
+    """2^16 groups x 4 views: view-permutation invariance (DLT / LS), row-scaling invariance of P (DLT),
+    noise-free recovery in fp32 within 1e-2 mm."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.synthetic import make_cameras, project
+    g_n, j, v_n = 1 << 16, 17, 4
+    gen = torch.Generator().manual_seed(3)
+    world = torch.randn((g_n, j, 3), generator=gen, dtype=torch.float64) * 300 + torch.tensor([0.0, 0.0, 900.0], dtype=torch.float64)
+    cams = make_cameras(v_n)
+    kps, pm = [], []
+    for c in cams:
+        uv, _ = project(world.reshape(-1, 3).numpy(), c)
+        kps.append(torch.from_numpy(uv).reshape(g_n, j, 2))
+        pm.append(torch.from_numpy(c["projection_matrix"]).expand(g_n, 3, 4))
+    kps = torch.cat(kps).to(dev)
+    pm = torch.cat(pm).contiguous().to(dev)
+    world = world.to(dev)
+    for method in ("iterative", "ls", "dlt"):
+        x32, st = hip.triangulate(kps.float(), pm.float(), v_n, method)
+        assert (x32.double() - world).abs().max().item() <= 1e-2
+        assert (st == 1).all()
+    noisy = kps + torch.randn(kps.shape, generator=gen, dtype=torch.float64).to(dev) * 2.0
+    perm = [2, 0, 3, 1]
+    kp_p = noisy.reshape(v_n, g_n, j, 2)[perm].reshape(-1, j, 2).contiguous()
+    pm_p = pm.reshape(v_n, g_n, 3, 4)[perm].reshape(-1, 3, 4).contiguous()
+    for method in ("ls", "dlt"):
+        a, _ = hip.triangulate(noisy, pm, v_n, method)
+        b, _ = hip.triangulate(kp_p, pm_p, v_n, method)
+        assert (a - b).abs().max().item() <= 1e-6
+    a, _ = hip.triangulate(noisy, pm, v_n, "dlt")
+    b, _ = hip.triangulate(noisy, pm * 3.7, v_n, "dlt")
+    assert (a - b).abs().max().item() <= 1e-6
