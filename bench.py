@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Benchmark of the EpipolarPose training hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is one full optimisation step (forward, soft-argmax criterion, backward, gradient all-reduce when N > 1,
+Adam) of the ResNet-50 volumetric-heat-map network on one synthetic 4-view 256x256 batch that is already resident
+in HBM.  Default workload = BASELINE.json configs[1] (fully-supervised SmoothL1 loss, 32 images = 8 groups x 4 views
+per GPU); ``--workload ss`` = configs[2] (pseudo labels from 4-view triangulation inside the step).
+Rank 0 prints ONE JSON line (see the task contract) carrying ``roofline`` and ``cpu_baseline`` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("fs", "ss"), default="fs")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU (groups x 4 views)")
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--layers", type=int, default=50)
+    ap.add_argument("--image", type=int, default=256)
+    ap.add_argument("--joints", type=int, default=17)
+    ap.add_argument("--depth", type=int, default=64)
+    ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (diagnostic; not the bench line)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def build_problem(args, device, rank):
+    from epipolarpose_amd.core import integral_loss
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.hip import DeviceMeta
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from epipolarpose_amd.synthetic import SyntheticScenes
+    from epipolarpose_amd.utils.utils import get_optimizer
+
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False               # no checkpoint on the box: random-init weights of the architecture
+    cfg.MODEL.NUM_JOINTS = args.joints
+    cfg.MODEL.DEPTH_RES = args.depth
+    cfg.MODEL.IMAGE_SIZE = [args.image, args.image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = args.layers
+    cfg.LOSS.FN = "SmoothL1JointLocationLoss"    # experiments/h36m/train.yaml:44
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    model = get_pose_net(cfg, is_train=True).to(device)
+    model.train()
+    criterion = getattr(integral_loss, cfg.LOSS.FN)(num_joints=cfg.MODEL.NUM_JOINTS, norm=cfg.LOSS.NORM).to(device)
+    optimizer = get_optimizer(cfg, model)        # Adam, lr 1e-3 (train.yaml)
+
+    n_group = args.batch // args.views
+    scenes = SyntheticScenes(n_group=n_group, n_view=args.views, num_joints=args.joints, patch=256, seed=100 + rank)
+    gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+    images = torch.randn((args.batch, 3, args.image, args.image), generator=gen).to(device)
+    images = images.contiguous(memory_format=torch.channels_last)
+    label = torch.from_numpy(scenes.label).to(device)
+    weight = torch.from_numpy(scenes.weight).to(device)
+    meta = DeviceMeta(scenes.meta, device) if args.workload == "ss" else None
+    return cfg, model, criterion, optimizer, images, label, weight, meta, scenes
+
+
+def cpu_baseline(args, scenes):
+    """cpu_baseline leg: the oracle (fp32 torch-CPU restatement of the reference's model + criterion, float64 NumPy
+    restatement of its self-supervision) timed on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from oracle import geometry as o_geo
+    from oracle import network as o_net
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.EXTRA.NUM_LAYERS = args.joints, args.depth, args.layers
+    torch.manual_seed(1234)
+    sd = {k: v.detach().clone().contiguous() for k, v in get_pose_net(cfg, True).state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    sd.update(params)
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    b = args.cpu_batch
+    x = torch.randn(b, 3, args.image, args.image)
+    gt = torch.from_numpy(scenes.label[:b].copy())
+    wt = torch.ones_like(gt)
+
+    def step():
+        opt.zero_grad()
+        logits = o_net.forward(sd, x, args.layers, training=True, new_stats={})
+        loss = o_net.joint_location_loss(logits, gt, wt, args.joints, "smoothl1")
+        loss.backward()
+        opt.step()
+    step()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < 8.0 and n < 10):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    out = {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": "%d steps of batch %d (ResNet-%d, %dx%d, J=%d, D=%d; fwd + SmoothL1 soft-argmax loss + bwd + Adam), "
+                     "fp32 torch-CPU oracle, %d threads" % (n, b, args.layers, args.image, args.image, args.joints,
+                                                            args.depth, cores)}
+    # self-supervision leg of the CPU path (float64 NumPy restatement, 1 core) + "MPJPE vs ref" on identical inputs
+    cp = scenes.patch_coords(noise_px=1.0, seed=3)
+    t0 = time.perf_counter()
+    _, _, xw_ref, _ = o_geo.self_supervision(None, scenes.meta, n_view=scenes.n_view, coords_patch=cp)
+    out["ss_groups_per_s_1core"] = round(scenes.n_group / (time.perf_counter() - t0), 2)
+    if torch.cuda.is_available():
+        from epipolarpose_amd import hip
+        xyz = np.stack([cp[:, :, 0] / 256 - 0.5, cp[:, :, 1] / 256 - 0.5, cp[:, :, 2] / 256], 2).reshape(cp.shape[0], -1)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        _, _, xw = hip.self_supervision(torch.from_numpy(xyz.astype(np.float32)).to(dev), hip.DeviceMeta(scenes.meta, dev),
+                                        scenes.n_view, want_world=True)
+        err = np.linalg.norm(xw.cpu().numpy() - xw_ref[:scenes.n_group], axis=2)
+        out["mpjpe_vs_ref_mm"] = float(err.mean())
+    return out
+
+
+def main():
+    args = parse_args()
+    from epipolarpose_amd import distributed as epd
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.core.function import train_step
+
+    rank, world, local = epd.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    hip.load()
+    torch.backends.cudnn.benchmark = True        # reference CUDNN.BENCHMARK: true -> MIOpen find mode
+
+    cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank)
+    grad_sync = None
+    if world > 1:
+        epd.broadcast_module(model)
+        grad_sync = epd.BucketedGradSync(model)
+    n_view = args.views if args.workload == "ss" else None
+    # 4-view SS uses the V-view generalisation of the reference's iterative LS solver (V=2 is the reference itself)
+
+    def step():
+        return train_step(model, criterion, optimizer, images, label, weight, meta=meta, n_view=n_view,
+                          autocast=not args.fp32, grad_sync=grad_sync)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    hip.timer.reset()
+    hip.timer.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hip.timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        global_batch = args.batch * world
+        elem = 4 if args.fp32 else 2
+        vox = args.joints * args.depth * (args.image // 4) ** 2
+        ksum = hip.timer.summary()
+        n_b, ms_b = ksum["epi_softargmax3d_bwd"]
+        n_f, ms_f = ksum["epi_softargmax3d_fwd"]
+        bytes_bwd = 2.0 * args.batch * vox * elem          # 1 read of the logits + 1 write of dlogits
+        bytes_fwd = 1.0 * args.batch * vox * elem          # 1 read of the logits
+        ach = bytes_bwd / (ms_b * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("softargmax_bwd_kernel/%s/b%d" % ("f32" if args.fp32 else "bf16", args.batch))
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "softargmax_bwd_kernel (epi_softargmax3d_bwd)", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "algorithmic_bytes": bytes_bwd, "avg_ms": round(ms_b, 5), "launches": n_b,
+                    "other": {"softargmax_partial+combine (epi_softargmax3d_fwd)": {
+                        "achieved": round(bytes_fwd / (ms_f * 1e-3) / 1e9, 1), "frac": round(bytes_fwd / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes": bytes_fwd, "avg_ms": round(ms_f, 5), "launches": n_f}}}
+        if "epi_self_supervision" in ksum:
+            roofline["other"]["self_supervision_kernel"] = {"avg_ms": round(ksum["epi_self_supervision"][1], 5),
+                                                            "launches": ksum["epi_self_supervision"][0],
+                                                            "note": "launch-latency bound at this size (7.5 KB/step)"}
+        line = {
+            "metric": "images/sec (4-view 256x256, ResNet-50) at 1/2/4/8 MI355X; MPJPE vs ref",
+            "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": ("configs[1]: ResNet-%d Integral-pose, 4-view %dx%d synthetic, batch=%d/GPU, fully-supervised "
+                                    "SmoothL1 loss" if args.workload == "fs" else
+                                    "configs[2]: ResNet-%d self-supervised, 4-view %dx%d epipolar-triangulation pseudo-labels, "
+                                    "batch=%d/GPU") % (args.layers, args.image, args.image, args.batch),
+                       "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
+                       "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, scenes)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""Training loop -- mirror of the reference's ``lib/core/function.py:14-63`` (``train_integral``).
+
+Same signature and logging ("Speed ... samples/s").  Differences that matter on MI355X:
+* the self-supervision step the reference defines but never wires in is inserted between the
+  forward pass and the criterion when ``config.DATASET.TRI`` is set: labels come from
+  ``self_supervision_device(preds.detach(), meta)`` and never leave the GPU;
+* the loss is accumulated on the device and read back only every ``PRINT_FREQ`` iterations (the reference
+  synchronises with ``loss.item()`` every step, function.py:48);
+* the backbone runs under bf16 autocast when ``train_integral.autocast`` is true (default).
+"""
+import logging
+import time
+
+import torch
+
+from ..utils.img_utils import self_supervision_device
+from ..utils.utils import AverageMeter
+
+logger = logging.getLogger(__name__)
+
+
+def train_step(model, criterion, optimizer, batch_data, batch_label, batch_label_weight, meta=None, n_view=None,
+               ss_method="iterative", autocast=True, grad_sync=None):
+    """One optimisation step on device-resident tensors.  Returns the (device) loss tensor."""
+    if grad_sync is not None:
+        grad_sync.zero_grad()                 # gradients live in the flat all-reduce buckets
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        preds = model(batch_data)
+    if meta is not None and n_view:          # self-supervised: pseudo labels by multi-view triangulation
+        batch_label, batch_label_weight = self_supervision_device(preds.detach(), meta, n_view=n_view, method=ss_method,
+                                                                  num_joints=getattr(criterion, "num_joints", None))
+    loss = criterion(preds, batch_label, batch_label_weight)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    optimizer.step()
+    return loss.detach()
+
+
+def train_integral(config, train_loader, model, criterion, optimizer, epoch, grad_sync=None):
+    batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
+    model.train()
+    use_ss = bool(config.DATASET.TRI)
+    n_view = 2 if use_ss else None           # reference pairing: first / second half of the batch (img_utils.py:194)
+    pending, pending_n = None, 0
+    end = time.time()
+    for i, data in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        batch_data, batch_label, batch_label_weight, meta = data
+        batch_data = batch_data.cuda(non_blocking=True)
+        batch_label = batch_label.cuda(non_blocking=True)
+        batch_label_weight = batch_label_weight.cuda(non_blocking=True)
+        batch_size = batch_data.size(0)
+        loss = train_step(model, criterion, optimizer, batch_data, batch_label, batch_label_weight,
+                          meta=meta if use_ss else None, n_view=n_view, grad_sync=grad_sync)
+        pending = loss * batch_size if pending is None else pending + loss * batch_size
+        pending_n += batch_size
+        if i % config.PRINT_FREQ == 0:
+            val = loss.item()                 # the only host synchronisation
+            losses.update(pending.item() / pending_n, pending_n)
+            losses.val = val
+            pending, pending_n = None, 0
+            batch_time.update(time.time() - end)
+            msg = 'Epoch: [{0}][{1}/{2}]\t' \
+                  'Time {batch_time.val:.3f}s ({batch_time.avg:.3f}s)\t' \
+                  'Speed {speed:.1f} samples/s\t' \
+                  'Data {data_time.val:.3f}s ({data_time.avg:.3f}s)\t' \
+                  'Loss {loss.val:.5f} ({loss.avg:.5f})'.format(
+                      epoch, i, len(train_loader), batch_time=batch_time, speed=batch_size / max(batch_time.val, 1e-9),
+                      data_time=data_time, loss=losses)
+            logger.info(msg)
+        else:
+            batch_time.update(time.time() - end)
+        end = time.time()
+    return losses.avg

@@ -131,7 +131,10 @@ __device__ __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (v < nv) {
-                const T w = (T)1 / dn[v];                                        // :166-169 (cumulative)
+                // :166-169 (cumulative).  float64: exactly the reference's 1/d.  float32: the same weights times
+                // the common factor d_0 (a global row scale leaves the LS solution unchanged) -- ten cumulative
+                // factors of 1/5000 would underflow fp32.
+                const T w = (sizeof(T) == 4) ? dn[0] / dn[v] : (T)1 / dn[v];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     A[2 * v + r][0] *= w; A[2 * v + r][1] *= w; A[2 * v + r][2] *= w; b[2 * v + r] *= w;

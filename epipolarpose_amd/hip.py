@@ -63,6 +63,38 @@ def load():
     return _lib
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  Used by bench.py for the live ``roofline`` figure; off by default."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self):
+        self.records = {}
+
+    def start(self, name):
+        if not self.enabled:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        self.records.setdefault(name, []).append(ev)
+        return ev
+
+    @staticmethod
+    def stop(ev):
+        if ev is not None:
+            ev[1].record()
+
+    def summary(self):
+        """{name: (launches, mean milliseconds)} -- call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.records.items()}
+
+
+timer = KernelTimer()
+
+
 def _check(status, what):
     if status != 0:
         raise RuntimeError("%s failed: %s" % (what, load().epi_status_string(status).decode()))
@@ -129,8 +161,10 @@ def softargmax3d_fwd(logits, num_joints):
     nbytes = lib.epi_softargmax3d_workspace_bytes(b, num_joints, d, h, w)
     ws = _workspace(nbytes, logits.device)
     with torch.cuda.device(logits.device):
+        ev = timer.start("epi_softargmax3d_fwd")
         _check(lib.epi_softargmax3d_fwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(xyz), _ptr(rmax), _ptr(rsum),
                                         _ptr(ws), ws.numel(), _stream()), "epi_softargmax3d_fwd")
+        timer.stop(ev)
     return xyz, rmax, rsum
 
 
@@ -144,9 +178,11 @@ def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_s
     grad_xyz = _dev(grad_xyz, torch.float32, "grad_xyz").contiguous()
     dlogits = torch.empty_like(logits)      # preserves the memory format
     with torch.cuda.device(logits.device):
+        ev = timer.start("epi_softargmax3d_bwd")
         _check(lib.epi_softargmax3d_bwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(row_max), _ptr(row_sum),
                                         _ptr(xyz), _ptr(grad_xyz), _ptr(grad_scale), _ptr(dlogits), _stream()),
                "epi_softargmax3d_bwd")
+        timer.stop(ev)
     return dlogits
 
 
@@ -275,7 +311,9 @@ def self_supervision(xyz, meta, n_view, method="iterative", patch_w=256.0, patch
     weight = torch.empty_like(label)
     xw = torch.empty((g, j, 3), dtype=torch.float64, device=xyz.device) if want_world else None
     with torch.cuda.device(xyz.device):
+        ev = timer.start("epi_self_supervision")
         _check(lib.epi_self_supervision(_ptr(xyz), g, n_view, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d,
                                         root_joint, TRI_METHODS[method], tolerance, max_iter, _ptr(label), _ptr(weight),
                                         _ptr(xw), _stream()), "epi_self_supervision")
+        timer.stop(ev)
     return (label, weight, xw) if want_world else (label, weight)

@@ -1,0 +1,178 @@
+"""Volumetric-heat-map pose network for MI355X -- mirror of the reference's ``lib/models/pose3d_resnet.py``.
+
+API surface kept: ``get_pose_net(cfg, is_train)``, ``PoseResNet.forward(x[B,3,H,W]) -> [B, J*D, H/4, W/4]``
+(``(heatmap, depth_fc)`` when ``MODEL.VOLUME`` is false), ``init_weights`` / ``load_pretrained_pose_model`` and -- the
+compatibility surface proper -- the ``state_dict()`` key names and shapes of the reference (pose3d_resnet.py:93-126):
+``conv1 bn1 layer{1..4}.{i}.{conv,bn}{1..3} layer*.0.downsample.{0,1} deconv_layers.{0,1,3,4,6,7} final_layer``.
+
+MI355X-first choices: the network is built channels-last (NHWC) so MIOpen/hipBLASLt see their native layout and the
+head's MFMA kernels read LDS-stageable rows; the backbone runs under bf16 autocast; residual units are generated
+from a per-depth plan table instead of two hand-written block classes.
+"""
+import logging
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+BN_MOMENTUM = 0.1
+logger = logging.getLogger(__name__)
+
+# depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
+_BASIC = ((3, 1, True), (3, 1, False))                    # reference BasicBlock, pose3d_resnet.py:18-47
+_BOTTLENECK = ((1, 1, False), (3, 1, True), (1, 4, False))  # reference Bottleneck (stride on the 3x3), :50-88
+resnet_spec = {18: (_BASIC, [2, 2, 2, 2]),
+               34: (_BASIC, [3, 4, 6, 3]),
+               50: (_BOTTLENECK, [3, 4, 6, 3]),
+               101: (_BOTTLENECK, [3, 4, 23, 3]),
+               152: (_BOTTLENECK, [3, 8, 36, 3])}
+
+
+class ResidualUnit(nn.Module):
+    """conv-bn(-relu) chain + identity/projection shortcut; parameters are named conv{i}/bn{i}/downsample.{0,1}."""
+
+    def __init__(self, inplanes, planes, plan, stride=1):
+        super().__init__()
+        self.n_conv = len(plan)
+        cin = inplanes
+        for i, (k, mult, strided) in enumerate(plan, start=1):
+            cout = planes * mult
+            setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=k, stride=stride if strided else 1,
+                                                  padding=k // 2, bias=False))
+            setattr(self, "bn%d" % i, nn.BatchNorm2d(cout, momentum=BN_MOMENTUM))
+            cin = cout
+        self.out_planes = cin
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or inplanes != cin:                 # pose3d_resnet.py:130-136
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, cin, kernel_size=1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(cin, momentum=BN_MOMENTUM))
+
+    def forward(self, x):
+        out = x
+        for i in range(1, self.n_conv + 1):
+            out = getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(out))
+            if i < self.n_conv:
+                out = self.relu(out)
+        shortcut = x if self.downsample is None else self.downsample(x)
+        out += shortcut
+        return self.relu(out)
+
+
+def _deconv_geometry(kernel):
+    """kernel -> (padding, output_padding) so that the output is exactly 2x the input (pose3d_resnet.py:145-156)."""
+    table = {4: (1, 0), 3: (1, 1), 2: (0, 0)}
+    if kernel not in table:
+        raise ValueError("unsupported deconv kernel %r" % (kernel,))
+    return table[kernel]
+
+
+class PoseResNet(nn.Module):
+
+    def __init__(self, plan, units, cfg, **kwargs):
+        super().__init__()
+        extra = cfg.MODEL.EXTRA
+        self.deconv_with_bias = extra.DECONV_WITH_BIAS
+        self.volume = cfg.MODEL.VOLUME
+        self.num_joints = cfg.MODEL.NUM_JOINTS
+        self.depth_res = cfg.MODEL.DEPTH_RES
+
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        width = 64
+        for stage, (planes, n_unit) in enumerate(zip((64, 128, 256, 512), units), start=1):
+            blocks = []
+            for u in range(n_unit):
+                blk = ResidualUnit(width, planes, plan, stride=2 if (u == 0 and stage > 1) else 1)
+                width = blk.out_planes
+                blocks.append(blk)
+            setattr(self, "layer%d" % stage, nn.Sequential(*blocks))
+        self.backbone_planes = width
+
+        n_dec, filters, kernels = extra.NUM_DECONV_LAYERS, list(extra.NUM_DECONV_FILTERS), list(extra.NUM_DECONV_KERNELS)
+        assert n_dec == len(filters), 'ERROR: num_deconv_layers is different len(num_deconv_filters)'
+        assert n_dec == len(kernels), 'ERROR: num_deconv_layers is different len(num_deconv_filters)'
+        head = []
+        for planes, k in zip(filters, kernels):
+            pad, out_pad = _deconv_geometry(k)
+            head += [nn.ConvTranspose2d(width, planes, kernel_size=k, stride=2, padding=pad, output_padding=out_pad,
+                                        bias=self.deconv_with_bias),
+                     nn.BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)]
+            width = planes
+        self.deconv_layers = nn.Sequential(*head)
+
+        fk = extra.FINAL_CONV_KERNEL
+        out_ch = self.num_joints * self.depth_res if self.volume else self.num_joints
+        self.final_layer = nn.Conv2d(width, out_ch, kernel_size=fk, stride=1, padding=1 if fk == 3 else 0)
+
+        if not self.volume:                                # legacy 2-D heat-map + depth FC branch, :124-126
+            self.avgpool = nn.AvgPool2d(kernel_size=int(cfg.MODEL.IMAGE_SIZE[0] / 2 ** 5), stride=1)
+            self.depth_fc = nn.Linear(self.backbone_planes, self.num_joints * self.depth_res)
+        self.to(memory_format=torch.channels_last)
+
+    def features(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+    def forward(self, x):
+        if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        feat = self.features(x)
+        heat = self.final_layer(self.deconv_layers(feat))
+        if self.volume:
+            return heat
+        depth = self.depth_fc(self.avgpool(feat).flatten(1))
+        return heat, depth
+
+    def init_weights(self, pretrained=''):
+        """pose3d_resnet.py:214-255: N(0, 0.001) head, BN (1, 0), then load by file-name substring; a missing file
+        is an error exactly as in the reference."""
+        if not os.path.isfile(pretrained):
+            logger.error('=> imagenet pretrained model dose not exist')
+            logger.error('=> please download it first')
+            raise ValueError('imagenet pretrained model does not exist')
+        for m in self.deconv_layers.modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                nn.init.normal_(m.weight, std=0.001)
+                if self.deconv_with_bias:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.final_layer.weight, std=0.001)
+        nn.init.constant_(self.final_layer.bias, 0)
+        if 'mpii' in pretrained or 'coco' in pretrained:
+            logger.info('=> loading pretrained pose model {}'.format(pretrained))
+            self.load_pretrained_pose_model(pretrained)
+        elif 'imagenet' in pretrained:
+            logger.info('=> loading pretrained imagenet model {}'.format(pretrained))
+            self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=False)
+
+    def load_pretrained_pose_model(self, pretrained):
+        """pose3d_resnet.py:257-286: strip a DataParallel ``module.`` prefix, drop shape-mismatched keys."""
+        loaded = torch.load(pretrained, map_location="cpu")
+        if len(loaded) and all('module' in k for k in loaded):
+            loaded = OrderedDict((k[7:], v) for k, v in loaded.items())
+        own = self.state_dict()
+        usable = OrderedDict()
+        for k, v in loaded.items():
+            if k not in own:
+                logger.info('%s not in model_dict' % k)
+                usable[k] = v
+            elif own[k].shape != v.shape:
+                logger.info('WARNING! There is a mismatch in => %s (%s, %s)' % (k, own[k].size(), v.size()))
+            else:
+                usable[k] = v
+        self.load_state_dict(usable, strict=False)
+
+
+def get_pose_net(cfg, is_train, **kwargs):
+    """pose3d_resnet.py:295-305."""
+    plan, units = resnet_spec[cfg.MODEL.EXTRA.NUM_LAYERS]
+    model = PoseResNet(plan, units, cfg, **kwargs)
+    if is_train and cfg.MODEL.INIT_WEIGHTS:
+        model.init_weights(cfg.MODEL.PRETRAINED)
+    return model

@@ -1,0 +1,140 @@
+"""CPU: host-side mirror of the reference interface -- config schema, model state-dict surface, label codec,
+group sharding, and (when /root/reference is present) live comparison with the reference modules."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_shims
+from make_golden_cases import NETWORK_CASES
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_cfg(layers, image, joints, depth):
+    from epipolarpose_amd.core.config import default_config
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = joints, depth, [image, image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    return cfg
+
+
+@pytest.mark.parametrize("case", NETWORK_CASES, ids=[c[0] for c in NETWORK_CASES])
+def test_state_dict_surface_matches_reference(golden, case):
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    g = golden("network")
+    name, layers, image, j, d, b = case
+    sd = get_pose_net(make_cfg(layers, image, j, d), is_train=True).state_dict()
+    assert list(sd.keys()) == g[name + "/keys"].tolist()
+    assert [tuple(v.shape) for v in sd.values()] == [ast.literal_eval(s) for s in g[name + "/shapes"].tolist()]
+
+
+def test_backbone_matches_golden_on_cpu(golden):
+    """The torch part of our model (everything; no HIP op inside nn.Module) reproduces the reference's logits."""
+    from det_weights import fill_state_dict, seeded_array
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    g = golden("network")
+    name, layers, image, j, d, b = NETWORK_CASES[0]
+    model = get_pose_net(make_cfg(layers, image, j, d), is_train=True)
+    shapes = {k: ast.literal_eval(s) for k, s in zip(g[name + "/keys"].tolist(), g[name + "/shapes"].tolist())}
+    model.load_state_dict(fill_state_dict(shapes, seed=1))
+    model.eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image))))
+    ref = g[name + "/logits_eval"]
+    np.testing.assert_allclose(out.numpy(), ref, atol=2e-4 * np.abs(ref).max())
+
+
+def test_init_weights_requires_file():
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    cfg = make_cfg(18, 64, 3, 8)
+    cfg.MODEL.INIT_WEIGHTS = True
+    cfg.MODEL.PRETRAINED = "/nonexistent/imagenet.pth"
+    with pytest.raises(ValueError):
+        get_pose_net(cfg, is_train=True)
+    get_pose_net(cfg, is_train=False)            # evaluation never touches the file (pose3d_resnet.py:302)
+
+
+def test_pretrained_loading_strips_module_prefix(tmp_path):
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    cfg = make_cfg(18, 64, 3, 8)
+    src = get_pose_net(cfg, is_train=False)
+    sd = {"module." + k: v for k, v in src.state_dict().items()}
+    sd["module.final_layer.weight"] = torch.zeros(7, 256, 1, 1)        # shape mismatch -> dropped
+    path = tmp_path / "mpii_pose.pth"
+    torch.save(sd, path)
+    cfg.MODEL.INIT_WEIGHTS, cfg.MODEL.PRETRAINED = True, str(path)
+    dst = get_pose_net(cfg, is_train=True)
+    assert torch.equal(dst.state_dict()["layer3.1.conv2.weight"], src.state_dict()["layer3.1.conv2.weight"])
+    assert dst.final_layer.weight.shape == (24, 256, 1, 1)
+
+
+def test_config_schema_and_yaml_overlay(tmp_path):
+    from epipolarpose_amd.core import config as C
+    cfg = C.default_config()
+    assert cfg.MODEL.EXTRA.NUM_DECONV_FILTERS == [256, 256, 256] and cfg.TRAIN.LR_STEP == [90, 110]
+    assert C.get_model_name(cfg) == ("pose3d_resnet_50", "256x256_pose3d_resnet_50_DR64_S1_DL1")
+    y = tmp_path / "exp.yaml"
+    y.write_text("GPUS: '0,1'\nMODEL:\n  NUM_JOINTS: 16\n  EXTRA:\n    NUM_LAYERS: 18\nLOSS:\n  FN: SmoothL1JointLocationLoss\n"
+                 "TRAIN:\n  LR_STEP:\n  - 90\n  - 120\n")
+    C.update_config(str(y), cfg)
+    assert cfg.GPUS == "0,1" and cfg.MODEL.NUM_JOINTS == 16 and cfg.MODEL.EXTRA.NUM_LAYERS == 18
+    assert cfg.MODEL.EXTRA.FINAL_CONV_KERNEL == 1 and cfg.TRAIN.LR_STEP == [90, 120]
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("MODEL:\n  NOT_A_KEY: 1\n")
+    with pytest.raises(ValueError, match="MODEL.NOT_A_KEY not exist"):
+        C.update_config(str(bad), cfg)
+    bad.write_text("NOPE: 1\n")
+    with pytest.raises(ValueError):
+        C.update_config(str(bad), cfg)
+
+
+@pytest.mark.skipif(not ref_shims.reference_available(), reason="/root/reference not present (GPU box)")
+def test_config_defaults_equal_reference_and_yaml_files_load():
+    from epipolarpose_amd.core import config as C
+    ref = ref_shims.load_reference().config.config
+
+    def flat(d, pre=""):
+        out = {}
+        for k, v in d.items():
+            if isinstance(v, dict):
+                out.update(flat(v, pre + k + "."))
+            else:
+                out[pre + k] = v.tolist() if isinstance(v, np.ndarray) else v
+        return out
+    assert flat(C.default_config()) == flat(ref)
+    for rel in ("h36m/train.yaml", "h36m/train-ss.yaml", "h36m/valid.yaml", "h36m/valid-ss.yaml", "mpii/train.yaml",
+                "mpii/valid.yaml"):
+        cfg = C.update_config(os.path.join(ref_shims.REFERENCE_ROOT, "experiments", rel), C.default_config())
+        assert cfg.MODEL.NAME == "pose3d_resnet"
+
+
+def test_label_codec_mutates_like_reference(golden):
+    from epipolarpose_amd.core.integral_loss import generate_joint_location_label, reverse_joint_location_label
+    g = golden("integral")
+    joints = g["label/joints"].copy()
+    lab, vis = generate_joint_location_label(256.0, 256.0, joints, np.ones((17, 3)))
+    np.testing.assert_allclose(lab, g["label/label"], atol=1e-15)
+    assert np.shares_memory(lab, joints)                      # in place, as integral_loss.py:171-173
+    np.testing.assert_allclose(reverse_joint_location_label(256.0, 256.0, lab.copy()), g["label/reverse"], atol=1e-12)
+
+
+def test_group_sharding_never_splits_views():
+    from epipolarpose_amd.distributed import shard_groups
+    for world in (1, 2, 4, 8):
+        spans = [shard_groups(64, r, world) for r in range(world)]
+        assert sum(n for _, n in spans) == 64 and spans[0][0] == 0
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert [shard_groups(10, r, 4)[1] for r in range(4)] == [3, 3, 2, 2]
+
+
+def test_synthetic_item_contract():
+    from epipolarpose_amd.synthetic import SyntheticScenes
+    sc = SyntheticScenes(n_group=3, n_view=4, num_joints=17, seed=0)
+    assert sc.label.shape == (12, 51) and sc.label.dtype == np.float32 and sc.weight.dtype == np.float32
+    assert set(sc.meta) == {"center_x", "center_y", "width", "height", "scale", "rot", "R", "T", "f", "c", "projection_matrix"}
+    assert sc.meta["projection_matrix"].shape == (12, 3, 4) and sc.meta["T"].shape == (12, 3, 1)
+    assert np.abs(sc.label).max() < 1.5
