@@ -48,14 +48,14 @@ template <typename T, int R>
 __device__ __forceinline__ void qr_solve3(T (&A)[R][3], T (&b)[R], T (&x)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        T nrm2 = 0;
+        T tail2 = 0;                                     // sub-diagonal part kept separate: no cancellation
 #pragma unroll
-        for (int i = k; i < R; ++i) nrm2 += A[i][k] * A[i][k];
-        const T nrm = sqrt(nrm2);
+        for (int i = k + 1; i < R; ++i) tail2 += A[i][k] * A[i][k];
         const T akk = A[k][k];
+        const T nrm = sqrt(akk * akk + tail2);
         const T alpha = (akk > 0) ? -nrm : nrm;
-        const T vk = akk - alpha;
-        const T vn2 = nrm2 - akk * akk + vk * vk;       // |v|^2
+        const T vk = akk - alpha;                       // same sign as akk: no cancellation
+        const T vn2 = vk * vk + tail2;                  // |v|^2
         const T inv = (vn2 > 0) ? (T)2 / vn2 : (T)0;
 #pragma unroll
         for (int j = k + 1; j < 3; ++j) {
@@ -131,10 +131,7 @@ __device__ __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (v < nv) {
-                // :166-169 (cumulative).  float64: exactly the reference's 1/d.  float32: the same weights times
-                // the common factor d_0 (a global row scale leaves the LS solution unchanged) -- ten cumulative
-                // factors of 1/5000 would underflow fp32.
-                const T w = (sizeof(T) == 4) ? dn[0] / dn[v] : (T)1 / dn[v];
+                const T w = (T)1 / dn[v];                                        // :166-169 (cumulative)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     A[2 * v + r][0] *= w; A[2 * v + r][1] *= w; A[2 * v + r][2] *= w; b[2 * v + r] *= w;
@@ -227,22 +224,26 @@ template <typename T, int NV, int METHOD>
 __device__ __forceinline__ int triangulate_one(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
     if (METHOD == TRI_ITER) return tri_iterative_ls<T, NV>(u, P, nv, tol, max_iter, x);
     if (METHOD == TRI_LS) return tri_linear_ls<T, NV>(u, P, nv, x);
-    double ud[NV][2], Pd[NV][12], xd[3];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        ud[v][0] = (double)u[v][0]; ud[v][1] = (double)u[v][1];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Pd[v][k] = (double)P[v][k];
-    }
-    const int st = tri_dlt<NV>(ud, Pd, nv, xd);
-    x[0] = (T)xd[0]; x[1] = (T)xd[1]; x[2] = (T)xd[2];
-    return st;
+    return -100;
+}
+template <int NV>
+__device__ __forceinline__ int triangulate_one_dlt(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
+    return tri_dlt<NV>(u, P, nv, x);
 }
 
-template <typename T, int NV, int METHOD>
-__global__ __launch_bounds__(256) void triangulate_kernel(const T* __restrict__ kps, int kstride, const T* __restrict__ Pm,
-                                                          int G, int V, int J, T tol, int max_iter, T* __restrict__ X,
+// Arithmetic type per method for storage type S.  The single-solve LS runs in the storage precision.  The
+// iterative solver always runs in float64: the reference's stopping rule compares depths (~5000 mm) with an
+// absolute 3e-5 mm tolerance (triangulation.py:161), below fp32 resolution, and its result depends on running
+// exactly as many re-weighting rounds as the reference does.  The homogeneous DLT needs float64 (sigma_max /
+// sigma_3 ~ 1e4).
+template <typename S, int METHOD> struct TriCompute { typedef double type; };
+template <> struct TriCompute<float, TRI_LS> { typedef float type; };
+
+template <typename S, int NV, int METHOD>
+__global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ kps, int kstride, const S* __restrict__ Pm,
+                                                          int G, int V, int J, double tol, int max_iter, S* __restrict__ X,
                                                           int* __restrict__ status) {
+    typedef typename TriCompute<S, METHOD>::type T;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)G * J) return;
     const int g = (int)(t / J), j = (int)(t - (long long)g * J);
@@ -251,19 +252,21 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const T* __restrict__ 
     for (int v = 0; v < NV; ++v) {
         if (v < V) {
             const long long s = (long long)v * G + g;                  // img_utils.py:197-202
-            const T* kp = kps + (s * J + j) * kstride;
-            u[v][0] = kp[0]; u[v][1] = kp[1];
-            const T* pp = Pm + s * 12;
+            const S* kp = kps + (s * J + j) * kstride;
+            u[v][0] = (T)kp[0]; u[v][1] = (T)kp[1];
+            const S* pp = Pm + s * 12;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) P[v][k] = pp[k];
+            for (int k = 0; k < 12; ++k) P[v][k] = (T)pp[k];
         } else {
             u[v][0] = u[v][1] = 0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) P[v][k] = 0;
         }
     }
-    const int st = triangulate_one<T, NV, METHOD>(u, P, V, tol, max_iter, x);
-    X[3 * t] = x[0]; X[3 * t + 1] = x[1]; X[3 * t + 2] = x[2];
+    int st;
+    if constexpr (METHOD == TRI_DLT) st = tri_dlt<NV>(u, P, V, x);
+    else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
+    X[3 * t] = (S)x[0]; X[3 * t + 1] = (S)x[1]; X[3 * t + 2] = (S)x[2];
     if (status) status[t] = st;
 }
 
@@ -365,7 +368,8 @@ __global__ __launch_bounds__(SS_THREADS) void self_supervision_kernel(const floa
                 for (int k = 0; k < 12; ++k) P[v][k] = 0;
             }
         }
-        triangulate_one<double, NV, METHOD>(u, P, V, tol, max_iter, x);
+        if constexpr (METHOD == TRI_DLT) tri_dlt<NV>(u, P, V, x);
+        else triangulate_one<double, NV, METHOD>(u, P, V, tol, max_iter, x);
         double* xs = Xs + (gl * J + j) * 3;
         xs[0] = x[0]; xs[1] = x[1]; xs[2] = x[2];
         if (Xout) {
@@ -410,7 +414,7 @@ static int launch_tri(const void* kps, int kstride, const void* P, int G, int V,
     const unsigned grid = (unsigned)((total + 255) / 256);
 #define EPI_TRI_LAUNCH(NVV)                                                                                               \
     hipLaunchKernelGGL((triangulate_kernel<T, NVV, METHOD>), dim3(grid), dim3(256), 0, st, (const T*)kps, kstride, (const T*)P, \
-                       G, V, J, (T)tol, max_iter, (T*)X, (int*)status)
+                       G, V, J, tol, max_iter, (T*)X, (int*)status)
     if (V == 2) EPI_TRI_LAUNCH(2);
     else if (V <= 4) EPI_TRI_LAUNCH(4);
     else EPI_TRI_LAUNCH(8);

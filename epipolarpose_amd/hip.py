@@ -39,6 +39,10 @@ _SIGNATURES = {
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
     "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
+    "epi_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -317,3 +321,84 @@ def self_supervision(xyz, meta, n_view, method="iterative", patch_w=256.0, patch
                                         _ptr(xw), _stream()), "epi_self_supervision")
         timer.stop(ev)
     return (label, weight, xw) if want_world else (label, weight)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Deconvolution head (MFMA implicit GEMMs).  Activations: NHWC bf16, passed as torch tensors of logical shape
+# [B, C, H, W] in channels_last memory format (so .data_ptr() is the NHWC buffer).
+# ---------------------------------------------------------------------------------------------------------------
+def _nhwc_bf16(t, name):
+    _dev(t, torch.bfloat16, name)
+    if t.dim() != 4:
+        raise ValueError("%s must be [B, C, H, W]" % name)
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def gemm_bf16(a, bt, bias=None, out_dtype=torch.bfloat16, out=None):
+    """C[M,N] = A[M,K] @ Bt[N,K]^T (+ bias).  a, bt: 2-D bf16 CUDA tensors with unit inner stride."""
+    lib = load()
+    _dev(a, torch.bfloat16, "a")
+    _dev(bt, torch.bfloat16, "bt")
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if bt.stride(1) != 1:
+        bt = bt.contiguous()
+    m, k = a.shape
+    n = bt.shape[0]
+    if bt.shape[1] != k:
+        raise ValueError("inner dimensions differ")
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a.device)
+    cdt = EPI_BF16 if out.dtype == torch.bfloat16 else EPI_F32
+    if bias is not None:
+        bias = _dev(bias, torch.float32, "bias").contiguous()
+    with torch.cuda.device(a.device):
+        ev = timer.start("epi_gemm_bf16")
+        _check(lib.epi_gemm_bf16(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(out), out.stride(0), cdt, m, n, k,
+                                 _ptr(bias), _stream()), "epi_gemm_bf16")
+        timer.stop(ev)
+    return out
+
+
+def deconv_pack_weight(weight, want_phase=True, want_bwd=True):
+    """weight [Cin, Cout, 4, 4] (any float dtype) -> (w_phase [4, Cout, 4*Cin] bf16, w_bwd [Cin, 16*Cout] bf16)."""
+    lib = load()
+    _dev(weight, name="weight")
+    cin, cout, kh, kw = weight.shape
+    if (kh, kw) != (4, 4):
+        raise ValueError("deconv head kernels cover kernel 4 / stride 2 / padding 1 only")
+    w = weight.detach().to(torch.bfloat16).contiguous()
+    wp = torch.empty((4, cout, 4 * cin), dtype=torch.bfloat16, device=w.device) if want_phase else None
+    wb = torch.empty((cin, 16 * cout), dtype=torch.bfloat16, device=w.device) if want_bwd else None
+    with torch.cuda.device(w.device):
+        _check(lib.epi_deconv4x4s2_pack_weight(_ptr(w), cin, cout, _ptr(wp), _ptr(wb), _stream()), "epi_deconv4x4s2_pack_weight")
+    return wp, wb
+
+
+def deconv4x4s2_fwd(x, w_phase):
+    """x [B, Cin, H, W] channels_last bf16 -> y [B, Cout, 2H, 2W] channels_last bf16 (raw ConvTranspose2d output)."""
+    lib = load()
+    x = _nhwc_bf16(x, "x")
+    b, cin, h, w = x.shape
+    cout = w_phase.shape[1]
+    y = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        ev = timer.start("epi_deconv4x4s2_fwd")
+        _check(lib.epi_deconv4x4s2_fwd(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _stream()), "epi_deconv4x4s2_fwd")
+        timer.stop(ev)
+    return y
+
+
+def deconv4x4s2_bwd_data(dy, w_bwd):
+    """dy [B, Cout, 2H, 2W] channels_last bf16 -> dx [B, Cin, H, W] channels_last bf16."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    b, cout, h2, w2 = dy.shape
+    cin = w_bwd.shape[0]
+    dx = torch.empty((b, cin, h2 // 2, w2 // 2), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    with torch.cuda.device(dy.device):
+        ev = timer.start("epi_deconv4x4s2_bwd_data")
+        _check(lib.epi_deconv4x4s2_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h2 // 2, w2 // 2, cin, cout, _stream()),
+               "epi_deconv4x4s2_bwd_data")
+        timer.stop(ev)
+    return dx

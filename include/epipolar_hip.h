@@ -137,6 +137,34 @@ int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_m
                          int method, double tolerance, int max_iter,
                          float* label, float* weight, double* X_out, epi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Deconvolution head on the matrix cores -- replaces the cuDNN calls behind
+ * lib/models/pose3d_resnet.py:158-183 (ConvTranspose2d k=4 s=2 p=1, no bias) and :116-122 (final 1x1 conv).
+ * Activations are NHWC bf16; accumulation is fp32 (v_mfma_f32_32x32x16_bf16).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* C[M][N] (bf16 or f32, row stride ldc) = A[M][K] (bf16, row stride lda) * Bt[N][K]^T (bf16, row stride ldb)
+ * (+ bias[N] f32 or NULL).  K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
+ * The final 1x1 convolution is this with A = activations [B*H*W][Cin], Bt = weight [Cout][Cin]; its
+ * backward-data is this with A = dlogits [B*H*W][Cout], Bt = weight^T [Cin][Cout]. */
+int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype,
+                  int M, int N, int K, const float* bias, epi_stream_t stream);
+
+/* Re-pack a ConvTranspose2d weight [Cin][Cout][4][4] (bf16) into the two GEMM operand forms:
+ *   w_phase [4][Cout][4*Cin] : per output-parity phase (2*(oh&1)+(ow&1)) the 2x2 taps that reach it
+ *   w_bwd   [Cin][16*Cout]   : all 16 taps, for backward-data.                   Either may be NULL. */
+int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout, void* w_phase, void* w_bwd,
+                                epi_stream_t stream);
+
+/* y [B][2H][2W][Cout] = ConvTranspose2d(x [B][H][W][Cin]) as 4 implicit (gather) GEMMs with K = 4*Cin.
+ * Cin % 64 == 0, Cout % 4 == 0.  Raw output (BatchNorm + ReLU follow, pose3d_resnet.py:180-181). */
+int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
+                        epi_stream_t stream);
+
+/* dx [B][H][W][Cin] from dy [B][2H][2W][Cout]: a 4x4 stride-2 implicit GEMM with K = 16*Cout.  Cout % 64 == 0. */
+int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                             epi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

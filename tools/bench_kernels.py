@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the hand-written kernels (run on the GPU box):  python tools/bench_kernels.py [what ...]
+what: softargmax gemm deconv tri.  Prints one line per case: time, achieved GB/s or TFLOP/s, fraction of peak."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epipolarpose_amd import hip  # noqa: E402
+
+DEV = torch.device("cuda:0")
+HBM, MFMA = 8000.0, 2500.0
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def bench_softargmax():
+    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        for cl in (False, True):
+            x = torch.randn(32, 17 * 64, 64, 64, device=DEV).to(dt)
+            if cl:
+                x = x.contiguous(memory_format=torch.channels_last)
+            nbytes = x.numel() * x.element_size()
+            xyz, rmax, rsum = hip.softargmax3d_fwd(x, 17)
+            g = torch.randn(32, 51, device=DEV)
+            tf = timeit(lambda: hip.softargmax3d_fwd(x, 17))
+            tb = timeit(lambda: hip.softargmax3d_bwd(x, 17, rmax, rsum, xyz, g))
+            print("softargmax %-4s %-4s fwd %.4f ms %7.1f GB/s (%.3f)   bwd %.4f ms %7.1f GB/s (%.3f)" % (
+                name, "nhwc" if cl else "nchw", tf, nbytes / tf / 1e6, nbytes / tf / 1e6 / HBM,
+                tb, 2 * nbytes / tb / 1e6, 2 * nbytes / tb / 1e6 / HBM), flush=True)
+
+
+def bench_gemm():
+    for m, n, k in ((131072, 1088, 256), (131072, 256, 1088), (32768, 256, 1024), (8192, 8192, 8192), (4096, 4096, 4096)):
+        a = torch.randn(m, k, device=DEV).to(torch.bfloat16)
+        bt = torch.randn(n, k, device=DEV).to(torch.bfloat16)
+        out = torch.empty(m, n, device=DEV, dtype=torch.bfloat16)
+        t = timeit(lambda: hip.gemm_bf16(a, bt, out=out))
+        tt = timeit(lambda: torch.matmul(a, bt.t(), out=out))
+        fl = 2.0 * m * n * k
+        print("gemm %6dx%5dx%5d  ours %.4f ms %7.1f TF (%.3f)   torch(hipBLASLt) %.4f ms %7.1f TF" % (
+            m, n, k, t, fl / t / 1e9, fl / t / 1e9 / MFMA, tt, fl / tt / 1e9), flush=True)
+
+
+def bench_deconv():
+    import torch.nn.functional as F
+    for b, h, cin, cout in ((32, 8, 2048, 256), (32, 16, 256, 256), (32, 32, 256, 256)):
+        x = torch.randn(b, cin, h, h, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cin, cout, 4, 4, device=DEV) * 0.02)
+        wp, wb = hip.deconv_pack_weight(w)
+        wb16 = w.to(torch.bfloat16)
+        fl = 2.0 * b * h * h * 16 * cin * cout
+        t = timeit(lambda: hip.deconv4x4s2_fwd(x, wp))
+        tt = timeit(lambda: F.conv_transpose2d(x, wb16, None, stride=2, padding=1))
+        dy = torch.randn(b, cout, 2 * h, 2 * h, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        t2 = timeit(lambda: hip.deconv4x4s2_bwd_data(dy, wb))
+        print("deconv B%d %dx%d %d->%d  fwd ours %.4f ms %6.1f TF  MIOpen %.4f ms %6.1f TF | bwd-data ours %.4f ms %6.1f TF" % (
+            b, h, h, cin, cout, t, fl / t / 1e9, tt, fl / tt / 1e9, t2, fl / t2 / 1e9), flush=True)
+
+
+def bench_tri():
+    g_n, j, v_n = 1 << 20, 17, 4
+    kps = torch.rand(v_n * g_n, j, 2, device=DEV) * 1000
+    from epipolarpose_amd.synthetic import make_cameras
+    pm = torch.cat([torch.from_numpy(c["projection_matrix"]).float().expand(g_n, 3, 4) for c in make_cameras(v_n)]).contiguous().to(DEV)
+    nbytes = (v_n * j * 2 + v_n * 12 + j * 3) * 4.0 * g_n
+    for method in ("ls", "iterative", "dlt"):
+        t = timeit(lambda: hip.triangulate(kps, pm, v_n, method), iters=5, warm=1)
+        print("triangulate %-9s f32 storage 2^20 groups x 4 views: %.3f ms  %7.1f GB/s (%.3f of HBM peak)" % (
+            method, t, nbytes / t / 1e6, nbytes / t / 1e6 / HBM), flush=True)
+
+
+if __name__ == "__main__":
+    hip.load()
+    what = sys.argv[1:] or ["softargmax", "gemm", "deconv", "tri"]
+    for w in what:
+        globals()["bench_" + w]()
