@@ -1,19 +1,23 @@
-// Training-mode BatchNorm2d + ReLU on NHWC bf16 activations for the deconvolution head (gfx950).
+// BatchNorm2d (+ residual add) (+ ReLU) on NHWC bf16 activations, training and inference, for gfx950.
 //
-// Replaces `nn.BatchNorm2d(momentum=0.1)` + `nn.ReLU` after each ConvTranspose2d of the reference
-// (lib/models/pose3d_resnet.py:180-181).  All kernels are HBM streaming kernels over x [R][C]
-// (R = B*H*W rows, C channels contiguous), 16 bytes (8 channels) per lane per access, with the
-// per-channel reductions done in registers -> LDS -> one fp32 atomic per channel per workgroup.
-//   forward : stats (1 read) -> finalize (tiny) -> apply (1 read + 1 write)
-//   backward: reduce (2 reads) -> apply (2 reads + 1 write)
+// Replaces, for every BatchNorm of the reference network (lib/models/pose3d_resnet.py: bn1, layer*.bn{1,2,3},
+// downsample.1, deconv_layers.{1,4,7}), the cuDNN/MIOpen batch-norm kernels (3 forward + 3 backward launches
+// per layer) plus the separate ReLU, residual-add and threshold-backward element-wise kernels.  At batch 32 these
+// HBM-bound passes -- not the convolutions -- dominate the step (profiles/), so they are fused:
+//   forward : stats (1 read) -> finalize (per-channel, tiny) -> apply: y = relu(x*scale + shift [+ res])
+//   backward: reduce (dbeta, dgamma: reads dy, x [, y]) -> apply: dx [and dres] in one pass
+// x [R][C]: R = B*H*W rows, C channels contiguous (C % 8 == 0); 16 bytes (8 channels) per lane per access;
+// per-channel reductions: registers -> LDS -> one fp32 atomic per channel per workgroup.
 #include "common.h"
 
 namespace epi {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_ROWS_PER_WG = 256;
+constexpr int BN_ROWS_PER_WG = 128;
 
-// sums[0..C) = sum x, sums[C..2C) = sum x^2      (pre-zeroed by the caller)
+enum { BN_MASK_NONE = 0, BN_MASK_FROM_X = 1, BN_MASK_FROM_Y = 2 };
+
+// sums[0..C) = sum x, sums[C..2C) = sum x^2      (zeroed by the previous finalize / the first-use memset)
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
                                                               float* __restrict__ sums) {
     extern __shared__ float red[];                 // [rlanes][2][C]
@@ -44,49 +48,68 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
     }
 }
 
-// mean / rstd, running statistics (momentum, unbiased variance), fused affine scale/shift
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
+// Training: mean / rstd from the batch sums, running statistics (momentum, unbiased variance), fused affine
+// scale/shift; clears the sums for the next call and bumps num_batches_tracked.
+// Inference (sums == nullptr): scale/shift from the running statistics.
+__global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ running_var, long long* __restrict__ num_batches, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches && sums) num_batches[0] += 1;
     if (c >= C) return;
-    const double m = (double)sums[c] / (double)R;
-    double var = (double)sums[C + c] / (double)R - m * m;
-    if (var < 0) var = 0;
+    double m, var;
+    if (sums) {
+        m = (double)sums[c] / (double)R;
+        var = (double)sums[C + c] / (double)R - m * m;
+        if (var < 0) var = 0;
+        sums[c] = 0.f;
+        sums[C + c] = 0.f;
+        if (running_mean) {
+            const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    } else {
+        m = running_mean[c];
+        var = running_var[c];
+    }
     const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    mean[c] = (float)m;
-    rstd[c] = rs;
+    if (mean) { mean[c] = (float)m; rstd[c] = rs; }
     const float sc = gamma[c] * rs;
     scale[c] = sc;
     shift[c] = beta[c] - (float)m * sc;
-    if (running_mean) {
-        const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
 }
 
-// y = relu(x * scale[c] + shift[c])
-__global__ __launch_bounds__(BN_THREADS) void bn_relu_apply_kernel(const unsigned short* __restrict__ x, long long nvec, int C,
-                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                   unsigned short* __restrict__ y) {
+// y = act(x * scale[c] + shift[c] (+ res))
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
+                                                              long long nvec, int C, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, unsigned short* __restrict__ y) {
     const int cg = C >> 3;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
         const int g = (int)(i % cg);
-        float v[8];
+        float v[8], r[8];
         Elem<unsigned short>::load(x + i * 8, v);
+        if (RES) Elem<unsigned short>::load(res + i * 8, r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * scale[g * 8 + k] + shift[g * 8 + k], 0.f);
+        for (int k = 0; k < 8; ++k) {
+            float t = v[k] * scale[g * 8 + k] + shift[g * 8 + k];
+            if (RES) t += r[k];
+            v[k] = RELU ? fmaxf(t, 0.f) : t;
+        }
         Elem<unsigned short>::store(y + i * 8, v);
     }
 }
 
-// sums[0..C) = sum dz, sums[C..2C) = sum dz * xhat,  dz = dy * (x*scale+shift > 0),  xhat = (x - mean) * rstd
-__global__ __launch_bounds__(BN_THREADS) void bn_relu_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
-                                                                        long long R, int C, const float* __restrict__ scale,
-                                                                        const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                        const float* __restrict__ rstd, float* __restrict__ sums) {
+// sums[0..C) = sum dz, sums[C..2C) = sum dz * xhat,   dz = dy * mask,   xhat = (x - mean) * rstd
+//   MASK_FROM_X: mask = (x*scale + shift > 0)     MASK_FROM_Y: mask = (y > 0)     MASK_NONE: 1
+template <int MASK>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                                   const unsigned short* __restrict__ y, long long R, int C,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   float* __restrict__ sums) {
     extern __shared__ float red[];
     const int cg = C >> 3;
     const int rlanes = BN_THREADS / cg;
@@ -101,12 +124,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_relu_bwd_reduce_kernel(const un
     const long long r1 = (r0 + BN_ROWS_PER_WG < R) ? r0 + BN_ROWS_PER_WG : R;
     if (rl < rlanes) {
         for (long long r = r0 + rl; r < r1; r += rlanes) {
-            float xv[8], gv[8];
+            float xv[8], gv[8], yv[8];
             Elem<unsigned short>::load(x + r * C + g * 8, xv);
             Elem<unsigned short>::load(dy + r * C + g * 8, gv);
+            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + g * 8, yv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dz = (xv[k] * sc[k] + sh[k] > 0.f) ? gv[k] : 0.f;
+                bool on = true;
+                if (MASK == BN_MASK_FROM_X) on = xv[k] * sc[k] + sh[k] > 0.f;
+                if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
+                const float dz = on ? gv[k] : 0.f;
                 s[k] += dz;
                 q[k] += dz * (xv[k] - mu[k]) * rs[k];
             }
@@ -123,79 +150,124 @@ __global__ __launch_bounds__(BN_THREADS) void bn_relu_bwd_reduce_kernel(const un
     }
 }
 
-// dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  also emits dgamma = sums[C+c], dbeta = sums[c] (fp32)
-__global__ __launch_bounds__(BN_THREADS) void bn_relu_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
-                                                                       long long nvec, long long R, int C, const float* __restrict__ gamma,
-                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                       const float* __restrict__ sums, unsigned short* __restrict__ dx) {
+// dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  dres = dz (residual branch gradient) when requested
+template <int MASK, bool DRES>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                                  const unsigned short* __restrict__ y, long long nvec, long long R, int C,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ sums,
+                                                                  unsigned short* __restrict__ dx, unsigned short* __restrict__ dres) {
     const int cg = C >> 3;
     const float inv_r = 1.f / (float)R;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
         const int g = (int)(i % cg);
-        float xv[8], gv[8], o[8];
+        float xv[8], gv[8], yv[8], o[8], z[8];
         Elem<unsigned short>::load(x + i * 8, xv);
         Elem<unsigned short>::load(dy + i * 8, gv);
+        if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + i * 8, yv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = g * 8 + k;
-            const float dz = (xv[k] * scale[c] + shift[c] > 0.f) ? gv[k] : 0.f;
+            bool on = true;
+            if (MASK == BN_MASK_FROM_X) on = xv[k] * scale[c] + shift[c] > 0.f;
+            if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
+            const float dz = on ? gv[k] : 0.f;
             const float xh = (xv[k] - mean[c]) * rstd[c];
+            z[k] = dz;
             o[k] = gamma[c] * rstd[c] * (dz - sums[c] * inv_r - xh * sums[C + c] * inv_r);
         }
         Elem<unsigned short>::store(dx + i * 8, o);
+        if (DRES) Elem<unsigned short>::store(dres + i * 8, z);
     }
 }
 
 static inline bool bn_shape_ok(long long R, int C) { return R > 0 && C > 0 && C % 8 == 0 && (C >> 3) <= BN_THREADS; }
 static inline unsigned stream_grid(long long nvec) {
     const long long want = (nvec + BN_THREADS - 1) / BN_THREADS;
-    return (unsigned)(want < 4096 ? want : 4096);
+    return (unsigned)(want < 8192 ? want : 8192);
 }
 
 }  // namespace epi
 
 using namespace epi;
 
-extern "C" int epi_bn_relu_fwd(const void* x, long long R, int C, const float* gamma, const float* beta, float eps, float momentum,
-                               float* running_mean, float* running_var, float* mean, float* rstd, float* scale_shift,
-                               float* sums_ws, void* y, epi_stream_t stream) {
-    if (!x || !gamma || !beta || !mean || !rstd || !scale_shift || !sums_ws || !y) return EPI_ERR_INVALID_ARGUMENT;
+extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
+                              float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws, void* y,
+                              epi_stream_t stream) {
+    if (!x || !gamma || !beta || !scale_shift || !y) return EPI_ERR_INVALID_ARGUMENT;
+    if (training && (!mean || !rstd || !sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
+    if (!training && (!running_mean || !running_var)) return EPI_ERR_INVALID_ARGUMENT;
     if ((running_mean == nullptr) != (running_var == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums_ws, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) return EPI_ERR_LAUNCH;
-    const int rlanes = BN_THREADS / (C >> 3);
-    const unsigned gridr = (unsigned)((R + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(gridr), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                       (const unsigned short*)x, R, C, sums_ws);
-    EPI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, sums_ws, R, C, gamma, beta, eps, momentum,
-                       running_mean, running_var, mean, rstd, scale_shift, scale_shift + C);
+    if (training) {
+        const int rlanes = BN_THREADS / (C >> 3);
+        const unsigned gridr = (unsigned)((R + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(gridr), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
+                           (const unsigned short*)x, R, C, sums_ws);
+        EPI_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C);
     EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
-    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(stream_grid(nvec)), dim3(BN_THREADS), 0, st, (const unsigned short*)x, nvec, C,
-                       scale_shift, scale_shift + C, (unsigned short*)y);
+    const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
+    const unsigned short* xs = (const unsigned short*)x;
+    const unsigned short* rs = (const unsigned short*)residual;
+    unsigned short* ys = (unsigned short*)y;
+    if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
+    else if (residual) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
-extern "C" int epi_bn_relu_bwd(const void* dy, const void* x, long long R, int C, const float* gamma, const float* mean,
-                               const float* rstd, const float* scale_shift, float* dgamma_dbeta_ws, void* dx, epi_stream_t stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dgamma_dbeta_ws || !dx) return EPI_ERR_INVALID_ARGUMENT;
+extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
+                              const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                              epi_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
+    if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(dgamma_dbeta_ws, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) return EPI_ERR_LAUNCH;
+    if (hipMemsetAsync(dbeta_dgamma, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) return EPI_ERR_LAUNCH;
     const int rlanes = BN_THREADS / (C >> 3);
     const unsigned gridr = (unsigned)((R + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG);
-    hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(gridr), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                       (const unsigned short*)dy, (const unsigned short*)x, R, C, scale_shift, scale_shift + C, mean, rstd,
-                       dgamma_dbeta_ws);
+    const size_t lds = (size_t)rlanes * 2 * C * sizeof(float);
+    const int mask = !relu ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
+    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x, *ys = (const unsigned short*)y;
+    const float *sc = scale_shift, *sh = scale_shift + C;
+#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(gridr), dim3(BN_THREADS), lds, st, dys, xs, ys, R, C, sc, sh, mean, rstd, dbeta_dgamma)
+    if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
+    else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
+    else EPI_BN_RED(BN_MASK_FROM_Y);
+#undef EPI_BN_RED
     EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
-    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(stream_grid(nvec)), dim3(BN_THREADS), 0, st, (const unsigned short*)dy,
-                       (const unsigned short*)x, nvec, R, C, gamma, scale_shift, scale_shift + C, mean, rstd, dgamma_dbeta_ws,
-                       (unsigned short*)dx);
+    const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
+    unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
+#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs)
+    if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
+    else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }
+    else { if (dres) EPI_BN_APP(BN_MASK_FROM_Y, true); else EPI_BN_APP(BN_MASK_FROM_Y, false); }
+#undef EPI_BN_APP
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+// Per-column sum and sum of squares of a bf16 matrix x [R][C] -> sums [2C] f32 (bias gradient of the final conv:
+// db = sum over rows of dlogits; torch computes it as a separate reduction in Conv2d's backward).
+extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
+    if (!x || !sums) return EPI_ERR_INVALID_ARGUMENT;
+    if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 2 * (size_t)C * sizeof(float), st) != hipSuccess) return EPI_ERR_LAUNCH;
+    const int rlanes = BN_THREADS / (C >> 3);
+    const unsigned gridr = (unsigned)((R + BN_ROWS_PER_WG - 1) / BN_ROWS_PER_WG);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(gridr), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
+                       (const unsigned short*)x, R, C, sums);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

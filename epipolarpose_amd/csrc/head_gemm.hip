@@ -288,3 +288,201 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// "TN" GEMM for the weight gradients:  C[i][j] = sum_r A[r][i] * B(r)[j]   (reduction over the ROW index of both
+// operands: r enumerates batch*pixels).  Both tiles are staged row-major ([r][i], [r][j], 288-byte padded rows) and
+// the MFMA operands (8 consecutive r per lane) are produced by the LDS transpose read ds_read_b64_tr_b16
+// (a 16-lane group reads a 4(r) x 16(col) block; lane c receives column c).  B may be an implicit gather
+// (ConvTranspose2d weight gradient: rows of dOut at (2*ih-1+kh, 2*iw-1+kw) for tap blockIdx.z).
+// The reduction is split across blockIdx.y; each split writes its own fp32 slab (reduced by slab_reduce_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+namespace epi {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int TN_ROW_BYTES = 288;                       // 128 cols * 2 B + 32 B pad: 4 consecutive rows hit disjoint banks
+constexpr int TN_TILE_BYTES = GBK * TN_ROW_BYTES;       // 18 KiB per operand tile
+
+struct GemmTnArgs {
+    const unsigned short* A;      // [R][lda]
+    const unsigned short* B;      // plain [R][ldb] or gather source [n][Hs][Ws][ldb]
+    float* C;                     // slabs [nsplit][ntap][I][J]
+    int R, I, J, lda, ldb;
+    int rows_per_split;
+    GemmGather gb;                // gather for B (enabled = 0: plain)
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col, int lane_c) {
+    // lane c of a 16-lane group addresses row row0 + (c >> 2) (and +4 for the second half), 4 columns at col + 4*(c & 3)
+    const char* p = tile + (row0 + (lane_c >> 2)) * TN_ROW_BYTES + (col + 4 * (lane_c & 3)) * 2;
+    struct { s16x4 lo, hi; } v;
+    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TN_ROW_BYTES));
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(GTHREADS, 2) void head_gemm_tn_kernel(GemmTnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_j = (p.J + GBN - 1) / GBN;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    const int i0 = tile_i * GBM, j0 = tile_j * GBN;
+    const int split = blockIdx.y, tap = blockIdx.z;
+    const int r_begin = split * p.rows_per_split;
+    const int r_end = min(p.R, r_begin + p.rows_per_split);
+
+    const int srow = tid >> 4, schunk = tid & 15;          // 16 rows x 16 chunks(16 B) per pass, 4 passes per 64-row tile
+    const bool a_col_ok = i0 + schunk * 8 < p.I, b_col_ok = j0 + schunk * 8 < p.J;
+    uint4v ra[4], rb[4];
+    auto load_tiles = [&](int r0) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = r0 + ps * 16 + srow;
+            const bool rok = r < r_end;
+            uint4v z; z.x = z.y = z.z = z.w = 0u;
+            ra[ps] = (rok && a_col_ok) ? *reinterpret_cast<const uint4v*>(p.A + (long long)r * p.lda + i0 + schunk * 8) : z;
+            bool ok = rok && b_col_ok;
+            long long off;
+            if (p.gb.enabled) {
+                const int hw = p.gb.Hg * p.gb.Wg;
+                const int n = r / hw, rem = r - n * hw;
+                const int ih = rem / p.gb.Wg, iw = rem - ih * p.gb.Wg;
+                const int y = ih * p.gb.stride + p.gb.dy[tap], x = iw * p.gb.stride + p.gb.dx[tap];
+                ok = ok && (unsigned)y < (unsigned)p.gb.Hs && (unsigned)x < (unsigned)p.gb.Ws;
+                off = (((long long)n * p.gb.Hs + y) * p.gb.Ws + x) * p.ldb + j0 + schunk * 8;
+            } else {
+                off = (long long)r * p.ldb + j0 + schunk * 8;
+            }
+            rb[ps] = ok ? *reinterpret_cast<const uint4v*>(p.B + off) : z;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* a_s = smem + buf * 2 * TN_TILE_BYTES;
+        char* b_s = a_s + TN_TILE_BYTES;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int o = (ps * 16 + srow) * TN_ROW_BYTES + schunk * 16;
+            *reinterpret_cast<uint4v*>(a_s + o) = ra[ps];
+            *reinterpret_cast<uint4v*>(b_s + o) = rb[ps];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (r_end - r_begin + GBK - 1) / GBK;
+    if (nk > 0) {
+        load_tiles(r_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int lane_c = lane & 15, grp = lane >> 4;
+    const int cblk = 16 * (grp & 1), khalf = grp >> 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(r_begin + (kt + 1) * GBK);
+        const char* a_s = smem + buf * 2 * TN_TILE_BYTES;
+        const char* b_s = a_s + TN_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = tr_frag(a_s, ks * 16 + 8 * khalf, wm * 64 + t * 32 + cblk, lane_c);
+                bfr[t] = tr_frag(b_s, ks * 16 + 8 * khalf, wn * 64 + t * 32 + cblk, lane_c);
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti], bfr[tj], acc[ti][tj], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i][j]: lane holds column j = lane & 31, rows i = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+    float* slab = p.C + ((long long)split * gridDim.z + tap) * p.I * p.J;
+    const int fcol = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int j = j0 + wn * 64 + tj * 32 + fcol;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int i = i0 + wm * 64 + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
+                if (i < p.I && j < p.J) slab[(long long)i * p.J + j] = acc[ti][tj][reg];
+            }
+        }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[(long long)k * n + e];
+    out[e] = s;
+}
+
+}  // namespace epi
+
+static int pick_split(int R, long long tiles, int ntap) {
+    // enough workgroups to fill 256 CUs x 2, but at least 1024 reduction rows per split
+    int nsplit = (int)((1024 + tiles * ntap - 1) / (tiles * ntap));
+    const int max_split = (R + 1023) / 1024;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    return nsplit;
+}
+
+static int launch_tn(GemmTnArgs a, int ntap, float* out, float* slab_ws, size_t slab_bytes, hipStream_t st) {
+    if (!a.A || !a.B || !out || !slab_ws || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8) return EPI_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15u) return EPI_ERR_UNSUPPORTED;
+    const long long tiles = (long long)((a.I + GBM - 1) / GBM) * ((a.J + GBN - 1) / GBN);
+    const int nsplit = pick_split(a.R, tiles, ntap);
+    int rps = (a.R + nsplit - 1) / nsplit;
+    rps = (rps + GBK - 1) / GBK * GBK;
+    const int nsplit2 = (a.R + rps - 1) / rps;
+    const long long n = (long long)ntap * a.I * a.J;
+    if ((size_t)nsplit2 * n * sizeof(float) > slab_bytes) return EPI_ERR_WORKSPACE;
+    a.rows_per_split = rps;
+    a.C = slab_ws;
+    hipLaunchKernelGGL(head_gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)nsplit2, (unsigned)ntap), dim3(GTHREADS), 4 * TN_TILE_BYTES, st, a);
+    EPI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab_ws, nsplit2, n, out);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap) {
+    if (R <= 0 || I <= 0 || J <= 0 || ntap <= 0) return 0;
+    const long long tiles = (long long)((I + GBM - 1) / GBM) * ((J + GBN - 1) / GBN);
+    return (size_t)pick_split(R, tiles, ntap) * ntap * I * J * sizeof(float);
+}
+
+// C[I][J] (f32) = A[R][I]^T * B[R][J]   (weight gradient of the 1x1 convolution: A = dlogits, B = activations)
+extern "C" int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J, void* workspace,
+                                size_t workspace_bytes, epi_stream_t stream) {
+    GemmTnArgs a = {};
+    a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.R = R; a.I = I; a.J = J; a.lda = lda; a.ldb = ldb;
+    return launch_tn(a, 1, C, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// dW_taps[16][Cin][Cout] (f32, tap = kh*4 + kw) of ConvTranspose2d(k4 s2 p1): x [B][H][W][Cin], dy [B][2H][2W][Cout]
+extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    GemmTnArgs a = {};
+    a.A = (const unsigned short*)x; a.B = (const unsigned short*)dy; a.R = B * H * W; a.I = Cin; a.J = Cout; a.lda = Cin; a.ldb = Cout;
+    a.gb.enabled = 1; a.gb.Hg = H; a.gb.Wg = W; a.gb.Hs = 2 * H; a.gb.Ws = 2 * W; a.gb.Cs = Cout; a.gb.stride = 2;
+    for (int kh = 0; kh < 4; ++kh)
+        for (int kw = 0; kw < 4; ++kw) { a.gb.dy[4 * kh + kw] = kh - 1; a.gb.dx[4 * kh + kw] = kw - 1; }
+    return launch_tn(a, 16, dw_taps, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -43,6 +43,13 @@ _SIGNATURES = {
     "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _vp, _vp]),
+    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -402,3 +409,89 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
                "epi_deconv4x4s2_bwd_data")
         timer.stop(ev)
     return dx
+
+
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, training, momentum, eps,
+               relu):
+    """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last).
+    -> (y, mean, rstd, scale_shift); mean/rstd are None in inference."""
+    lib = load()
+    x = _nhwc_bf16(x, "x")
+    b, c, h, w = x.shape
+    if residual is not None:
+        residual = _nhwc_bf16(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("residual shape mismatch")
+    y = torch.empty_like(x)
+    dev = x.device
+    mean = torch.empty(c, dtype=torch.float32, device=dev) if training else None
+    rstd = torch.empty(c, dtype=torch.float32, device=dev) if training else None
+    scale_shift = torch.empty(2 * c, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
+                                  int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
+                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(y), _stream()), "epi_bn_act_fwd")
+    return y, mean, rstd, scale_shift
+
+
+def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres):
+    """-> (dx, dres or None, dgamma, dbeta)."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    b, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
+                                  int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
+    return dx, dres, sums[c:], sums[:c]
+
+
+def gemm_tn_bf16(a, b):
+    """C[I, J] (f32) = a[R, I]^T @ b[R, J]; a, b bf16 with unit inner stride (weight gradient of the 1x1 conv)."""
+    lib = load()
+    _dev(a, torch.bfloat16, "a")
+    _dev(b, torch.bfloat16, "b")
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if b.stride(1) != 1:
+        b = b.contiguous()
+    r, i = a.shape
+    j = b.shape[1]
+    out = torch.empty((i, j), dtype=torch.float32, device=a.device)
+    ws = _workspace(lib.epi_gemm_tn_workspace_bytes(r, i, j, 1), a.device)
+    with torch.cuda.device(a.device):
+        ev = timer.start("epi_gemm_tn_bf16")
+        _check(lib.epi_gemm_tn_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), r, i, j, _ptr(ws), ws.numel(), _stream()),
+               "epi_gemm_tn_bf16")
+        timer.stop(ev)
+    return out
+
+
+def deconv4x4s2_bwd_weight(x, dy):
+    """x [B, Cin, H, W], dy [B, Cout, 2H, 2W] (channels_last bf16) -> dW [Cin, Cout, 4, 4] f32."""
+    lib = load()
+    x, dy = _nhwc_bf16(x, "x"), _nhwc_bf16(dy, "dy")
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    taps = torch.empty((16, cin, cout), dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.epi_gemm_tn_workspace_bytes(b * h * w, cin, cout, 16), x.device)
+    with torch.cuda.device(x.device):
+        ev = timer.start("epi_deconv4x4s2_bwd_weight")
+        _check(lib.epi_deconv4x4s2_bwd_weight(_ptr(x), _ptr(dy), _ptr(taps), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
+               "epi_deconv4x4s2_bwd_weight")
+        timer.stop(ev)
+    return taps.reshape(4, 4, cin, cout).permute(2, 3, 0, 1).contiguous()
+
+
+def column_sum_bf16(x):
+    """x [R, C] bf16 -> per-column sums [C] f32."""
+    lib = load()
+    _dev(x, torch.bfloat16, "x")
+    x = x if x.is_contiguous() else x.contiguous()
+    r, c = x.shape
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(sums), _stream()), "epi_column_sums_bf16")
+    return sums[:c]

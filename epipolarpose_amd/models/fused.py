@@ -1,0 +1,137 @@
+"""Network building blocks backed by the HIP kernels of ``libepipolar_hip.so``.
+
+* ``FusedBatchNormAct``  -- BatchNorm2d (+ residual add) (+ ReLU) in one apply pass (``epi_bn_act_fwd/bwd``); same
+  parameters / buffers (and therefore ``state_dict`` keys) as ``nn.BatchNorm2d``.
+* ``Deconv4x4s2``        -- ``nn.ConvTranspose2d(k=4, s=2, p=1)`` as MFMA implicit GEMMs (``epi_deconv4x4s2_*``).
+* ``Conv1x1``            -- the final 1x1 convolution as an MFMA GEMM (``epi_gemm_bf16``).
+All activations are NHWC (``channels_last``) bf16; parameters stay fp32 (master weights).  No CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+
+
+def _nhwc_bf16(x):
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+class _BNActFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, module, relu):
+        training = module.training
+        y, mean, rstd, scale_shift = hip.bn_act_fwd(
+            x, residual, weight, bias, module.running_mean, module.running_var, module.num_batches_tracked,
+            module.sums_ws, training, module.momentum, module.eps, relu)
+        ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
+        if training:
+            ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, rstd, scale_shift)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("FusedBatchNormAct: backward through inference-mode statistics is not supported")
+        x, y, weight, mean, rstd, scale_shift = ctx.saved_tensors
+        dx, dres, dgamma, dbeta = hip.bn_act_bwd(dy, x, y, weight, mean, rstd, scale_shift, ctx.relu, ctx.has_res)
+        return dx, dgamma, dbeta, dres, None, None
+
+
+class FusedBatchNormAct(nn.Module):
+    """y = act(BN(x) [+ residual]);  training-mode semantics of ``nn.BatchNorm2d(momentum)``: biased batch variance
+    for normalisation, unbiased for the running estimate (pose3d_resnet.py:24,57,61,65,133,174 use momentum 0.1)."""
+
+    def __init__(self, num_features, momentum=0.1, eps=1e-5, relu=True):
+        super().__init__()
+        self.num_features, self.momentum, self.eps, self.relu = num_features, momentum, eps, relu
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel scratch, kept zero
+
+    def forward(self, x, residual=None):
+        x = _nhwc_bf16(x)
+        if residual is not None:
+            residual = _nhwc_bf16(residual)
+        return _BNActFunction.apply(x, self.weight, self.bias, residual, self, self.relu)
+
+    def extra_repr(self):
+        return "{num_features}, eps={eps}, momentum={momentum}, relu={relu}".format(**self.__dict__)
+
+
+class _DeconvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        w_phase, w_bwd = hip.deconv_pack_weight(weight, want_phase=True, want_bwd=True)
+        ctx.save_for_backward(x, weight, w_bwd)
+        return hip.deconv4x4s2_fwd(x, w_phase)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, w_bwd = ctx.saved_tensors
+        dy = _nhwc_bf16(dy)
+        dx = hip.deconv4x4s2_bwd_data(dy, w_bwd) if ctx.needs_input_grad[0] else None
+        dw = hip.deconv4x4s2_bwd_weight(x, dy).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class Deconv4x4s2(nn.Module):
+    """ConvTranspose2d(kernel 4, stride 2, padding 1, no bias); weight [Cin, Cout, 4, 4] as in the reference."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 4, 4))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.ConvTranspose2d default initialisation
+
+    def forward(self, x):
+        return _DeconvFunction.apply(_nhwc_bf16(x), self.weight)
+
+
+class _Conv1x1Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        b, cin, h, w = x.shape
+        cout = weight.shape[0]
+        w2 = weight.detach().reshape(cout, cin).to(torch.bfloat16)
+        x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, cin)          # NHWC view, no copy
+        out = hip.gemm_bf16(x2, w2, bias=None if bias is None else bias.detach().float())
+        ctx.save_for_backward(x, w2)
+        ctx.has_bias = bias is not None
+        return out.reshape(b, h, w, cout).permute(0, 3, 1, 2)       # logical NCHW, NHWC memory
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        b, cin, h, w = x.shape
+        cout = w2.shape[0]
+        dy2 = _nhwc_bf16(dy).permute(0, 2, 3, 1).reshape(b * h * w, cout)
+        x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, cin)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.gemm_bf16(dy2, w2.t().contiguous()).reshape(b, h, w, cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = hip.gemm_tn_bf16(dy2, x2).reshape(cout, cin, 1, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = hip.column_sum_bf16(dy2)
+        return dx, dw, db
+
+
+class Conv1x1(nn.Module):
+    """1x1 convolution with bias; weight [Cout, Cin, 1, 1] as ``nn.Conv2d`` (pose3d_resnet.py:116-122)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.Conv2d default initialisation
+        bound = 1.0 / in_channels ** 0.5
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return _Conv1x1Function.apply(_nhwc_bf16(x), self.weight, self.bias)

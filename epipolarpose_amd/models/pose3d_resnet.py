@@ -5,9 +5,11 @@ API surface kept: ``get_pose_net(cfg, is_train)``, ``PoseResNet.forw
 compatibility surface proper -- the ``state_dict()`` key names and shapes of the reference (pose3d_resnet.py:93-126):
 ``conv1 bn1 layer{1..4}.{i}.{conv,bn}{1..3} layer*.0.downsample.{0,1} deconv_layers.{0,1,3,4,6,7} final_layer``.
 
-MI355X-first choices: the network is built channels-last (NHWC) so MIOpen/hipBLASLt see their native layout and the
-head's MFMA kernels read LDS-stageable rows; the backbone runs under bf16 autocast; residual units are generated
-from a per-depth plan table instead of two hand-written block classes.
+MI355X-first choices: the network is built channels-last (NHWC) bf16 end to end; backbone convolutions go to
+MIOpen/hipBLASLt under bf16 autocast; EVERY BatchNorm (+ReLU, + residual add) is one fused HIP apply pass
+(``FusedBatchNormAct``) because at batch 32 those HBM-bound passes dominate the step; the deconvolution head and the
+final 1x1 convolution are hand-written MFMA implicit GEMMs (``Deconv4x4s2``, ``Conv1x1``); residual units are
+generated from a per-depth plan table instead of two hand-written block classes.  GPU only (no CPU path).
 """
 import logging
 import os
@@ -15,6 +17,8 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
+
+from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct
 
 BN_MOMENTUM = 0.1
 logger = logging.getLogger(__name__)
@@ -40,24 +44,22 @@ class ResidualUnit(nn.Module):
             cout = planes * mult
             setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=k, stride=stride if strided else 1,
                                                   padding=k // 2, bias=False))
-            setattr(self, "bn%d" % i, nn.BatchNorm2d(cout, momentum=BN_MOMENTUM))
+            setattr(self, "bn%d" % i, FusedBatchNormAct(cout, momentum=BN_MOMENTUM, relu=True))
             cin = cout
         self.out_planes = cin
-        self.relu = nn.ReLU(inplace=True)
         self.downsample = None
         if stride != 1 or inplanes != cin:                 # pose3d_resnet.py:130-136
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, cin, kernel_size=1, stride=stride, bias=False),
-                                            nn.BatchNorm2d(cin, momentum=BN_MOMENTUM))
+                                            FusedBatchNormAct(cin, momentum=BN_MOMENTUM, relu=False))
 
     def forward(self, x):
         out = x
-        for i in range(1, self.n_conv + 1):
-            out = getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(out))
-            if i < self.n_conv:
-                out = self.relu(out)
+        for i in range(1, self.n_conv):
+            out = getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(out))          # conv -> BN -> ReLU, fused
         shortcut = x if self.downsample is None else self.downsample(x)
-        out += shortcut
-        return self.relu(out)
+        last = self.n_conv
+        # conv -> BN -> (+ shortcut) -> ReLU in one apply pass (pose3d_resnet.py:44-45,85-86)
+        return getattr(self, "bn%d" % last)(getattr(self, "conv%d" % last)(out), residual=shortcut)
 
 
 def _deconv_geometry(kernel):
@@ -79,8 +81,7 @@ class PoseResNet(nn.Module):
         self.depth_res = cfg.MODEL.DEPTH_RES
 
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64, momentum=BN_MOMENTUM)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = FusedBatchNormAct(64, momentum=BN_MOMENTUM, relu=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         width = 64
         for stage, (planes, n_unit) in enumerate(zip((64, 128, 256, 512), units), start=1):
@@ -98,15 +99,22 @@ class PoseResNet(nn.Module):
         head = []
         for planes, k in zip(filters, kernels):
             pad, out_pad = _deconv_geometry(k)
-            head += [nn.ConvTranspose2d(width, planes, kernel_size=k, stride=2, padding=pad, output_padding=out_pad,
-                                        bias=self.deconv_with_bias),
-                     nn.BatchNorm2d(planes, momentum=BN_MOMENTUM), nn.ReLU(inplace=True)]
+            if k == 4 and not self.deconv_with_bias and width % 64 == 0 and planes % 64 == 0:
+                deconv = Deconv4x4s2(width, planes)                           # MFMA implicit GEMM
+            else:   # configurations no shipped experiment uses (kernel 2/3, bias): MIOpen through torch
+                deconv = nn.ConvTranspose2d(width, planes, kernel_size=k, stride=2, padding=pad, output_padding=out_pad,
+                                            bias=self.deconv_with_bias)
+            # third slot keeps the reference's Sequential indices (ReLU is fused into the BatchNorm pass)
+            head += [deconv, FusedBatchNormAct(planes, momentum=BN_MOMENTUM, relu=True), nn.Identity()]
             width = planes
         self.deconv_layers = nn.Sequential(*head)
 
         fk = extra.FINAL_CONV_KERNEL
         out_ch = self.num_joints * self.depth_res if self.volume else self.num_joints
-        self.final_layer = nn.Conv2d(width, out_ch, kernel_size=fk, stride=1, padding=1 if fk == 3 else 0)
+        if fk == 1 and width % 64 == 0 and out_ch % 8 == 0:
+            self.final_layer = Conv1x1(width, out_ch)                         # MFMA GEMM
+        else:
+            self.final_layer = nn.Conv2d(width, out_ch, kernel_size=fk, stride=1, padding=1 if fk == 3 else 0)
 
         if not self.volume:                                # legacy 2-D heat-map + depth FC branch, :124-126
             self.avgpool = nn.AvgPool2d(kernel_size=int(cfg.MODEL.IMAGE_SIZE[0] / 2 ** 5), stride=1)
@@ -114,7 +122,7 @@ class PoseResNet(nn.Module):
         self.to(memory_format=torch.channels_last)
 
     def features(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x)))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):
@@ -135,11 +143,11 @@ class PoseResNet(nn.Module):
             logger.error('=> please download it first')
             raise ValueError('imagenet pretrained model does not exist')
         for m in self.deconv_layers.modules():
-            if isinstance(m, nn.ConvTranspose2d):
+            if isinstance(m, (nn.ConvTranspose2d, Deconv4x4s2)):
                 nn.init.normal_(m.weight, std=0.001)
                 if self.deconv_with_bias:
                     nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.BatchNorm2d):
+            elif isinstance(m, (nn.BatchNorm2d, FusedBatchNormAct)):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         nn.init.normal_(self.final_layer.weight, std=0.001)

@@ -1,5 +1,6 @@
 """GPU parity: MFMA head kernels (through the C ABI) vs. plain PyTorch fp32 references of the same ops on the
 same bf16-rounded inputs.  Tolerance: bf16 output rounding (2^-8 relative) + fp32 accumulation-order noise."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -64,3 +65,73 @@ def test_deconv_fwd_bwd_data_vs_torch(dev, b, h, w, cin, cout):
         xr = x.float().requires_grad_(True)
         F.conv_transpose2d(xr, w32, None, stride=2, padding=1).backward(dy.float())
         close(dx, xr.grad)
+
+
+@pytest.mark.parametrize("r,i,j", [(4096, 128, 128), (5000, 1088, 256), (300, 72, 40), (131072, 256, 128)])
+def test_gemm_tn_vs_torch(dev, r, i, j):
+    from epipolarpose_amd import hip
+    a = rnd((r, i), dev, 7).to(torch.bfloat16)
+    b = rnd((r, j), dev, 8).to(torch.bfloat16)
+    ref = a.float().t() @ b.float()
+    got = hip.gemm_tn_bf16(a, b)
+    assert got.dtype == torch.float32
+    close(got, ref, rel=3e-5 * max(1.0, (r / 4096) ** 0.5))
+    np_sum = hip.column_sum_bf16(a)
+    close(np_sum, a.float().sum(0), rel=1e-5)
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 8, 8, 128, 64), (3, 5, 7, 64, 72), (32, 16, 16, 256, 256)])
+def test_deconv_bwd_weight_vs_torch(dev, b, h, w, cin, cout):
+    from epipolarpose_amd import hip
+    x = rnd((b, cin, h, w), dev, 9).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = rnd((b, cout, 2 * h, 2 * w), dev, 10).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.zeros((cin, cout, 4, 4), device=dev, requires_grad=True)
+    F.conv_transpose2d(x.float(), wt, None, stride=2, padding=1).backward(dy.float())
+    close(hip.deconv4x4s2_bwd_weight(x, dy), wt.grad, rel=1e-4)
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(4, 64, 9, 7), (32, 256, 16, 16), (2, 2048, 2, 2)])
+def test_fused_bn_act_vs_torch(dev, relu, res, shape):
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    b, c, h, w = shape
+    x = rnd(shape, dev, 11, 2.0).add_(0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = rnd(shape, dev, 12).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    m = FusedBatchNormAct(c, momentum=0.1, relu=relu).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(rnd((c,), dev, 13).abs() + 0.5)
+        m.bias.copy_(rnd((c,), dev, 14) * 0.3)
+    ref = torch.nn.BatchNorm2d(c, momentum=0.1).to(dev)
+    ref.load_state_dict({k: v for k, v in m.state_dict().items()})
+    xg = x.clone().requires_grad_(True)
+    rg = r.clone().requires_grad_(True) if res else None
+    y = m(xg, residual=rg)
+    x32 = x.float().requires_grad_(True)
+    r32 = r.float().requires_grad_(True) if res else None
+    t = ref(x32)
+    if res:
+        t = t + r32
+    if relu:
+        t = torch.relu(t)
+    close(y, t, rel=1e-2)
+    dy = rnd(shape, dev, 15).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    # reference backward with the same activation mask as the fused kernel sees it
+    t.backward(dy.float())
+    close(xg.grad, x32.grad, rel=2e-2)
+    if res:
+        close(rg.grad, r32.grad, rel=1e-2)
+    close(m.weight.grad, ref.weight.grad, rel=2e-2)
+    close(m.bias.grad, ref.bias.grad, rel=2e-2)
+    close(m.running_mean, ref.running_mean, rel=1e-3)
+    close(m.running_var, ref.running_var, rel=1e-3)
+    assert int(m.num_batches_tracked) == 1 and float(m.sums_ws.abs().max()) == 0.0
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        ye = m(x, residual=r)
+        te = ref(x.float())
+        if res:
+            te = te + r.float()
+        if relu:
+            te = torch.relu(te)
+    close(ye, te, rel=1e-2)

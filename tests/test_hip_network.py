@@ -1,0 +1,90 @@
+"""GPU: the whole network (MIOpen backbone convolutions + fused HIP BatchNorm/ReLU + MFMA head) against the golden
+vectors produced by the reference's PoseResNet (fp32).  Our network computes in bf16, so the bar is the bf16 one:
+logits within 3 % of max|logit|, loss within 2 %, weight-gradient cosine >= 0.99."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from det_weights import fill_state_dict, seeded_array
+from make_golden_cases import NETWORK_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cfg(layers, image, joints, depth):
+    from epipolarpose_amd.core.config import default_config
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = joints, depth, [image, image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    return cfg
+
+
+def cosine(a, b):
+    a, b = a.reshape(-1).double(), b.reshape(-1).double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("case", NETWORK_CASES, ids=[c[0] for c in NETWORK_CASES])
+def test_network_vs_reference_golden(golden, case):
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    g = golden("network")
+    name, layers, image, j, d, b = case
+    model = get_pose_net(make_cfg(layers, image, j, d), is_train=True).to(dev)
+    shapes = {k: ast.literal_eval(s) for k, s in zip(g[name + "/keys"].tolist(), g[name + "/shapes"].tolist())}
+    assert list(model.state_dict().keys()) == list(shapes.keys())
+    model.load_state_dict(fill_state_dict(shapes, seed=1))
+    x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image))).to(dev)
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(x)
+    ref = g[name + "/logits_eval"]
+    assert out.shape == ref.shape
+    assert np.abs(out.float().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max()
+    model.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = model(x)
+    ref = g[name + "/logits_train"]
+    assert np.abs(logits.float().detach().cpu().numpy() - ref).max() <= 4e-2 * np.abs(ref).max()
+    gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
+    loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
+    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=2e-2)
+    loss.backward()
+    sd = model.state_dict()
+    np.testing.assert_allclose(sd["bn1.running_mean"].cpu().numpy(), g[name + "/bn1.running_mean"], atol=2e-3)
+    np.testing.assert_allclose(sd["deconv_layers.7.running_var"].cpu().numpy(), g[name + "/deconv_layers.7.running_var"], rtol=5e-2)
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.0.weight", "conv1.weight"):
+        got = grads[k].float().contiguous().cpu()
+        refg = torch.from_numpy(g[name + "/grad/" + k])
+        if refg.dim() == 1 and got.dim() > 1:
+            got = got.reshape(-1)[:: max(1, got.numel() // 50000)]
+        assert cosine(got, refg) >= 0.99, k
+        assert abs(float(got.norm() / refg.norm()) - 1.0) <= 0.08, k
+
+
+def test_training_reduces_loss_and_ss_step_runs():
+    from epipolarpose_amd.core.function import train_step
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.hip import DeviceMeta
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from epipolarpose_amd.synthetic import SyntheticScenes
+    dev = torch.device("cuda:0")
+    j, d, image = 5, 16, 64
+    torch.manual_seed(0)
+    model = get_pose_net(make_cfg(18, image, j, d), is_train=True).to(dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sc = SyntheticScenes(n_group=2, n_view=2, num_joints=j, seed=4)
+    x = torch.from_numpy(sc.images(size=image)).to(dev)
+    label, weight = torch.from_numpy(sc.label).to(dev), torch.from_numpy(sc.weight).to(dev)
+    losses = [float(train_step(model, crit, opt, x, label, weight)) for _ in range(12)]
+    assert losses[-1] < 0.7 * losses[0], losses
+    meta = DeviceMeta(sc.meta, dev)
+    l_ss = train_step(model, crit, opt, x, None, None, meta=meta, n_view=2)
+    assert torch.isfinite(l_ss)
