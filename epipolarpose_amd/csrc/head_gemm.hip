@@ -90,10 +90,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
             } else {
                 off = a_base[ps] + k0 + schunk * 8;
             }
+            const bool kok = k0 + schunk * 8 < p.K;             // K tail (K % 8 == 0): zero-filled chunks
             uint4v z; z.x = z.y = z.z = z.w = 0u;
-            ra[ps] = ok ? *reinterpret_cast<const uint4v*>(p.A + off) : z;
+            ra[ps] = (ok && kok) ? *reinterpret_cast<const uint4v*>(p.A + off) : z;
             const int n = n0 + ps * 32 + srow;
-            rb[ps] = (n < p.N) ? *reinterpret_cast<const uint4v*>(p.Bt + (long long)n * p.ldb + k0 + schunk * 8) : z;
+            rb[ps] = (n < p.N && kok) ? *reinterpret_cast<const uint4v*>(p.Bt + (long long)n * p.ldb + k0 + schunk * 8) : z;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / GBK;
+    const int nk = (p.K + GBK - 1) / GBK;
     load_tiles(0);
     store_tiles(0);
     __syncthreads();
@@ -197,7 +198,7 @@ using namespace epi;
 
 static int launch_gemm(const GemmArgs& a, bool out_f32, hipStream_t st) {
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
-    if (a.K % GBK || a.lda % 8 || a.ldb % 8 || a.ldc % 4) return EPI_ERR_UNSUPPORTED;
+    if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
     const long long tiles = (long long)((a.M + GBM - 1) / GBM) * ((a.N + GBN - 1) / GBN);

@@ -144,7 +144,7 @@ int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_m
  * ------------------------------------------------------------------------------------------------ */
 
 /* C[M][N] (bf16 or f32, row stride ldc) = A[M][K] (bf16, row stride lda) * Bt[N][K]^T (bf16, row stride ldb)
- * (+ bias[N] f32 or NULL).  K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
+ * (+ bias[N] f32 or NULL).  K % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
  * The final 1x1 convolution is this with A = activations [B*H*W][Cin], Bt = weight [Cout][Cin]; its
  * backward-data is this with A = dlogits [B*H*W][Cout], Bt = weight^T [Cin][Cout]. */
 int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype,

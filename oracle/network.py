@@ -62,9 +62,9 @@ def softmax_integral(preds, num_joints):
     b, c, h, w = preds.shape
     d = c // num_joints
     p = F.softmax(preds.reshape(b, num_joints, -1), dim=2).reshape(b, num_joints, d, h, w)
-    ex = (p.sum(dim=(2, 3)) * torch.arange(w, dtype=p.dtype)).sum(dim=2, keepdim=True)
-    ey = (p.sum(dim=(2, 4)) * torch.arange(h, dtype=p.dtype)).sum(dim=2, keepdim=True)
-    ez = (p.sum(dim=(3, 4)) * torch.arange(d, dtype=p.dtype)).sum(dim=2, keepdim=True)
+    ex = (p.sum(dim=(2, 3)) * torch.arange(w, dtype=p.dtype, device=p.device)).sum(dim=2, keepdim=True)
+    ey = (p.sum(dim=(2, 4)) * torch.arange(h, dtype=p.dtype, device=p.device)).sum(dim=2, keepdim=True)
+    ez = (p.sum(dim=(3, 4)) * torch.arange(d, dtype=p.dtype, device=p.device)).sum(dim=2, keepdim=True)
     return torch.cat((ex / w - 0.5, ey / h - 0.5, ez / d - 0.5), dim=2).reshape(b, num_joints * 3)
 
 

@@ -27,7 +27,7 @@ def close(got, ref, rel=1.2e-2):
     assert err <= tol, "max err %.4g > tol %.4g" % (err, tol)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 1088, 256), (1000, 200, 128), (4096, 256, 1088), (77, 36, 192)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 1088, 256), (1000, 200, 128), (4096, 256, 1088), (77, 36, 192), (512, 256, 24), (300, 40, 200)])
 def test_gemm_vs_torch(dev, m, n, k):
     from epipolarpose_amd import hip
     a = rnd((m, k), dev, 1).to(torch.bfloat16)
