@@ -41,6 +41,9 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc;
     GemmGather ga;
     GemmScatter sc;
+    int deconv_phases;     // 1: blockIdx.z = output-parity phase 2*ph+pw of ConvTranspose2d(k4,s2,p1); taps/weights/scatter derive from it
+    int k_per_split;       // split-K: blockIdx.y handles K range [y*k_per_split, ...) and writes an fp32 slab (plain rows)
+    float* slabs;          // [nsplit][nphase][M][N] when gridDim.y > 1
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -53,6 +56,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     const int tiles_n = (p.N + GBN - 1) / GBN;
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
+    const int phase = blockIdx.z, ph = phase >> 1, pw = phase & 1;
+    const unsigned short* Bt = p.Bt + (p.deconv_phases ? (long long)phase * p.N * p.ldb : 0);
+    const int sc_oy = p.deconv_phases ? ph : p.sc.oy, sc_ox = p.deconv_phases ? pw : p.sc.ox;
+    const int k_begin = blockIdx.y * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
 
     // ---- staging roles: thread t moves chunk (t & 7) of rows (t >> 3) + 32*pass of both tiles ----
     const int srow = tid >> 3, schunk = tid & 7;
@@ -84,17 +92,20 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
             bool ok = a_ok[ps];
             long long off;
             if (p.ga.enabled) {
-                const int y = a_iy[ps] + p.ga.dy[tap], x = a_jx[ps] + p.ga.dx[tap];
+                // ConvTranspose phases: oh = 2*ih - 1 + kh, so tap (ty, tx) of phase (ph, pw) reads (i + ph - ty, j + pw - tx)
+                const int tdy = p.deconv_phases ? ph - (tap >> 1) : p.ga.dy[tap];
+                const int tdx = p.deconv_phases ? pw - (tap & 1) : p.ga.dx[tap];
+                const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
                 ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
                 off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + schunk * 8;
             } else {
                 off = a_base[ps] + k0 + schunk * 8;
             }
-            const bool kok = k0 + schunk * 8 < p.K;             // K tail (K % 8 == 0): zero-filled chunks
+            const bool kok = k0 + schunk * 8 < k_end;           // K tail (K % 8 == 0): zero-filled chunks
             uint4v z; z.x = z.y = z.z = z.w = 0u;
             ra[ps] = (ok && kok) ? *reinterpret_cast<const uint4v*>(p.A + off) : z;
             const int n = n0 + ps * 32 + srow;
-            rb[ps] = (n < p.N && kok) ? *reinterpret_cast<const uint4v*>(p.Bt + (long long)n * p.ldb + k0 + schunk * 8) : z;
+            rb[ps] = (n < p.N && kok) ? *reinterpret_cast<const uint4v*>(Bt + (long long)n * p.ldb + k0 + schunk * 8) : z;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -116,14 +127,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.K + GBK - 1) / GBK;
-    load_tiles(0);
+    const int nk = (k_end - k_begin + GBK - 1) / GBK;
+    load_tiles(k_begin);
     store_tiles(0);
     __syncthreads();
     const int frow = lane & 31, fhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * GBK);
+        if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * GBK);
         const char* a_s = smem + buf * 2 * TILE_BYTES;
         const char* b_s = a_s + TILE_BYTES;
 #pragma unroll
@@ -150,6 +161,27 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
 
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*64 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
+    if (gridDim.y > 1) {        // split-K partial: fp32, plain rows, finished by splitk_finish_kernel
+        float* slab = p.slabs + ((long long)blockIdx.y * gridDim.z + phase) * p.M * p.N;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int m = m0 + wm * 64 + ti * 32 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + tj * 32 + 8 * q + 4 * fhalf;
+                    if (n + 3 < p.N) {
+                        float4v t; t.x = acc[ti][tj][4 * q]; t.y = acc[ti][tj][4 * q + 1]; t.z = acc[ti][tj][4 * q + 2]; t.w = acc[ti][tj][4 * q + 3];
+                        *reinterpret_cast<float4v*>(slab + (long long)m * p.N + n) = t;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) slab[(long long)m * p.N + n + e] = acc[ti][tj][4 * q + e];
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
         const int m = m0 + wm * 64 + ti * 32 + frow;
@@ -159,7 +191,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
             const int hw = p.sc.Hg * p.sc.Wg;
             const int n = m / hw, rem = m - n * hw;
             const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
-            orow = ((long long)n * p.sc.Ho + i * p.sc.so + p.sc.oy) * p.sc.Wo + j * p.sc.so + p.sc.ox;
+            orow = ((long long)n * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
         }
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
@@ -192,63 +224,125 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     }
 }
 
+// sum the split-K slabs, add the bias, convert and write through the row scatter (N % 4 == 0)
+template <bool OUT_F32>
+__global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, int nphase, GemmArgs p) {
+    const long long nq = (long long)p.N >> 2;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nphase * p.M * nq) return;
+    const int n = (int)(t % nq) * 4;
+    const long long pm = t / nq;
+    const int m = (int)(pm % p.M), phase = (int)(pm / p.M);
+    float4v a; a.x = a.y = a.z = a.w = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float4v v = *reinterpret_cast<const float4v*>(slabs + (((long long)s * nphase + phase) * p.M + m) * p.N + n);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (p.bias) { a.x += p.bias[n]; a.y += p.bias[n + 1]; a.z += p.bias[n + 2]; a.w += p.bias[n + 3]; }
+    long long orow = m;
+    if (p.sc.enabled) {
+        const int hw = p.sc.Hg * p.sc.Wg;
+        const int b = m / hw, rem = m - b * hw;
+        const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
+        const int oy = p.deconv_phases ? (phase >> 1) : p.sc.oy, ox = p.deconv_phases ? (phase & 1) : p.sc.ox;
+        orow = ((long long)b * p.sc.Ho + i * p.sc.so + oy) * p.sc.Wo + j * p.sc.so + ox;
+    }
+    if (OUT_F32) {
+        *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = a;
+    } else {
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
+        o.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
+    }
+}
+
 }  // namespace epi
 
 using namespace epi;
 
-static int launch_gemm(const GemmArgs& a, bool out_f32, hipStream_t st) {
+// split so that at least ~512 workgroups exist, each split keeping >= 512 of K
+static int gemm_pick_split(long long tiles, int nphase, int K) {
+    const long long wgs = tiles * nphase;
+    if (wgs >= 384) return 1;
+    int nsplit = (int)((512 + wgs - 1) / wgs);
+    const int max_split = K / 512 > 0 ? K / 512 : 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 16) nsplit = 16;
+    return nsplit < 1 ? 1 : nsplit;
+}
+
+extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
+    if (M <= 0 || N <= 0 || K <= 0 || nphase <= 0) return 0;
+    const long long tiles = (long long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    const int nsplit = gemm_pick_split(tiles, nphase, K);
+    return nsplit > 1 ? (size_t)nsplit * nphase * M * N * sizeof(float) : 0;
+}
+
+static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
     const long long tiles = (long long)((a.M + GBM - 1) / GBM) * ((a.N + GBN - 1) / GBN);
     if (tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+    int nsplit = gemm_pick_split(tiles, nphase, a.K);
+    if (a.N % 4) nsplit = 1;
+    int kps = a.K;
+    if (nsplit > 1) {
+        kps = ((a.K + nsplit - 1) / nsplit + GBK - 1) / GBK * GBK;
+        nsplit = (a.K + kps - 1) / kps;
+    }
+    if (nsplit > 1) {
+        if (!workspace || (size_t)nsplit * nphase * a.M * a.N * sizeof(float) > workspace_bytes) return EPI_ERR_WORKSPACE;
+        a.slabs = (float*)workspace;
+    }
+    a.k_per_split = kps;
     const size_t lds = 4 * TILE_BYTES;
-    if (out_f32) hipLaunchKernelGGL(head_gemm_kernel<true>, dim3((unsigned)tiles), dim3(GTHREADS), lds, st, a);
-    else hipLaunchKernelGGL(head_gemm_kernel<false>, dim3((unsigned)tiles), dim3(GTHREADS), lds, st, a);
+    const dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)nphase);
+    if (out_f32) hipLaunchKernelGGL(head_gemm_kernel<true>, grid, dim3(GTHREADS), lds, st, a);
+    else hipLaunchKernelGGL(head_gemm_kernel<false>, grid, dim3(GTHREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
-    return EPI_OK;
-}
-
-extern "C" int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
-                             const float* bias, epi_stream_t stream) {
-    GemmArgs a = {};
-    a.A = (const unsigned short*)A; a.Bt = (const unsigned short*)Bt; a.C = C; a.bias = bias;
-    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    if (c_dtype != EPI_BF16 && c_dtype != EPI_F32) return EPI_ERR_UNSUPPORTED;
-    return launch_gemm(a, c_dtype == EPI_F32, (hipStream_t)stream);
-}
-
-// ConvTranspose2d(k=4, s=2, p=1), NHWC bf16:  x [B][H][W][Cin]  ->  y [B][2H][2W][Cout]  (raw, pre-BatchNorm).
-// w_phase: [4 phases][Cout][4 taps * Cin] packed by epi_deconv4x4s2_pack_weight (phase = 2*(oh&1) + (ow&1)).
-extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
-                                   epi_stream_t stream) {
-    if (!x || !w_phase || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
-    if (Cin % GBK || Cout % 4) return EPI_ERR_UNSUPPORTED;
-    for (int ph = 0; ph < 2; ++ph) {
-        for (int pw = 0; pw < 2; ++pw) {
-            GemmArgs a = {};
-            a.A = (const unsigned short*)x;
-            a.Bt = (const unsigned short*)w_phase + (size_t)(2 * ph + pw) * Cout * 4 * Cin;
-            a.C = y;
-            a.M = B * H * W; a.N = Cout; a.K = 4 * Cin; a.lda = 0; a.ldb = 4 * Cin; a.ldc = Cout;
-            a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = H; a.ga.Ws = W; a.ga.Cs = Cin; a.ga.stride = 1;
-            // oh = 2*ih - 1 + kh.  oh even: kh in {1,3} -> ih = i, i-1;  oh odd: kh in {0,2} -> ih = i+1, i
-            const int dyv[2] = {ph ? 1 : 0, ph ? 0 : -1}, dxv[2] = {pw ? 1 : 0, pw ? 0 : -1};
-            for (int ty = 0; ty < 2; ++ty)
-                for (int tx = 0; tx < 2; ++tx) { a.ga.dy[2 * ty + tx] = dyv[ty]; a.ga.dx[2 * ty + tx] = dxv[tx]; }
-            a.sc.enabled = 1; a.sc.Hg = H; a.sc.Wg = W; a.sc.Ho = 2 * H; a.sc.Wo = 2 * W; a.sc.so = 2; a.sc.oy = ph; a.sc.ox = pw;
-            const int st = launch_gemm(a, false, (hipStream_t)stream);
-            if (st != EPI_OK) return st;
-        }
+    if (nsplit > 1) {
+        const long long n = (long long)nphase * a.M * (a.N >> 2);
+        const dim3 fg((unsigned)((n + 255) / 256));
+        if (out_f32) hipLaunchKernelGGL(splitk_finish_kernel<true>, fg, dim3(256), 0, st, a.slabs, nsplit, nphase, a);
+        else hipLaunchKernelGGL(splitk_finish_kernel<false>, fg, dim3(256), 0, st, a.slabs, nsplit, nphase, a);
+        EPI_CHECK_LAUNCH();
     }
     return EPI_OK;
 }
 
+extern "C" int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
+                             const float* bias, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    GemmArgs a = {};
+    a.A = (const unsigned short*)A; a.Bt = (const unsigned short*)Bt; a.C = C; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    if (c_dtype != EPI_BF16 && c_dtype != EPI_F32) return EPI_ERR_UNSUPPORTED;
+    return launch_gemm(a, c_dtype == EPI_F32, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ConvTranspose2d(k=4, s=2, p=1), NHWC bf16:  x [B][H][W][Cin]  ->  y [B][2H][2W][Cout]  (raw, pre-BatchNorm).
+// w_phase: [4 phases][Cout][4 taps * Cin] packed by epi_deconv4x4s2_pack_weight (phase = 2*(oh&1) + (ow&1)).
+// All four output-parity phases run in ONE launch (blockIdx.z); workspace: epi_gemm_workspace_bytes(B*H*W, Cout, 4*Cin, 4).
+extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
+                                   void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!x || !w_phase || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (Cin % GBK || Cout % 4) return EPI_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)x; a.Bt = (const unsigned short*)w_phase; a.C = y;
+    a.M = B * H * W; a.N = Cout; a.K = 4 * Cin; a.lda = 0; a.ldb = 4 * Cin; a.ldc = Cout;
+    a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = H; a.ga.Ws = W; a.ga.Cs = Cin; a.ga.stride = 1;
+    a.sc.enabled = 1; a.sc.Hg = H; a.sc.Wg = W; a.sc.Ho = 2 * H; a.sc.Wo = 2 * W; a.sc.so = 2;
+    a.deconv_phases = 1;
+    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // Backward-data of the same layer:  dy [B][2H][2W][Cout] -> dx [B][H][W][Cin];
 // w_bwd: [Cin][16 taps * Cout] packed by epi_deconv4x4s2_pack_weight (tap = kh*4 + kw).
+// workspace: epi_gemm_workspace_bytes(B*H*W, Cin, 16*Cout, 1).
 extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
-                                        epi_stream_t stream) {
+                                        void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (Cout % GBK || Cin % 4) return EPI_ERR_UNSUPPORTED;
     GemmArgs a = {};
@@ -257,7 +351,7 @@ extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void*
     a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = 2 * H; a.ga.Ws = 2 * W; a.ga.Cs = Cout; a.ga.stride = 2;
     for (int kh = 0; kh < 4; ++kh)
         for (int kw = 0; kw < 4; ++kw) { a.ga.dy[4 * kh + kw] = kh - 1; a.ga.dx[4 * kh + kw] = kw - 1; }   // oh = 2*ih - 1 + kh
-    return launch_gemm(a, false, (hipStream_t)stream);
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 namespace epi {

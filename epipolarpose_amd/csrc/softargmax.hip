@@ -98,29 +98,31 @@ __device__ __forceinline__ long long row_base_of(const RowGeom& g, int row) {
     return (long long)row * g.N;
 }
 
-template <typename T, int VEC, bool NHWC>
+template <typename T, int VEC, bool NHWC, int ITERS>
 __global__ __launch_bounds__(SA_THREADS) void softargmax_partial_kernel(const T* __restrict__ logits, RowGeom g,
                                                                         int nchunk, SoftPartial* __restrict__ part) {
     const int row = blockIdx.x / nchunk;
     const int chunk = blockIdx.x - row * nchunk;
     const int tid = threadIdx.x;
     constexpr int STRIDE = SA_THREADS * VEC;
-    const int e_begin = chunk * (STRIDE * SA_ITERS) + tid * VEC;
+    const int e_begin = chunk * (STRIDE * ITERS) + tid * VEC;
+    const bool full = (chunk + 1) * (STRIDE * ITERS) <= g.N;      // workgroup-uniform: no bounds checks needed
 
     Cursor<NHWC> cur;
     cur.init(g, row_base_of<NHWC>(g, row), e_begin, STRIDE);
 
-    float m = -FLT_MAX, s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // running state: ml = max * log2(e) so that exp(x - max) = exp2(fma(x, log2e, -ml)) costs one FMA + v_exp_f32
+    float ml = -FLT_MAX, s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
     int e = e_begin;
 #pragma unroll 1
-    for (int it = 0; it < SA_ITERS; it += SA_UNROLL) {
+    for (int it = 0; it < ITERS; it += SA_UNROLL) {
         float x[SA_UNROLL][VEC];
         float k0[SA_UNROLL], k1[SA_UNROLL], k2[SA_UNROLL];
         bool ok[SA_UNROLL];
         float bm = -FLT_MAX;
 #pragma unroll
         for (int u = 0; u < SA_UNROLL; ++u) {
-            ok[u] = (e < g.N);
+            ok[u] = full || (e < g.N);
             if (ok[u]) {
                 VecIO<T, VEC>::load(logits + cur.mem, x[u]);
             } else {
@@ -135,33 +137,31 @@ __global__ __launch_bounds__(SA_THREADS) void softargmax_partial_kernel(const T*
         for (int u = 0; u < SA_UNROLL; ++u)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) bm = fmaxf(bm, x[u][k]);
-        const float mn = fmaxf(m, bm);
-        const float sc = fast_exp2((m - mn) * EPI_LOG2E);
+        const float mln = fmaxf(ml, bm * EPI_LOG2E);
+        const float sc = fast_exp2(ml - mln);
         s *= sc; a0 *= sc; a1 *= sc; a2 *= sc;
-        m = mn;
+        ml = mln;
 #pragma unroll
         for (int u = 0; u < SA_UNROLL; ++u) {
             float es = 0.f, ek = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                float ex = fast_exp2((x[u][k] - m) * EPI_LOG2E);
-                ex = ok[u] ? ex : 0.f;
+                float ex = fast_exp2(fmaf(x[u][k], EPI_LOG2E, -ml));
+                if (!full) ex = ok[u] ? ex : 0.f;
                 es += ex;
-                ek += ex * (float)k;
+                if (k) ek = fmaf(ex, (float)k, ek);
             }
             s += es;
-            a0 += es * k0[u] + ek;
-            a1 += es * k1[u];
-            a2 += es * k2[u];
+            a0 += fmaf(es, k0[u], ek);
+            a1 = fmaf(es, k1[u], a1);
+            a2 = fmaf(es, k2[u], a2);
         }
     }
-    // wave reduce
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-        const float b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64), b2 = __shfl_xor(a2, o, 64);
-        merge(m, s, a0, a1, a2, m2, s2, b0, b1, b2);
-    }
+    // wave reduce: one max reduction, one rescale, then plain sums (no exp inside the shuffle tree)
+    const float mw = wave_max(ml);
+    const float f = fast_exp2(ml - mw);
+    s = wave_sum(s * f); a0 = wave_sum(a0 * f); a1 = wave_sum(a1 * f); a2 = wave_sum(a2 * f);
+    float m = mw / EPI_LOG2E;
     __shared__ float red[SA_THREADS / 64][5];
     const int lane = tid & 63, wid = tid >> 6;
     if (lane == 0) { red[wid][0] = m; red[wid][1] = s; red[wid][2] = a0; red[wid][3] = a1; red[wid][4] = a2; }
@@ -308,10 +308,13 @@ __global__ void argmax_combine_kernel(const ArgPartial* __restrict__ part, int r
     val[row] = bv;
 }
 
-static inline int chunks_for(long long n, int vec) {
-    const long long per = (long long)SA_THREADS * vec * SA_ITERS;
+static inline int chunks_for(long long n, int vec, int iters = SA_ITERS) {
+    const long long per = (long long)SA_THREADS * vec * iters;
     return (int)((n + per - 1) / per);
 }
+// forward chunk length (vectors per thread): long chunks for the 8-wide bf16 path halve the number of partials
+template <typename T> struct FwdIters { static constexpr int value = SA_ITERS; };
+template <> struct FwdIters<unsigned short> { static constexpr int value = 2 * SA_ITERS; };
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -329,13 +332,13 @@ template <typename T, bool NHWC>
 static int launch_fwd(const T* logits, RowGeom g, int rows, bool vec, float* xyz, float* row_max, float* row_sum,
                       SoftPartial* part, size_t ws_bytes, hipStream_t st) {
     const int VECW = Elem<T>::VEC;
-    const int nchunk = chunks_for(g.N, vec ? VECW : 1);
+    const int nchunk = vec ? chunks_for(g.N, VECW, FwdIters<T>::value) : chunks_for(g.N, 1);
     if ((size_t)rows * nchunk * sizeof(SoftPartial) > ws_bytes) return EPI_ERR_WORKSPACE;
     const unsigned grid = (unsigned)((long long)rows * nchunk);
     if (vec)
-        hipLaunchKernelGGL((softargmax_partial_kernel<T, Elem<T>::VEC, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, part);
+        hipLaunchKernelGGL((softargmax_partial_kernel<T, Elem<T>::VEC, NHWC, FwdIters<T>::value>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, part);
     else
-        hipLaunchKernelGGL((softargmax_partial_kernel<T, 1, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, part);
+        hipLaunchKernelGGL((softargmax_partial_kernel<T, 1, NHWC, SA_ITERS>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, part);
     EPI_CHECK_LAUNCH();
     hipLaunchKernelGGL((softargmax_combine_kernel<NHWC>), dim3((rows + 127) / 128), dim3(128), 0, st, part, rows, nchunk, g, xyz, row_max, row_sum);
     EPI_CHECK_LAUNCH();

@@ -39,17 +39,19 @@ _SIGNATURES = {
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
     "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
-    "epi_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "epi_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epi_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp]),
-    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "epi_bn_workspace_floats": (_sz, [_i]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
+    "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -359,10 +361,11 @@ def gemm_bf16(a, bt, bias=None, out_dtype=torch.bfloat16, out=None):
     cdt = EPI_BF16 if out.dtype == torch.bfloat16 else EPI_F32
     if bias is not None:
         bias = _dev(bias, torch.float32, "bias").contiguous()
+    ws = _workspace(lib.epi_gemm_workspace_bytes(m, n, k, 1), a.device)
     with torch.cuda.device(a.device):
         ev = timer.start("epi_gemm_bf16")
         _check(lib.epi_gemm_bf16(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(out), out.stride(0), cdt, m, n, k,
-                                 _ptr(bias), _stream()), "epi_gemm_bf16")
+                                 _ptr(bias), _ptr(ws), ws.numel(), _stream()), "epi_gemm_bf16")
         timer.stop(ev)
     return out
 
@@ -389,9 +392,11 @@ def deconv4x4s2_fwd(x, w_phase):
     b, cin, h, w = x.shape
     cout = w_phase.shape[1]
     y = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_gemm_workspace_bytes(b * h * w, cout, 4 * cin, 4), x.device)
     with torch.cuda.device(x.device):
         ev = timer.start("epi_deconv4x4s2_fwd")
-        _check(lib.epi_deconv4x4s2_fwd(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _stream()), "epi_deconv4x4s2_fwd")
+        _check(lib.epi_deconv4x4s2_fwd(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
+               "epi_deconv4x4s2_fwd")
         timer.stop(ev)
     return y
 
@@ -403,16 +408,16 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     b, cout, h2, w2 = dy.shape
     cin = w_bwd.shape[0]
     dx = torch.empty((b, cin, h2 // 2, w2 // 2), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_gemm_workspace_bytes(b * (h2 // 2) * (w2 // 2), cin, 16 * cout, 1), dy.device)
     with torch.cuda.device(dy.device):
         ev = timer.start("epi_deconv4x4s2_bwd_data")
-        _check(lib.epi_deconv4x4s2_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h2 // 2, w2 // 2, cin, cout, _stream()),
-               "epi_deconv4x4s2_bwd_data")
+        _check(lib.epi_deconv4x4s2_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h2 // 2, w2 // 2, cin, cout, _ptr(ws), ws.numel(),
+                                            _stream()), "epi_deconv4x4s2_bwd_data")
         timer.stop(ev)
     return dx
 
 
-def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, training, momentum, eps,
-               relu):
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
     """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last).
     -> (y, mean, rstd, scale_shift); mean/rstd are None in inference."""
     lib = load()
@@ -427,10 +432,11 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_
     mean = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     rstd = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     scale_shift = torch.empty(2 * c, dtype=torch.float32, device=dev)
+    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), dev) if training else None
     with torch.cuda.device(dev):
         _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
                                   int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
-                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(y), _stream()), "epi_bn_act_fwd")
+                                  _ptr(rstd), _ptr(scale_shift), _ptr(ws), _ptr(y), _stream()), "epi_bn_act_fwd")
     return y, mean, rstd, scale_shift
 
 
@@ -442,9 +448,10 @@ def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres):
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), x.device)
     with torch.cuda.device(x.device):
         _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
-                                  int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
+                                  int(relu), _ptr(ws), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
     return dx, dres, sums[c:], sums[:c]
 
 
@@ -492,6 +499,7 @@ def column_sum_bf16(x):
     x = x if x.is_contiguous() else x.contiguous()
     r, c = x.shape
     sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), x.device)
     with torch.cuda.device(x.device):
-        _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(sums), _stream()), "epi_column_sums_bf16")
+        _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(ws), _ptr(sums), _stream()), "epi_column_sums_bf16")
     return sums[:c]

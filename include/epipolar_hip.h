@@ -146,9 +146,12 @@ int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_m
 /* C[M][N] (bf16 or f32, row stride ldc) = A[M][K] (bf16, row stride lda) * Bt[N][K]^T (bf16, row stride ldb)
  * (+ bias[N] f32 or NULL).  K % 8 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, 16-byte aligned bases.
  * The final 1x1 convolution is this with A = activations [B*H*W][Cin], Bt = weight [Cout][Cin]; its
- * backward-data is this with A = dlogits [B*H*W][Cout], Bt = weight^T [Cin][Cout]. */
+ * backward-data is this with A = dlogits [B*H*W][Cout], Bt = weight^T [Cin][Cout].
+ * workspace: epi_gemm_workspace_bytes(M, N, K, nphase) bytes (split-K slabs; 0 when the problem already fills
+ * the chip; nphase = 1 except 4 for epi_deconv4x4s2_fwd). */
+size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase);
 int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype,
-                  int M, int N, int K, const float* bias, epi_stream_t stream);
+                  int M, int N, int K, const float* bias, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
 /* Re-pack a ConvTranspose2d weight [Cin][Cout][4][4] (bf16) into the two GEMM operand forms:
  *   w_phase [4][Cout][4*Cin] : per output-parity phase (2*(oh&1)+(ow&1)) the 2x2 taps that reach it
@@ -157,44 +160,49 @@ int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout, void* w_p
                                 epi_stream_t stream);
 
 /* y [B][2H][2W][Cout] = ConvTranspose2d(x [B][H][W][Cin]) as 4 implicit (gather) GEMMs with K = 4*Cin.
- * Cin % 64 == 0, Cout % 4 == 0.  Raw output (BatchNorm + ReLU follow, pose3d_resnet.py:180-181). */
+ * Cin % 64 == 0, Cout % 4 == 0.  Raw output (BatchNorm + ReLU follow, pose3d_resnet.py:180-181).
+ * workspace: epi_gemm_workspace_bytes(B*H*W, Cout, 4*Cin, 4). */
 int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
-                        epi_stream_t stream);
+                        void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
-/* dx [B][H][W][Cin] from dy [B][2H][2W][Cout]: a 4x4 stride-2 implicit GEMM with K = 16*Cout.  Cout % 64 == 0. */
+/* dx [B][H][W][Cin] from dy [B][2H][2W][Cout]: a 4x4 stride-2 implicit GEMM with K = 16*Cout.  Cout % 64 == 0.
+ * workspace: epi_gemm_workspace_bytes(B*H*W, Cin, 16*Cout, 1). */
 int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
-                             epi_stream_t stream);
+                             void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (+ residual add) (+ ReLU), NHWC bf16 -- replaces every nn.BatchNorm2d(momentum=0.1) + nn.ReLU
  * (+ `out += residual`) of lib/models/pose3d_resnet.py:31-47,68-88,158-183,186-188.
  *   x, residual, y : [R][C] bf16 (R = B*H*W, C % 8 == 0);  gamma, beta, running_mean, running_var, mean, rstd : [C] f32
  *   scale_shift    : [2C] f32 out (scale = gamma*rstd, shift = beta - mean*scale), reused by the backward
- *   sums_ws        : [2C] f32 scratch that must be ZERO on entry; it is zero again on return
+ *   partials_ws    : f32 scratch of epi_bn_workspace_floats(C) elements (per-workgroup partial sums; no
+ *                    atomics, no zero-initialisation needed)
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
  *                    num_batches_tracked += 1;   training == 0: running statistics.
  * Backward (training):  dbeta_dgamma [2C] f32 out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
  *   = gradient of the residual input;  y = saved forward output, required when relu && dres.
  * ------------------------------------------------------------------------------------------------ */
+size_t epi_bn_workspace_floats(int C);
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
-                   long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
+                   long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* partials_ws,
                    void* y, epi_stream_t stream);
 int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma,
-                   const float* mean, const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma,
-                   void* dx, void* dres, epi_stream_t stream);
+                   const float* mean, const float* rstd, const float* scale_shift, int relu, float* partials_ws,
+                   float* dbeta_dgamma, void* dx, void* dres, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (ntap = 1 for epi_gemm_tn_bf16, 16 for the deconvolution).
  *   epi_gemm_tn_bf16:            C[I][J] = A[R][I]^T * B[R][J]  (final conv: A = dlogits, B = activations -> dW[Cout][Cin])
  *   epi_deconv4x4s2_bwd_weight:  dw_taps[16][Cin][Cout], tap = kh*4+kw, from x [B][H][W][Cin], dy [B][2H][2W][Cout]
- *   epi_column_sums_bf16:        sums[2C] = per-column (sum, sum of squares) of x [R][C]  (bias gradient) */
+ *   epi_column_sums_bf16:        sums[2C] = per-column (sum, sum of squares) of x [R][C]  (bias gradient);
+ *                                partials_ws as for the BatchNorm entry points */
 size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap);
 int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J,
                      void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, epi_stream_t stream);
-int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream);
+int epi_column_sums_bf16(const void* x, long long R, int C, float* partials_ws, float* sums, epi_stream_t stream);
 
 #ifdef __cplusplus
 }
