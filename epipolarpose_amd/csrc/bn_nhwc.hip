@@ -13,13 +13,13 @@
 namespace epi {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_WG = 1024;        // reduction workgroups per tensor: each writes one [2C] partial (no atomics)
+constexpr int BN_MAX_WG = 512;         // reduction workgroups per tensor: few enough that the 2C fp32 atomics each issues do not contend
 
 enum { BN_MASK_NONE = 0, BN_MASK_FROM_X = 1, BN_MASK_FROM_Y = 2 };
 
-// part[wg][0..C) = sum x, part[wg][C..2C) = sum x^2 over the workgroup's row block
+// sums[0..C) += sum x, sums[C..2C) += sum x^2 over the workgroup's row block   (sums zero on entry)
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
-                                                              int rows_per_wg, float* __restrict__ part) {
+                                                              int rows_per_wg, float* __restrict__ sums) {
     extern __shared__ float red[];                 // [rlanes][2][C]
     const int cg = C >> 3;                          // 8-channel groups per row
     const int rlanes = BN_THREADS / cg;             // rows processed concurrently by the workgroup
@@ -30,7 +30,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     if (rl < rlanes) {
-        for (long long r = r0 + rl; r < r1; r += rlanes) {
+        long long r = r0 + rl;
+        for (; r + rlanes < r1; r += 2 * rlanes) {          // two independent 16-byte loads in flight
+            float v[8], w[8];
+            Elem<unsigned short>::load(x + r * C + g * 8, v);
+            Elem<unsigned short>::load(x + (r + rlanes) * C + g * 8, w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += v[k] + w[k]; q[k] += v[k] * v[k] + w[k] * w[k]; }
+        }
+        for (; r < r1; r += rlanes) {
             float v[8];
             Elem<unsigned short>::load(x + r * C + g * 8, v);
 #pragma unroll
@@ -44,50 +52,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
         const int which = c / C, ch = c - which * C;
         float t = 0.f;
         for (int l = 0; l < rlanes; ++l) t += red[(l * 2 + which) * C + ch];
-        part[(long long)blockIdx.x * 2 * C + c] = t;
+        atomicAdd(sums + c, t);
     }
-}
-
-// sums[c] = sum over workgroups of part[wg][c]  (c < 2C): 64 columns x 4 segments per block
-__device__ __forceinline__ float sum_partials(const float* __restrict__ part, int nwg, int C2, int c, float* red4 /*[4][64]*/) {
-    const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    float t = 0.f;
-    if (c < C2)
-        for (int w = seg; w < nwg; w += 4) t += part[(long long)w * C2 + c];
-    red4[seg * 64 + cl] = t;
-    __syncthreads();
-    const float r = red4[cl] + red4[64 + cl] + red4[128 + cl] + red4[192 + cl];
-    __syncthreads();
-    return r;
 }
 
 // Training: mean / rstd from the batch sums, running statistics (momentum, unbiased variance), fused affine
 // scale/shift; clears the sums for the next call and bumps num_batches_tracked.
 // Inference (sums == nullptr): scale/shift from the running statistics.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nwg, long long R, int C,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                          float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          long long* __restrict__ num_batches, float* __restrict__ mean,
-                                                          float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ float red4[256];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool lead = threadIdx.x < 64 && c < C;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches && part) num_batches[0] += 1;
+__global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ num_batches, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches && sums) num_batches[0] += 1;
+    if (c >= C) return;
     double m, var;
-    if (part) {
-        const float s1 = sum_partials(part, nwg, 2 * C, c < C ? c : 2 * C, red4);
-        const float s2 = sum_partials(part, nwg, 2 * C, c < C ? C + c : 2 * C, red4);
-        if (!lead) return;
-        m = (double)s1 / (double)R;
-        var = (double)s2 / (double)R - m * m;
+    if (sums) {
+        m = (double)sums[c] / (double)R;
+        var = (double)sums[C + c] / (double)R - m * m;
         if (var < 0) var = 0;
+        sums[c] = 0.f;                 // leave the accumulator clean for the next call (and graph replays)
+        sums[C + c] = 0.f;
         if (running_mean) {
             const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     } else {
-        if (!lead) return;
         m = running_mean[c];
         var = running_var[c];
     }
@@ -126,7 +117,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
                                                                    const unsigned short* __restrict__ y, long long R, int C,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                   int rows_per_wg, float* __restrict__ part) {
+                                                                   int rows_per_wg, float* __restrict__ sums) {
     extern __shared__ float red[];
     const int cg = C >> 3;
     const int rlanes = BN_THREADS / cg;
@@ -163,16 +154,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
         const int which = c / C, ch = c - which * C;
         float t = 0.f;
         for (int l = 0; l < rlanes; ++l) t += red[(l * 2 + which) * C + ch];
-        part[(long long)blockIdx.x * 2 * C + c] = t;
+        atomicAdd(sums + c, t);
     }
-}
-
-// sums[0..2C) = sum over workgroups of the partials (dbeta | dgamma)
-__global__ __launch_bounds__(256) void bn_sum_partials_kernel(const float* __restrict__ part, int nwg, int C2, float* __restrict__ sums) {
-    __shared__ float red4[256];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const float r = sum_partials(part, nwg, C2, c < C2 ? c : C2, red4);
-    if (threadIdx.x < 64 && c < C2) sums[c] = r;
 }
 
 // dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  dres = dz (residual branch gradient) when requested
@@ -226,28 +209,26 @@ static inline void reduce_blocking(long long R, int C, int* rows_per_wg, int* nw
 
 using namespace epi;
 
-extern "C" size_t epi_bn_workspace_floats(int C) { return (size_t)BN_MAX_WG * 2 * (size_t)C; }
-
 extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                               float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* partials_ws, void* y,
+                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws, void* y,
                               epi_stream_t stream) {
     if (!x || !gamma || !beta || !scale_shift || !y) return EPI_ERR_INVALID_ARGUMENT;
-    if (training && (!mean || !rstd || !partials_ws)) return EPI_ERR_INVALID_ARGUMENT;
+    if (training && (!mean || !rstd || !sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
     if (!training && (!running_mean || !running_var)) return EPI_ERR_INVALID_ARGUMENT;
     if ((running_mean == nullptr) != (running_var == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    int rpw = 0, nwg = 0;
     if (training) {
+        int rpw = 0, nwg = 0;
         reduce_blocking(R, C, &rpw, &nwg);
         const int rlanes = BN_THREADS / (C >> 3);
         hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                           (const unsigned short*)x, R, C, rpw, partials_ws);
+                           (const unsigned short*)x, R, C, rpw, sums_ws);
         EPI_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, training ? partials_ws : nullptr, nwg, R, C, gamma, beta,
-                       eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C);
     EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
@@ -263,9 +244,9 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
 }
 
 extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
-                              const float* rstd, const float* scale_shift, int relu, float* partials_ws, float* dbeta_dgamma, void* dx,
-                              void* dres, epi_stream_t stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !partials_ws || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
+                              const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                              epi_stream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -276,13 +257,11 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     const int mask = !relu ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x, *ys = (const unsigned short*)y;
     const float *sc = scale_shift, *sh = scale_shift + C;
-#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(nwg), dim3(BN_THREADS), lds, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, partials_ws)
+#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(nwg), dim3(BN_THREADS), lds, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
     if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
     else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
     else EPI_BN_RED(BN_MASK_FROM_Y);
 #undef EPI_BN_RED
-    EPI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, partials_ws, nwg, 2 * C, dbeta_dgamma);
     EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
@@ -296,19 +275,17 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     return EPI_OK;
 }
 
-// Per-column sum and sum of squares of a bf16 matrix x [R][C] -> sums [2C] f32 (bias gradient of the final conv:
-// db = sum over rows of dlogits; torch computes it as a separate reduction in Conv2d's backward).
-extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* partials_ws, float* sums, epi_stream_t stream) {
-    if (!x || !sums || !partials_ws) return EPI_ERR_INVALID_ARGUMENT;
+// Per-column sum and sum of squares of a bf16 matrix x [R][C], ACCUMULATED into sums [2C] f32 (caller zeroes it)
+// (bias gradient of the final conv: db = sum over rows of dlogits).
+extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
+    if (!x || !sums) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int rpw = 0, nwg = 0;
     reduce_blocking(R, C, &rpw, &nwg);
     const int rlanes = BN_THREADS / (C >> 3);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                       (const unsigned short*)x, R, C, rpw, partials_ws);
-    EPI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, st, partials_ws, nwg, 2 * C, sums);
+                       (const unsigned short*)x, R, C, rpw, sums);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

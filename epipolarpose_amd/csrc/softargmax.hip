@@ -98,6 +98,28 @@ __device__ __forceinline__ long long row_base_of(const RowGeom& g, int row) {
     return (long long)row * g.N;
 }
 
+// raw (unconverted) 16-byte vector held in registers while the next block's loads are in flight
+template <typename T, int VEC> struct RawVec {
+    uint4v r;
+    __device__ __forceinline__ void load(const T* p) { r = *reinterpret_cast<const uint4v*>(p); }
+    __device__ __forceinline__ void fill_low() { r.x = r.y = r.z = r.w = (sizeof(T) == 4) ? 0xff7fffffu : 0xff7fff7fu; }   // -FLT_MAX / -bf16 max
+    __device__ __forceinline__ void unpack(float (&v)[VEC]) const {
+        if (sizeof(T) == 4) {
+            v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y); v[2] = __uint_as_float(r.z); v[VEC - 1] = __uint_as_float(r.w);
+        } else {
+            const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[(2 * i) % VEC] = __uint_as_float(w[i] << 16); v[(2 * i + 1) % VEC] = __uint_as_float(w[i] & 0xffff0000u); }
+        }
+    }
+};
+template <typename T> struct RawVec<T, 1> {
+    float r;
+    __device__ __forceinline__ void load(const T* p) { r = Elem<T>::load1(p); }
+    __device__ __forceinline__ void fill_low() { r = -FLT_MAX; }
+    __device__ __forceinline__ void unpack(float (&v)[1]) const { v[0] = r; }
+};
+
 template <typename T, int VEC, bool NHWC, int ITERS>
 __global__ __launch_bounds__(SA_THREADS) void softargmax_partial_kernel(const T* __restrict__ logits, RowGeom g,
                                                                         int nchunk, SoftPartial* __restrict__ part) {
@@ -105,49 +127,53 @@ __global__ __launch_bounds__(SA_THREADS) void softargmax_partial_kernel(const T*
     const int chunk = blockIdx.x - row * nchunk;
     const int tid = threadIdx.x;
     constexpr int STRIDE = SA_THREADS * VEC;
+    constexpr int NBLK = ITERS / SA_UNROLL;
     const int e_begin = chunk * (STRIDE * ITERS) + tid * VEC;
-    const bool full = (chunk + 1) * (STRIDE * ITERS) <= g.N;      // workgroup-uniform: no bounds checks needed
 
     Cursor<NHWC> cur;
     cur.init(g, row_base_of<NHWC>(g, row), e_begin, STRIDE);
 
-    // running state: ml = max * log2(e) so that exp(x - max) = exp2(fma(x, log2e, -ml)) costs one FMA + v_exp_f32
-    float ml = -FLT_MAX, s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // running state: mx = exact running max; exp(x - mx) = exp2(fma(x, log2e, -mx*log2e)): one FMA + v_exp_f32
+    float mx = -FLT_MAX, s = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
     int e = e_begin;
-#pragma unroll 1
-    for (int it = 0; it < ITERS; it += SA_UNROLL) {
-        float x[SA_UNROLL][VEC];
-        float k0[SA_UNROLL], k1[SA_UNROLL], k2[SA_UNROLL];
-        bool ok[SA_UNROLL];
-        float bm = -FLT_MAX;
+    RawVec<T, VEC> cur_raw[SA_UNROLL], nxt_raw[SA_UNROLL];
+    float k0[SA_UNROLL], k1[SA_UNROLL], k2[SA_UNROLL], n0[SA_UNROLL], n1[SA_UNROLL], n2[SA_UNROLL];
+    bool ok[SA_UNROLL], nok[SA_UNROLL];
+    auto issue = [&](RawVec<T, VEC> (&dst)[SA_UNROLL], float (&c0)[SA_UNROLL], float (&c1)[SA_UNROLL], float (&c2)[SA_UNROLL],
+                     bool (&valid)[SA_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < SA_UNROLL; ++u) {
-            ok[u] = full || (e < g.N);
-            if (ok[u]) {
-                VecIO<T, VEC>::load(logits + cur.mem, x[u]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) x[u][k] = -FLT_MAX;
-            }
-            k0[u] = cur.c0; k1[u] = cur.c1; k2[u] = cur.c2;
+            valid[u] = e < g.N;
+            if (valid[u]) dst[u].load(logits + cur.mem); else dst[u].fill_low();
+            c0[u] = cur.c0; c1[u] = cur.c1; c2[u] = cur.c2;
             cur.advance();
             e += STRIDE;
         }
+    };
+    issue(cur_raw, k0, k1, k2, ok);
+#pragma unroll 1
+    for (int blk = 0; blk < NBLK; ++blk) {
+        if (blk + 1 < NBLK) issue(nxt_raw, n0, n1, n2, nok);        // next block's loads fly during this block's math
+        float x[SA_UNROLL][VEC];
+        float bm = -FLT_MAX;
 #pragma unroll
-        for (int u = 0; u < SA_UNROLL; ++u)
+        for (int u = 0; u < SA_UNROLL; ++u) {
+            cur_raw[u].unpack(x[u]);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) bm = fmaxf(bm, x[u][k]);
-        const float mln = fmaxf(ml, bm * EPI_LOG2E);
-        const float sc = fast_exp2(ml - mln);
+        }
+        const float mn = fmaxf(mx, bm);
+        const float sc = fast_exp2((mx - mn) * EPI_LOG2E);
         s *= sc; a0 *= sc; a1 *= sc; a2 *= sc;
-        ml = mln;
+        mx = mn;
+        const float ml = mx * EPI_LOG2E;
 #pragma unroll
         for (int u = 0; u < SA_UNROLL; ++u) {
             float es = 0.f, ek = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 float ex = fast_exp2(fmaf(x[u][k], EPI_LOG2E, -ml));
-                if (!full) ex = ok[u] ? ex : 0.f;
+                ex = ok[u] ? ex : 0.f;
                 es += ex;
                 if (k) ek = fmaf(ex, (float)k, ek);
             }
@@ -156,12 +182,15 @@ __global__ __launch_bounds__(SA_THREADS) void softargmax_partial_kernel(const T*
             a1 = fmaf(es, k1[u], a1);
             a2 = fmaf(es, k2[u], a2);
         }
+#pragma unroll
+        for (int u = 0; u < SA_UNROLL; ++u) {
+            cur_raw[u] = nxt_raw[u]; k0[u] = n0[u]; k1[u] = n1[u]; k2[u] = n2[u]; ok[u] = nok[u];
+        }
     }
     // wave reduce: one max reduction, one rescale, then plain sums (no exp inside the shuffle tree)
-    const float mw = wave_max(ml);
-    const float f = fast_exp2(ml - mw);
+    float m = wave_max(mx);
+    const float f = fast_exp2((mx - m) * EPI_LOG2E);
     s = wave_sum(s * f); a0 = wave_sum(a0 * f); a1 = wave_sum(a1 * f); a2 = wave_sum(a2 * f);
-    float m = mw / EPI_LOG2E;
     __shared__ float red[SA_THREADS / 64][5];
     const int lane = tid & 63, wid = tid >> 6;
     if (lane == 0) { red[wid][0] = m; red[wid][1] = s; red[wid][2] = a0; red[wid][3] = a1; red[wid][4] = a2; }

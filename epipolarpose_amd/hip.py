@@ -46,12 +46,11 @@ _SIGNATURES = {
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp]),
-    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "epi_bn_workspace_floats": (_sz, [_i]),
+    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp]),
+    "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -417,7 +416,8 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     return dx
 
 
-def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, training, momentum, eps,
+               relu):
     """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last).
     -> (y, mean, rstd, scale_shift); mean/rstd are None in inference."""
     lib = load()
@@ -432,11 +432,10 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_
     mean = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     rstd = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     scale_shift = torch.empty(2 * c, dtype=torch.float32, device=dev)
-    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), dev) if training else None
     with torch.cuda.device(dev):
         _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
                                   int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
-                                  _ptr(rstd), _ptr(scale_shift), _ptr(ws), _ptr(y), _stream()), "epi_bn_act_fwd")
+                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(y), _stream()), "epi_bn_act_fwd")
     return y, mean, rstd, scale_shift
 
 
@@ -447,11 +446,10 @@ def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres):
     b, c, h, w = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), x.device)
+    sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
-                                  int(relu), _ptr(ws), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
+                                  int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
     return dx, dres, sums[c:], sums[:c]
 
 
@@ -498,8 +496,7 @@ def column_sum_bf16(x):
     _dev(x, torch.bfloat16, "x")
     x = x if x.is_contiguous() else x.contiguous()
     r, c = x.shape
-    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-    ws = _workspace(4 * lib.epi_bn_workspace_floats(c), x.device)
+    sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(ws), _ptr(sums), _stream()), "epi_column_sums_bf16")
+        _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(sums), _stream()), "epi_column_sums_bf16")
     return sums[:c]

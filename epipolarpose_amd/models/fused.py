@@ -24,7 +24,7 @@ class _BNActFunction(torch.autograd.Function):
         training = module.training
         y, mean, rstd, scale_shift = hip.bn_act_fwd(
             x, residual, weight, bias, module.running_mean, module.running_var, module.num_batches_tracked,
-            training, module.momentum, module.eps, relu)
+            module.sums_ws, training, module.momentum, module.eps, relu)
         ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
         if training:
             ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, rstd, scale_shift)
@@ -51,6 +51,7 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
 
     def forward(self, x, residual=None):
         x = _nhwc_bf16(x)

@@ -175,34 +175,32 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  * (+ `out += residual`) of lib/models/pose3d_resnet.py:31-47,68-88,158-183,186-188.
  *   x, residual, y : [R][C] bf16 (R = B*H*W, C % 8 == 0);  gamma, beta, running_mean, running_var, mean, rstd : [C] f32
  *   scale_shift    : [2C] f32 out (scale = gamma*rstd, shift = beta - mean*scale), reused by the backward
- *   partials_ws    : f32 scratch of epi_bn_workspace_floats(C) elements (per-workgroup partial sums; no
- *                    atomics, no zero-initialisation needed)
+ *   sums_ws        : [2C] f32 accumulator that must be ZERO on entry; it is zero again on return (keep one per
+ *                    layer: graph replays then need no memset)
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
  *                    num_batches_tracked += 1;   training == 0: running statistics.
- * Backward (training):  dbeta_dgamma [2C] f32 out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
+ * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
  *   = gradient of the residual input;  y = saved forward output, required when relu && dres.
  * ------------------------------------------------------------------------------------------------ */
-size_t epi_bn_workspace_floats(int C);
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
-                   long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* partials_ws,
+                   long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
                    void* y, epi_stream_t stream);
 int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma,
-                   const float* mean, const float* rstd, const float* scale_shift, int relu, float* partials_ws,
+                   const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (ntap = 1 for epi_gemm_tn_bf16, 16 for the deconvolution).
  *   epi_gemm_tn_bf16:            C[I][J] = A[R][I]^T * B[R][J]  (final conv: A = dlogits, B = activations -> dW[Cout][Cin])
  *   epi_deconv4x4s2_bwd_weight:  dw_taps[16][Cin][Cout], tap = kh*4+kw, from x [B][H][W][Cin], dy [B][2H][2W][Cout]
- *   epi_column_sums_bf16:        sums[2C] = per-column (sum, sum of squares) of x [R][C]  (bias gradient);
- *                                partials_ws as for the BatchNorm entry points */
+ *   epi_column_sums_bf16:        sums[2C] += per-column (sum, sum of squares) of x [R][C]  (bias gradient; zero it first) */
 size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap);
 int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J,
                      void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, epi_stream_t stream);
-int epi_column_sums_bf16(const void* x, long long R, int C, float* partials_ws, float* sums, epi_stream_t stream);
+int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream);
 
 #ifdef __cplusplus
 }
