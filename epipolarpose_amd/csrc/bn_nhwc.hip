@@ -13,7 +13,7 @@
 namespace epi {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_WG = 512;         // reduction workgroups per tensor: few enough that the 2C fp32 atomics each issues do not contend
+constexpr int BN_MAX_WG = 1024;        // reduction workgroups per tensor: few enough that the 2C fp32 atomics each issues do not contend
 
 enum { BN_MASK_NONE = 0, BN_MASK_FROM_X = 1, BN_MASK_FROM_Y = 2 };
 
@@ -31,12 +31,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     if (rl < rlanes) {
         long long r = r0 + rl;
-        for (; r + rlanes < r1; r += 2 * rlanes) {          // two independent 16-byte loads in flight
-            float v[8], w[8];
-            Elem<unsigned short>::load(x + r * C + g * 8, v);
-            Elem<unsigned short>::load(x + (r + rlanes) * C + g * 8, w);
+        for (; r + 3LL * rlanes < r1; r += 4LL * rlanes) {   // four independent 16-byte loads in flight per lane
+            uint4v raw[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s[k] += v[k] + w[k]; q[k] += v[k] * v[k] + w[k] * w[k]; }
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4v*>(x + (r + (long long)u * rlanes) * C + g * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+                    s[2 * i] += lo; q[2 * i] = fmaf(lo, lo, q[2 * i]);
+                    s[2 * i + 1] += hi; q[2 * i + 1] = fmaf(hi, hi, q[2 * i + 1]);
+                }
+            }
         }
         for (; r < r1; r += rlanes) {
             float v[8];
@@ -131,11 +139,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
     const long long r0 = (long long)blockIdx.x * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     if (rl < rlanes) {
-        for (long long r = r0 + rl; r < r1; r += rlanes) {
-            float xv[8], gv[8], yv[8];
-            Elem<unsigned short>::load(x + r * C + g * 8, xv);
-            Elem<unsigned short>::load(dy + r * C + g * 8, gv);
-            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + g * 8, yv);
+        auto accum = [&](const float (&xv)[8], const float (&gv)[8], const float (&yv)[8]) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 bool on = true;
@@ -145,6 +149,27 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
                 s[k] += dz;
                 q[k] += dz * (xv[k] - mu[k]) * rs[k];
             }
+        };
+        long long r = r0 + rl;
+        for (; r + rlanes < r1; r += 2LL * rlanes) {        // two rows (4-6 independent 16-byte loads) in flight per lane
+            float xa[8], ga[8], ya[8], xb[8], gb[8], yb[8];
+            Elem<unsigned short>::load(x + r * C + g * 8, xa);
+            Elem<unsigned short>::load(dy + r * C + g * 8, ga);
+            Elem<unsigned short>::load(x + (r + rlanes) * C + g * 8, xb);
+            Elem<unsigned short>::load(dy + (r + rlanes) * C + g * 8, gb);
+            if (MASK == BN_MASK_FROM_Y) {
+                Elem<unsigned short>::load(y + r * C + g * 8, ya);
+                Elem<unsigned short>::load(y + (r + rlanes) * C + g * 8, yb);
+            }
+            accum(xa, ga, ya);
+            accum(xb, gb, yb);
+        }
+        for (; r < r1; r += rlanes) {
+            float xv[8], gv[8], yv[8];
+            Elem<unsigned short>::load(x + r * C + g * 8, xv);
+            Elem<unsigned short>::load(dy + r * C + g * 8, gv);
+            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + g * 8, yv);
+            accum(xv, gv, yv);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { red[(rl * 2 + 0) * C + g * 8 + k] = s[k]; red[(rl * 2 + 1) * C + g * 8 + k] = q[k]; }
