@@ -37,12 +37,13 @@ def parse_args():
     ap.add_argument("--joints", type=int, default=17)
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (diagnostic; not the bench line)")
+    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as one hipGraph; 0: eager; -1: graph when N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
 
 
-def build_problem(args, device, rank):
+def build_problem(args, device, rank, capturable=False):
     from epipolarpose_amd.core import integral_loss
     from epipolarpose_amd.core.config import default_config
     from epipolarpose_amd.hip import DeviceMeta
@@ -61,7 +62,7 @@ def build_problem(args, device, rank):
     model = get_pose_net(cfg, is_train=True).to(device)
     model.train()
     criterion = getattr(integral_loss, cfg.LOSS.FN)(num_joints=cfg.MODEL.NUM_JOINTS, norm=cfg.LOSS.NORM).to(device)
-    optimizer = get_optimizer(cfg, model)        # Adam, lr 1e-3 (train.yaml)
+    optimizer = get_optimizer(cfg, model, capturable=capturable)        # Adam, lr 1e-3 (train.yaml)
 
     n_group = args.batch // args.views
     scenes = SyntheticScenes(n_group=n_group, n_view=args.views, num_joints=args.joints, patch=256, seed=100 + rank)
@@ -139,7 +140,7 @@ def main():
     args = parse_args()
     from epipolarpose_amd import distributed as epd
     from epipolarpose_amd import hip
-    from epipolarpose_amd.core.function import train_step
+    from epipolarpose_amd.core.function import GraphedTrainStep, train_step
 
     rank, world, local = epd.init_from_env()
     if world != args.gpus:
@@ -151,7 +152,8 @@ def main():
     hip.load()
     torch.backends.cudnn.benchmark = True        # reference CUDNN.BENCHMARK: true -> MIOpen find mode
 
-    cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank)
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank, capturable=use_graph)
     grad_sync = None
     if world > 1:
         epd.broadcast_module(model)
@@ -159,9 +161,15 @@ def main():
     n_view = args.views if args.workload == "ss" else None
     # 4-view SS uses the V-view generalisation of the reference's iterative LS solver (V=2 is the reference itself)
 
-    def step():
+    def eager_step():
         return train_step(model, criterion, optimizer, images, label, weight, meta=meta, n_view=n_view,
                           autocast=not args.fp32, grad_sync=grad_sync)
+    step = eager_step
+    if use_graph:
+        if world > 1:
+            raise SystemExit("--graph 1 is single-GPU only (the gradient all-reduce is issued eagerly)")
+        step = GraphedTrainStep(model, criterion, optimizer, images, label, weight, meta=meta, n_view=n_view,
+                                autocast=not args.fp32)
 
     def barrier():
         if world > 1:
@@ -172,7 +180,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     hip.timer.reset()
-    hip.timer.enabled = True
+    hip.timer.enabled = not use_graph            # events cannot be recorded inside a replayed graph
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -181,6 +189,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hip.timer.enabled = False
+    if use_graph:
+        # per-kernel durations for the roofline: the same criterion kernels on the same resident logits-sized tensor,
+        # launched eagerly with HIP events on the launch stream right after the timed region
+        hip.timer.reset()
+        hip.timer.enabled = True
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=not args.fp32):
+            probe_logits = model(images)
+        probe_logits = probe_logits.detach().requires_grad_(True)
+        for _ in range(args.steps):
+            criterion(probe_logits, label, weight).backward()
+        torch.cuda.synchronize()
+        hip.timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -225,7 +245,8 @@ def main():
                                     "configs[2]: ResNet-%d self-supervised, 4-view %dx%d epipolar-triangulation pseudo-labels, "
                                     "batch=%d/GPU") % (args.layers, args.image, args.image, args.batch),
                        "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
-                       "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6)},
+                       "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6),
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

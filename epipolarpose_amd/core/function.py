@@ -39,6 +39,43 @@ def train_step(model, criterion, optimizer, batch_data, batch_label, batch_label
     return loss.detach()
 
 
+class GraphedTrainStep:
+    """One optimisation step captured as a hipGraph and replayed (north-star: HIP graphs instead of a tracing compiler).
+
+    The eager step issues ~800 launches; at batch 32 their host-side cost (Python + dispatcher) exceeds the GPU time,
+    so the whole step -- forward, criterion, backward, Adam -- is captured once on static tensors and replayed with a
+    single host call.  Inputs are copied into the static buffers before each replay.  Requires a capturable optimizer
+    (``torch.optim.Adam(..., capturable=True)``) and warmed-up MIOpen kernels (done here on a side stream).
+    """
+
+    def __init__(self, model, criterion, optimizer, batch_data, batch_label, batch_label_weight, meta=None, n_view=None,
+                 ss_method="iterative", autocast=True, warmup=3):
+        self.data, self.label, self.weight = batch_data, batch_label, batch_label_weight
+        args = (model, criterion, optimizer, self.data, self.label, self.weight)
+        kw = dict(meta=meta, n_view=n_view, ss_method=ss_method, autocast=autocast)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(*args, **kw)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(*args, **kw)
+
+    def __call__(self, batch_data=None, batch_label=None, batch_label_weight=None):
+        if batch_data is not None and batch_data is not self.data:
+            self.data.copy_(batch_data, non_blocking=True)
+        if batch_label is not None and batch_label is not self.label:
+            self.label.copy_(batch_label, non_blocking=True)
+        if batch_label_weight is not None and batch_label_weight is not self.weight:
+            self.weight.copy_(batch_label_weight, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
 def train_integral(config, train_loader, model, criterion, optimizer, epoch, grad_sync=None):
     batch_time, data_time, losses = AverageMeter(), AverageMeter(), AverageMeter()
     model.train()

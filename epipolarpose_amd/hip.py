@@ -112,8 +112,33 @@ def _check(status, what):
         raise RuntimeError("%s failed: %s" % (what, load().epi_status_string(status).decode()))
 
 
-def _stream():
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device_index=None):
+    """Raw hipStream_t of torch's current stream.  The fast private accessor keeps the per-call Python overhead low
+    (hundreds of launches per step); it follows stream switches (side streams, graph capture) like the public API."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if device_index is None else device_index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoCtx:
+    """Kernels run on the CURRENT device; callers keep tensors on it (one process per GPU).  `with _on(t.device)` used
+    to switch devices per call, which cost ~15 us of host time per launch."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def _on(device):
+    return _NOCTX
 
 
 def _dev(t, dtype=None, name="tensor"):
@@ -172,7 +197,7 @@ def softargmax3d_fwd(logits, num_joints):
     rsum = torch.empty_like(rmax)
     nbytes = lib.epi_softargmax3d_workspace_bytes(b, num_joints, d, h, w)
     ws = _workspace(nbytes, logits.device)
-    with torch.cuda.device(logits.device):
+    with _on(logits.device):
         ev = timer.start("epi_softargmax3d_fwd")
         _check(lib.epi_softargmax3d_fwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(xyz), _ptr(rmax), _ptr(rsum),
                                         _ptr(ws), ws.numel(), _stream()), "epi_softargmax3d_fwd")
@@ -189,7 +214,7 @@ def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_s
     d = c // num_joints
     grad_xyz = _dev(grad_xyz, torch.float32, "grad_xyz").contiguous()
     dlogits = torch.empty_like(logits)      # preserves the memory format
-    with torch.cuda.device(logits.device):
+    with _on(logits.device):
         ev = timer.start("epi_softargmax3d_bwd")
         _check(lib.epi_softargmax3d_bwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(row_max), _ptr(row_sum),
                                         _ptr(xyz), _ptr(grad_xyz), _ptr(grad_scale), _ptr(dlogits), _stream()),
@@ -209,7 +234,7 @@ def joint_loss(pred, target, weight, kind, norm=False, size_average=True, need_g
     b, n = pred.shape
     loss = torch.empty((), dtype=torch.float32, device=pred.device)
     grad = torch.empty_like(pred) if need_grad else None
-    with torch.cuda.device(pred.device):
+    with _on(pred.device):
         _check(lib.epi_joint_loss(_ptr(pred), _ptr(target), _ptr(weight), b, n, LOSS_KINDS[kind], int(bool(norm)),
                                   int(bool(size_average)), _ptr(loss), _ptr(grad), _stream()), "epi_joint_loss")
     return loss, grad
@@ -228,7 +253,7 @@ def argmax_rows(x):
     val = torch.empty((rows,), dtype=torch.float32, device=x.device)
     nbytes = lib.epi_argmax_workspace_bytes(rows, n)
     ws = _workspace(nbytes, x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib.epi_argmax_rows(_ptr(x), dt, rows, n, _ptr(idx), _ptr(val), _ptr(ws), ws.numel(), _stream()),
                "epi_argmax_rows")
     return idx, val
@@ -262,7 +287,7 @@ def decode_to_image(xyz, meta, patch_w=256.0, patch_h=256.0, rect3d=2000.0):
     xyz = _dev(xyz, torch.float32, "xyz").contiguous()
     b, j = xyz.shape[0], xyz.shape[1] // 3
     out = torch.empty((b, j, 3), dtype=torch.float64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         _check(lib.epi_decode_to_image(_ptr(xyz), b, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d, _ptr(out),
                                        _stream()), "epi_decode_to_image")
     return out
@@ -282,7 +307,7 @@ def triangulate(kps, proj, n_view, method="iterative", tolerance=3.0e-5, max_ite
     dt = EPI_F64 if kps.dtype == torch.float64 else EPI_F32
     x = torch.empty((g, j, 3), dtype=kps.dtype, device=kps.device)
     status = torch.empty((g, j), dtype=torch.int32, device=kps.device)
-    with torch.cuda.device(kps.device):
+    with _on(kps.device):
         if method == "iterative":
             st = lib.epi_triangulate_iterls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, tolerance, max_iter, _ptr(x),
                                             _ptr(status), _stream())
@@ -304,7 +329,7 @@ def reproject_labels(x_world, meta, n_view, patch_w=256.0, patch_h=256.0, rect3d
     b = g * n_view
     label = torch.empty((b, 3 * j), dtype=torch.float32, device=x_world.device)
     weight = torch.empty_like(label)
-    with torch.cuda.device(x_world.device):
+    with _on(x_world.device):
         _check(lib.epi_reproject_labels(_ptr(x_world), g, n_view, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d,
                                         root_joint, _ptr(label), _ptr(weight), _stream()), "epi_reproject_labels")
     return label, weight
@@ -322,7 +347,7 @@ def self_supervision(xyz, meta, n_view, method="iterative", patch_w=256.0, patch
     label = torch.empty((b, 3 * j), dtype=torch.float32, device=xyz.device)
     weight = torch.empty_like(label)
     xw = torch.empty((g, j, 3), dtype=torch.float64, device=xyz.device) if want_world else None
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         ev = timer.start("epi_self_supervision")
         _check(lib.epi_self_supervision(_ptr(xyz), g, n_view, j, ctypes.byref(meta.struct), patch_w, patch_h, rect3d,
                                         root_joint, TRI_METHODS[method], tolerance, max_iter, _ptr(label), _ptr(weight),
@@ -361,7 +386,7 @@ def gemm_bf16(a, bt, bias=None, out_dtype=torch.bfloat16, out=None):
     if bias is not None:
         bias = _dev(bias, torch.float32, "bias").contiguous()
     ws = _workspace(lib.epi_gemm_workspace_bytes(m, n, k, 1), a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         ev = timer.start("epi_gemm_bf16")
         _check(lib.epi_gemm_bf16(_ptr(a), a.stride(0), _ptr(bt), bt.stride(0), _ptr(out), out.stride(0), cdt, m, n, k,
                                  _ptr(bias), _ptr(ws), ws.numel(), _stream()), "epi_gemm_bf16")
@@ -379,7 +404,7 @@ def deconv_pack_weight(weight, want_phase=True, want_bwd=True):
     w = weight.detach().to(torch.bfloat16).contiguous()
     wp = torch.empty((4, cout, 4 * cin), dtype=torch.bfloat16, device=w.device) if want_phase else None
     wb = torch.empty((cin, 16 * cout), dtype=torch.bfloat16, device=w.device) if want_bwd else None
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _check(lib.epi_deconv4x4s2_pack_weight(_ptr(w), cin, cout, _ptr(wp), _ptr(wb), _stream()), "epi_deconv4x4s2_pack_weight")
     return wp, wb
 
@@ -392,7 +417,7 @@ def deconv4x4s2_fwd(x, w_phase):
     cout = w_phase.shape[1]
     y = torch.empty((b, cout, 2 * h, 2 * w), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     ws = _workspace(lib.epi_gemm_workspace_bytes(b * h * w, cout, 4 * cin, 4), x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         ev = timer.start("epi_deconv4x4s2_fwd")
         _check(lib.epi_deconv4x4s2_fwd(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
                "epi_deconv4x4s2_fwd")
@@ -408,7 +433,7 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     cin = w_bwd.shape[0]
     dx = torch.empty((b, cin, h2 // 2, w2 // 2), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     ws = _workspace(lib.epi_gemm_workspace_bytes(b * (h2 // 2) * (w2 // 2), cin, 16 * cout, 1), dy.device)
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         ev = timer.start("epi_deconv4x4s2_bwd_data")
         _check(lib.epi_deconv4x4s2_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h2 // 2, w2 // 2, cin, cout, _ptr(ws), ws.numel(),
                                             _stream()), "epi_deconv4x4s2_bwd_data")
@@ -432,7 +457,7 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_
     mean = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     rstd = torch.empty(c, dtype=torch.float32, device=dev) if training else None
     scale_shift = torch.empty(2 * c, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
                                   int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
                                   _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(y), _stream()), "epi_bn_act_fwd")
@@ -447,7 +472,7 @@ def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres):
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
                                   int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
     return dx, dres, sums[c:], sums[:c]
@@ -466,7 +491,7 @@ def gemm_tn_bf16(a, b):
     j = b.shape[1]
     out = torch.empty((i, j), dtype=torch.float32, device=a.device)
     ws = _workspace(lib.epi_gemm_tn_workspace_bytes(r, i, j, 1), a.device)
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         ev = timer.start("epi_gemm_tn_bf16")
         _check(lib.epi_gemm_tn_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), r, i, j, _ptr(ws), ws.numel(), _stream()),
                "epi_gemm_tn_bf16")
@@ -482,7 +507,7 @@ def deconv4x4s2_bwd_weight(x, dy):
     cout = dy.shape[1]
     taps = torch.empty((16, cin, cout), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.epi_gemm_tn_workspace_bytes(b * h * w, cin, cout, 16), x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         ev = timer.start("epi_deconv4x4s2_bwd_weight")
         _check(lib.epi_deconv4x4s2_bwd_weight(_ptr(x), _ptr(dy), _ptr(taps), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
                "epi_deconv4x4s2_bwd_weight")
@@ -497,6 +522,6 @@ def column_sum_bf16(x):
     x = x if x.is_contiguous() else x.contiguous()
     r, c = x.shape
     sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(sums), _stream()), "epi_column_sums_bf16")
     return sums[:c]

@@ -28,13 +28,14 @@ def create_logger(cfg, cfg_name, phase='train'):
     return logger, str(out_dir)
 
 
-def get_optimizer(cfg, model):
-    """utils.py:45-61.  Adam takes only the learning rate (the reference ignores TRAIN.WD for Adam)."""
+def get_optimizer(cfg, model, capturable=False):
+    """utils.py:45-61.  Adam takes only the learning rate (the reference ignores TRAIN.WD for Adam).
+    ``capturable=True`` keeps Adam's step counter on the device so the step can live inside a hipGraph."""
     if cfg.TRAIN.OPTIMIZER == 'sgd':
         return optim.SGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WD,
                          nesterov=cfg.TRAIN.NESTEROV)
     if cfg.TRAIN.OPTIMIZER == 'adam':
-        return optim.Adam(model.parameters(), lr=cfg.TRAIN.LR)
+        return optim.Adam(model.parameters(), lr=cfg.TRAIN.LR, capturable=capturable)
     return None
 
 

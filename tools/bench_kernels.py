@@ -84,8 +84,40 @@ def bench_tri():
             method, t, nbytes / t / 1e6, nbytes / t / 1e6 / HBM), flush=True)
 
 
+def bench_bn():
+    import torch.nn.functional as F
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    for shape, res in (((32, 64, 128, 128), False), ((32, 256, 64, 64), True), ((32, 64, 64, 64), False), ((32, 512, 32, 32), True),
+                       ((32, 1024, 16, 16), True), ((32, 2048, 8, 8), True), ((32, 256, 64, 64), False)):
+        b, c, h, w = shape
+        x = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        r = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+        dy = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        m = FusedBatchNormAct(c).to(DEV)
+        ref = torch.nn.BatchNorm2d(c).to(DEV)
+        nbytes = x.numel() * 2
+        xg = x.clone().requires_grad_(True)
+        rg = r.clone().requires_grad_(True) if res else None
+
+        def ours_fwd():
+            return m(xg, residual=rg)
+
+        def stock_fwd():
+            t = ref(xg)
+            if res:
+                t = t + rg
+            return torch.relu(t)
+        tf, ts = timeit(ours_fwd), timeit(stock_fwd)
+        y, t = ours_fwd(), stock_fwd()
+        tb = timeit(lambda: torch.autograd.grad(y, [xg] + ([rg] if res else []) + [m.weight, m.bias], dy, retain_graph=True))
+        tsb = timeit(lambda: torch.autograd.grad(t, [xg] + ([rg] if res else []) + [ref.weight, ref.bias], dy, retain_graph=True))
+        rf, rb = (3 if res else 2) + 1, (5 if res else 4) + (2 if res else 1)      # passes over the tensor: fwd (stats+apply), bwd
+        print("bn %-18s res=%d  fwd ours %.4f ms (%5.0f GB/s) stock %.4f ms | bwd ours %.4f ms (%5.0f GB/s) stock %.4f ms" % (
+            shape, res, tf, rf * nbytes / tf / 1e6, ts, tb, rb * nbytes / tb / 1e6, tsb), flush=True)
+
+
 if __name__ == "__main__":
     hip.load()
-    what = sys.argv[1:] or ["softargmax", "gemm", "deconv", "tri"]
+    what = sys.argv[1:] or ["softargmax", "gemm", "deconv", "tri", "bn"]
     for w in what:
         globals()["bench_" + w]()
