@@ -37,7 +37,8 @@ def parse_args():
     ap.add_argument("--joints", type=int, default=17)
     ap.add_argument("--depth", type=int, default=64)
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (diagnostic; not the bench line)")
-    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as one hipGraph; 0: eager; -1: graph when N=1")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step as one hipGraph (N=1 only); 0: eager (default: "
+                    "the step is GPU-bound and hipGraph replay measured 6 %% slower than eager launches on ROCm 7.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
@@ -152,7 +153,7 @@ def main():
     hip.load()
     torch.backends.cudnn.benchmark = True        # reference CUDNN.BENCHMARK: true -> MIOpen find mode
 
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = bool(args.graph)
     cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank, capturable=use_graph)
     grad_sync = None
     if world > 1:
@@ -212,28 +213,58 @@ def main():
         elem = 4 if args.fp32 else 2
         vox = args.joints * args.depth * (args.image // 4) ** 2
         ksum = hip.timer.summary()
+        MFMA_PEAK = 2500.0      # dense bf16 TFLOP/s (MI355X_MICROARCH.md)
+        b, hm, cd, jd = args.batch, args.image // 4, 256, args.joints * args.depth
+        # algorithmic FLOPs per launch (2 x MACs, BASELINE.md section 3 / SURVEY 2.2), B = per-GPU batch
+        flops = {
+            "epi_gemm_bf16": None,      # two shapes share this entry point: reported separately below
+            "epi_deconv4x4s2_fwd": None, "epi_deconv4x4s2_bwd_data": None, "epi_deconv4x4s2_bwd_weight": None,
+        }
+        head_ms, head_flops = 0.0, 0.0
+        deconv_macs = [2048 * 256 * 16 * (hm // 8) ** 2, 256 * 256 * 16 * (hm // 4) ** 2, 256 * 256 * 16 * (hm // 2) ** 2]
+        final_macs = cd * jd * hm * hm
+        per_step_flops = {"epi_deconv4x4s2_fwd": 2.0 * b * sum(deconv_macs), "epi_deconv4x4s2_bwd_data": 2.0 * b * sum(deconv_macs),
+                          "epi_deconv4x4s2_bwd_weight": 2.0 * b * sum(deconv_macs), "epi_gemm_bf16": 2.0 * b * final_macs * 2,
+                          "epi_gemm_tn_bf16": 2.0 * b * final_macs}
+        per_kernel = {}
+        steps_timed = args.steps
+        for name, fl in per_step_flops.items():
+            if name in ksum:
+                n, ms = ksum[name]
+                step_ms = ms * n / steps_timed
+                per_kernel[name] = {"launches_per_step": n / steps_timed, "ms_per_step": round(step_ms, 4),
+                                    "achieved_tflops": round(fl / (step_ms * 1e-3) / 1e12, 1)}
+                head_ms += step_ms
+                head_flops += fl
         n_b, ms_b = ksum["epi_softargmax3d_bwd"]
         n_f, ms_f = ksum["epi_softargmax3d_fwd"]
         bytes_bwd = 2.0 * args.batch * vox * elem          # 1 read of the logits + 1 write of dlogits
         bytes_fwd = 1.0 * args.batch * vox * elem          # 1 read of the logits
-        ach = bytes_bwd / (ms_b * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("softargmax_bwd_kernel/%s/b%d" % ("f32" if args.fp32 else "bf16", args.batch))
+                traffic = json.load(open(tpath)).get("head_gemm_kernel/b%d" % args.batch)
             except Exception:
                 traffic = None
-        roofline = {"kernel": "softargmax_bwd_kernel (epi_softargmax3d_bwd)", "bound": "hbm",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "algorithmic_bytes": bytes_bwd, "avg_ms": round(ms_b, 5), "launches": n_b,
-                    "other": {"softargmax_partial+combine (epi_softargmax3d_fwd)": {
-                        "achieved": round(bytes_fwd / (ms_f * 1e-3) / 1e9, 1), "frac": round(bytes_fwd / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes": bytes_fwd, "avg_ms": round(ms_f, 5), "launches": n_f}}}
-        if "epi_self_supervision" in ksum:
-            roofline["other"]["self_supervision_kernel"] = {"avg_ms": round(ksum["epi_self_supervision"][1], 5),
-                                                            "launches": ksum["epi_self_supervision"][0],
-                                                            "note": "launch-latency bound at this size (7.5 KB/step)"}
+        hbm = {"softargmax_bwd_kernel (epi_softargmax3d_bwd)": {
+                   "bound": "hbm", "achieved": round(bytes_bwd / (ms_b * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(bytes_bwd / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": bytes_bwd,
+                   "avg_ms": round(ms_b, 5), "launches": n_b},
+               "softargmax_partial+combine (epi_softargmax3d_fwd)": {
+                   "bound": "hbm", "achieved": round(bytes_fwd / (ms_f * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(bytes_fwd / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": bytes_fwd,
+                   "avg_ms": round(ms_f, 5), "launches": n_f}}
+        if head_ms > 0:
+            ach = head_flops / (head_ms * 1e-3) / 1e12
+            roofline = {"kernel": "head_gemm_kernel / head_gemm_tn_kernel (deconvolution head + final 1x1 conv, fwd + bwd-data + "
+                                  "bwd-weight; the hand-written kernels with the largest share of the step)",
+                        "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
+                        "traffic": traffic, "algorithmic_flops_per_step": head_flops, "ms_per_step": round(head_ms, 4),
+                        "entry_points": per_kernel, "other": hbm}
+        else:
+            k = "softargmax_bwd_kernel (epi_softargmax3d_bwd)"
+            roofline = dict(hbm[k], kernel=k, traffic=None, other={kk: v for kk, v in hbm.items() if kk != k})
         line = {
             "metric": "images/sec (4-view 256x256, ResNet-50) at 1/2/4/8 MI355X; MPJPE vs ref",
             "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/s",
