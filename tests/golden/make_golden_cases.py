@@ -8,5 +8,5 @@ INTEGRAL_CASES = [  # name, B, J, D, H, W, logit scale
 ]
 NETWORK_CASES = [  # name, layers, image, J, D, batch
     ("r18", 18, 64, 3, 8, 2),
-    ("r50", 50, 64, 2, 16, 2),
+    ("r50", 50, 128, 2, 16, 4),
 ]
