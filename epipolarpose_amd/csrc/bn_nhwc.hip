@@ -13,28 +13,47 @@
 namespace epi {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_WG = 1024;        // reduction workgroups per tensor: few enough that the 2C fp32 atomics each issues do not contend
 
 enum { BN_MASK_NONE = 0, BN_MASK_FROM_X = 1, BN_MASK_FROM_Y = 2 };
 
-// sums[0..C) += sum x, sums[C..2C) += sum x^2 over the workgroup's row block   (sums zero on entry)
+// Reduction kernels use a 2-D partition: blockIdx.x = 64-channel slab (8 lanes x 16 B = one 128-byte line per row),
+// blockIdx.y = row block.  256 threads = 8 channel groups x 32 row lanes, four rows in flight per lane.  Each workgroup
+// ends with 128 fp32 atomics (64 channels x 2 sums); the partition keeps the total number of atomics per tensor ~64 K
+// whatever the shape (C = 64, R = 524 288 ... C = 2048, R = 2048).
+constexpr int BN_SLAB = 64;                 // channels per slab
+constexpr int BN_RLANES = BN_THREADS / 8;   // 32 row lanes
+
+__device__ __forceinline__ void slab_reduce_and_add(const float (&s)[8], const float (&q)[8], int g, int rl, int slab, int C,
+                                                    float* __restrict__ sums, float* red /* [32][128] */) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[rl * 128 + g * 8 + k] = s[k]; red[rl * 128 + 64 + g * 8 + k] = q[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < BN_RLANES; ++l) t += red[l * 128 + threadIdx.x];
+        const int which = threadIdx.x >> 6, ch = slab * BN_SLAB + (threadIdx.x & 63);
+        if (ch < C) atomicAdd(sums + which * C + ch, t);
+    }
+}
+
+// sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
                                                               int rows_per_wg, float* __restrict__ sums) {
-    extern __shared__ float red[];                 // [rlanes][2][C]
-    const int cg = C >> 3;                          // 8-channel groups per row
-    const int rlanes = BN_THREADS / cg;             // rows processed concurrently by the workgroup
-    const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+    __shared__ float red[BN_RLANES * 128];
+    const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    const int ch0 = slab * BN_SLAB + g * 8;
     float s[8], q[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
-    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
-    if (rl < rlanes) {
+    if (ch0 < C) {
         long long r = r0 + rl;
-        for (; r + 3LL * rlanes < r1; r += 4LL * rlanes) {   // four independent 16-byte loads in flight per lane
+        for (; r + 3LL * BN_RLANES < r1; r += 4LL * BN_RLANES) {
             uint4v raw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4v*>(x + (r + (long long)u * rlanes) * C + g * 8);
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4v*>(x + (r + (long long)u * BN_RLANES) * C + ch0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const unsigned int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
@@ -46,22 +65,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
                 }
             }
         }
-        for (; r < r1; r += rlanes) {
+        for (; r < r1; r += BN_RLANES) {
             float v[8];
-            Elem<unsigned short>::load(x + r * C + g * 8, v);
+            Elem<unsigned short>::load(x + r * C + ch0, v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s[k] += v[k]; q[k] += v[k] * v[k]; }
+            for (int k = 0; k < 8; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { red[(rl * 2 + 0) * C + g * 8 + k] = s[k]; red[(rl * 2 + 1) * C + g * 8 + k] = q[k]; }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) {
-        const int which = c / C, ch = c - which * C;
-        float t = 0.f;
-        for (int l = 0; l < rlanes; ++l) t += red[(l * 2 + which) * C + ch];
-        atomicAdd(sums + c, t);
-    }
+    slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
 }
 
 // Training: mean / rstd from the batch sums, running statistics (momentum, unbiased variance), fused affine
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned sho
     }
 }
 
-// sums[0..C) = sum dz, sums[C..2C) = sum dz * xhat,   dz = dy * mask,   xhat = (x - mean) * rstd
+// sums[0..C) += sum dz, sums[C..2C) += sum dz * xhat,   dz = dy * mask,   xhat = (x - mean) * rstd   (sums zero on entry)
 //   MASK_FROM_X: mask = (x*scale + shift > 0)     MASK_FROM_Y: mask = (y > 0)     MASK_NONE: 1
 template <int MASK>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
@@ -126,19 +137,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    int rows_per_wg, float* __restrict__ sums) {
-    extern __shared__ float red[];
-    const int cg = C >> 3;
-    const int rlanes = BN_THREADS / cg;
-    const int g = threadIdx.x % cg, rl = threadIdx.x / cg;
+    __shared__ float red[BN_RLANES * 128];
+    const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    const int ch0 = slab * BN_SLAB + g * 8;
     float s[8], q[8], sc[8], sh[8], mu[8], rs[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        s[k] = 0.f; q[k] = 0.f;
-        sc[k] = scale[g * 8 + k]; sh[k] = shift[g * 8 + k]; mu[k] = mean[g * 8 + k]; rs[k] = rstd[g * 8 + k];
-    }
-    const long long r0 = (long long)blockIdx.x * rows_per_wg;
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; sc[k] = sh[k] = mu[k] = rs[k] = 0.f; }
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
-    if (rl < rlanes) {
+    if (ch0 < C) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale[ch0 + k]; sh[k] = shift[ch0 + k]; mu[k] = mean[ch0 + k]; rs[k] = rstd[ch0 + k]; }
         auto accum = [&](const float (&xv)[8], const float (&gv)[8], const float (&yv)[8]) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -147,40 +156,32 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
                 if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
                 const float dz = on ? gv[k] : 0.f;
                 s[k] += dz;
-                q[k] += dz * (xv[k] - mu[k]) * rs[k];
+                q[k] = fmaf(dz, (xv[k] - mu[k]) * rs[k], q[k]);
             }
         };
         long long r = r0 + rl;
-        for (; r + rlanes < r1; r += 2LL * rlanes) {        // two rows (4-6 independent 16-byte loads) in flight per lane
+        for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {        // two rows (4-6 independent 16-byte loads) in flight per lane
             float xa[8], ga[8], ya[8], xb[8], gb[8], yb[8];
-            Elem<unsigned short>::load(x + r * C + g * 8, xa);
-            Elem<unsigned short>::load(dy + r * C + g * 8, ga);
-            Elem<unsigned short>::load(x + (r + rlanes) * C + g * 8, xb);
-            Elem<unsigned short>::load(dy + (r + rlanes) * C + g * 8, gb);
+            Elem<unsigned short>::load(x + r * C + ch0, xa);
+            Elem<unsigned short>::load(dy + r * C + ch0, ga);
+            Elem<unsigned short>::load(x + (r + BN_RLANES) * C + ch0, xb);
+            Elem<unsigned short>::load(dy + (r + BN_RLANES) * C + ch0, gb);
             if (MASK == BN_MASK_FROM_Y) {
-                Elem<unsigned short>::load(y + r * C + g * 8, ya);
-                Elem<unsigned short>::load(y + (r + rlanes) * C + g * 8, yb);
+                Elem<unsigned short>::load(y + r * C + ch0, ya);
+                Elem<unsigned short>::load(y + (r + BN_RLANES) * C + ch0, yb);
             }
             accum(xa, ga, ya);
             accum(xb, gb, yb);
         }
-        for (; r < r1; r += rlanes) {
+        for (; r < r1; r += BN_RLANES) {
             float xv[8], gv[8], yv[8];
-            Elem<unsigned short>::load(x + r * C + g * 8, xv);
-            Elem<unsigned short>::load(dy + r * C + g * 8, gv);
-            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + g * 8, yv);
+            Elem<unsigned short>::load(x + r * C + ch0, xv);
+            Elem<unsigned short>::load(dy + r * C + ch0, gv);
+            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + ch0, yv);
             accum(xv, gv, yv);
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { red[(rl * 2 + 0) * C + g * 8 + k] = s[k]; red[(rl * 2 + 1) * C + g * 8 + k] = q[k]; }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) {
-        const int which = c / C, ch = c - which * C;
-        float t = 0.f;
-        for (int l = 0; l < rlanes; ++l) t += red[(l * 2 + which) * C + ch];
-        atomicAdd(sums + c, t);
-    }
+    slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
 }
 
 // dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  dres = dz (residual branch gradient) when requested
@@ -215,19 +216,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
     }
 }
 
-static inline bool bn_shape_ok(long long R, int C) { return R > 0 && C > 0 && C % 8 == 0 && (C >> 3) <= BN_THREADS; }
+static inline bool bn_shape_ok(long long R, int C) { return R > 0 && C > 0 && C % 8 == 0 && R < (1LL << 40); }
 static inline unsigned stream_grid(long long nvec) {
     const long long want = (nvec + BN_THREADS - 1) / BN_THREADS;
     return (unsigned)(want < 8192 ? want : 8192);
 }
-// row blocking of the reduction kernels: at most BN_MAX_WG workgroups, each at least one pass of its row lanes
-static inline void reduce_blocking(long long R, int C, int* rows_per_wg, int* nwg) {
-    const int rlanes = BN_THREADS / (C >> 3);
-    long long rpw = (R + BN_MAX_WG - 1) / BN_MAX_WG;
-    const long long min_rows = 4LL * rlanes;
-    if (rpw < min_rows) rpw = min_rows;
+// 2-D blocking of the reduction kernels: nslab x nrb workgroups, ~512-1024 in total, >= 128 rows each
+static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* grid) {
+    const int nslab = (C + BN_SLAB - 1) / BN_SLAB;
+    long long nrb = (nslab >= 2 ? 1024 : 512) / nslab;
+    const long long max_rb = (R + 127) / 128;
+    if (nrb > max_rb) nrb = max_rb;
+    if (nrb < 1) nrb = 1;
+    long long rpw = (R + nrb - 1) / nrb;
+    rpw = (rpw + BN_RLANES - 1) / BN_RLANES * BN_RLANES;
+    nrb = (R + rpw - 1) / rpw;
     *rows_per_wg = (int)rpw;
-    *nwg = (int)((R + rpw - 1) / rpw);
+    *grid = dim3((unsigned)nslab, (unsigned)nrb);
 }
 
 }  // namespace epi
@@ -245,11 +250,10 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (training) {
-        int rpw = 0, nwg = 0;
-        reduce_blocking(R, C, &rpw, &nwg);
-        const int rlanes = BN_THREADS / (C >> 3);
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                           (const unsigned short*)x, R, C, rpw, sums_ws);
+        int rpw = 0;
+        dim3 rgrid;
+        reduce_blocking(R, C, &rpw, &rgrid);
+        hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws);
         EPI_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
@@ -275,14 +279,13 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    int rpw = 0, nwg = 0;
-    reduce_blocking(R, C, &rpw, &nwg);
-    const int rlanes = BN_THREADS / (C >> 3);
-    const size_t lds = (size_t)rlanes * 2 * C * sizeof(float);
+    int rpw = 0;
+    dim3 rgrid;
+    reduce_blocking(R, C, &rpw, &rgrid);
     const int mask = !relu ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x, *ys = (const unsigned short*)y;
     const float *sc = scale_shift, *sh = scale_shift + C;
-#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), dim3(nwg), dim3(BN_THREADS), lds, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
+#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
     if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
     else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
     else EPI_BN_RED(BN_MASK_FROM_Y);
@@ -306,11 +309,10 @@ extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* su
     if (!x || !sums) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    int rpw = 0, nwg = 0;
-    reduce_blocking(R, C, &rpw, &nwg);
-    const int rlanes = BN_THREADS / (C >> 3);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nwg), dim3(BN_THREADS), (size_t)rlanes * 2 * C * sizeof(float), st,
-                       (const unsigned short*)x, R, C, rpw, sums);
+    int rpw = 0;
+    dim3 rgrid;
+    reduce_blocking(R, C, &rpw, &rgrid);
+    hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
