@@ -158,7 +158,7 @@ def main():
     grad_sync = None
     if world > 1:
         epd.broadcast_module(model)
-        grad_sync = epd.BucketedGradSync(model)
+        grad_sync = epd.BucketedGradSync(model, optimizer=optimizer)
     n_view = args.views if args.workload == "ss" else None
     # 4-view SS uses the V-view generalisation of the reference's iterative LS solver (V=2 is the reference itself)
 

@@ -52,16 +52,20 @@ class BucketedGradSync:
     ``finish()`` waits for all of them and applies the 1/world scale.
     """
 
-    def __init__(self, module, bucket_bytes=64 << 20, grad_dtype=None):
+    def __init__(self, module, bucket_bytes=64 << 20, grad_dtype=None, optimizer=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
+        copies = optimizer.training_copies() if hasattr(optimizer, "training_copies") else {}
+        if copies:      # convolution weights trained through bf16 copies: their gradients live on the copies (bf16:
+            # half the xGMI traffic); same parameter order as the optimizer's
+            self.params = [copies.get(i, p) for i, p in enumerate(self.params)]
         self.buckets = []          # (flat tensor, [params])
         self._pending = {}
         self._handles = []
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * (grad_dtype or p.dtype).itemsize
-            if cur and cur_bytes + nbytes > bucket_bytes:
+            if cur and (cur_bytes + nbytes > bucket_bytes or (grad_dtype is None and p.dtype != cur[0].dtype)):
                 self._make_bucket(cur, grad_dtype)
                 cur, cur_bytes = [], 0
             cur.append(p)

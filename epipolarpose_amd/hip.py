@@ -51,6 +51,9 @@ _SIGNATURES = {
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
+    "epi_adam_tensor_bytes": (_sz, []),
+    "epi_adam_chunk_elems": (_i, []),
+    "epi_adam_step": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -525,3 +528,11 @@ def column_sum_bf16(x):
     with _on(x.device):
         _check(lib.epi_column_sums_bf16(_ptr(x), r, c, _ptr(sums), _stream()), "epi_column_sums_bf16")
     return sums[:c]
+
+
+def adam_step(table_dev, chunks_dev, nchunks, lr, beta1, beta2, eps, step):
+    """One fused Adam update over every tensor described by the device-resident table (see optim.FusedAdam)."""
+    lib = load()
+    ev = timer.start("epi_adam_step")
+    _check(lib.epi_adam_step(_ptr(table_dev), _ptr(chunks_dev), nchunks, lr, beta1, beta2, eps, step, _stream()), "epi_adam_step")
+    timer.stop(ev)

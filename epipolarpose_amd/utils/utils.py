@@ -28,13 +28,19 @@ def create_logger(cfg, cfg_name, phase='train'):
     return logger, str(out_dir)
 
 
-def get_optimizer(cfg, model, capturable=False):
+def get_optimizer(cfg, model, capturable=False, fused=True):
     """utils.py:45-61.  Adam takes only the learning rate (the reference ignores TRAIN.WD for Adam).
-    ``capturable=True`` keeps Adam's step counter on the device so the step can live inside a hipGraph."""
+    On the GPU the default is ``epipolarpose_amd.optim.FusedAdam`` (same arithmetic, one launch, bf16 training copies
+    of the MIOpen convolution weights); ``fused=False`` or ``capturable=True`` (hipGraph capture keeps Adam's step
+    counter on the device) selects ``torch.optim.Adam``."""
     if cfg.TRAIN.OPTIMIZER == 'sgd':
         return optim.SGD(model.parameters(), lr=cfg.TRAIN.LR, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WD,
                          nesterov=cfg.TRAIN.NESTEROV)
     if cfg.TRAIN.OPTIMIZER == 'adam':
+        params = [p for p in model.parameters() if p.requires_grad]
+        if fused and not capturable and params and all(p.is_cuda for p in params):
+            from ..optim import FusedAdam
+            return FusedAdam(model, lr=cfg.TRAIN.LR)
         return optim.Adam(model.parameters(), lr=cfg.TRAIN.LR, capturable=capturable)
     return None
 

@@ -202,6 +202,20 @@ int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, in
                                void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-tensor Adam -- replaces torch.optim.Adam as built by lib/utils/utils.py:55-59 (lr only, betas
+ * (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), one launch for all parameters.
+ *   table  : device array of rows {float* p; const void* g; float* m; float* v; uint16* shadow; int64 n; int32
+ *            g_bf16; int32 pad} (epi_adam_tensor_bytes() bytes each).  g is bf16 when g_bf16 != 0, else f32;
+ *            shadow (or NULL) receives the bf16 copy of the updated parameter.
+ *   chunks : device array of int32 pairs (tensor index, chunk index), chunk = epi_adam_chunk_elems() elements.
+ *   step   : 1-based step count (bias correction is computed on the host from it).
+ * ------------------------------------------------------------------------------------------------ */
+size_t epi_adam_tensor_bytes(void);
+int epi_adam_chunk_elems(void);
+int epi_adam_step(const void* table, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                  long long step, epi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

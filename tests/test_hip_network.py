@@ -108,3 +108,36 @@ def test_training_reduces_loss_and_ss_step_runs():
     meta = DeviceMeta(sc.meta, dev)
     l_ss = train_step(model, crit, opt, x, None, None, meta=meta, n_view=2)
     assert torch.isfinite(l_ss)
+
+
+def test_fused_adam_matches_torch_adam():
+    """Same arithmetic as torch.optim.Adam: fp32 path to 1e-6; the bf16-training-copy path tracks it to bf16 precision."""
+    import copy
+    import torch.nn as nn
+    from epipolarpose_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    base = nn.Sequential(nn.Conv2d(8, 16, 3, padding=1, bias=False), nn.ReLU(), nn.Conv2d(16, 8, 1, bias=True), nn.Flatten(),
+                         nn.Linear(8 * 6 * 5, 7)).to(dev).to(memory_format=torch.channels_last)
+    x, y = torch.randn(4, 8, 6, 5, device=dev), torch.randn(4, 7, device=dev)
+
+    def run(opt_factory, steps=4):
+        m = copy.deepcopy(base)
+        opt = opt_factory(m)
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            ((m(x).float() - y) ** 2).mean().backward()
+            opt.step()
+        return [p.detach().float().clone() for p in m.parameters()], opt
+    ref, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-2))
+    got, _ = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=False))
+    for a, b in zip(got, ref):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
+    got_lp, opt = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=True))
+    assert len(opt.training_copies()) == 1                  # only the bias-free conv trains through a bf16 copy
+    for a, b in zip(got_lp, ref):
+        torch.testing.assert_close(a, b, rtol=5e-2, atol=2e-2)
+    for i, lp in opt.training_copies().items():             # copy == bf16(master), same layout
+        assert torch.equal(lp.detach().float(), opt._params[i].detach().to(torch.bfloat16).float())
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
