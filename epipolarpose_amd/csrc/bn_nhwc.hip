@@ -81,10 +81,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
 __global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long long* __restrict__ num_batches, float* __restrict__ mean,
-                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ bwd_sums) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && num_batches && sums) num_batches[0] += 1;
     if (c >= C) return;
+    if (bwd_sums) { bwd_sums[c] = 0.f; bwd_sums[C + c] = 0.f; }     // accumulator of this layer's NEXT backward pass
     double m, var;
     if (sums) {
         m = (double)sums[c] / (double)R;
@@ -241,8 +243,8 @@ using namespace epi;
 
 extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                               float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws, void* y,
-                              epi_stream_t stream) {
+                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
+                              float* bwd_sums, void* y, epi_stream_t stream) {
     if (!x || !gamma || !beta || !scale_shift || !y) return EPI_ERR_INVALID_ARGUMENT;
     if (training && (!mean || !rstd || !sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
     if (!training && (!running_mean || !running_var)) return EPI_ERR_INVALID_ARGUMENT;
@@ -257,7 +259,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
         EPI_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
-                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C);
+                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C, bwd_sums);
     EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);

@@ -7,9 +7,10 @@
 //     2x2-tap gather GEMM with K = 4*Cin;
 //   * its backward-data = a 4x4 stride-2 gather GEMM with K = 16*Cout;
 //   * the final 1x1 convolution (pose3d_resnet.py:116-122) forward / backward-data = plain GEMMs.
-// Tile 128x128x64, 256 threads (2x2 waves, each 2x2 MFMA 32x32 tiles), register-staged global->LDS with the next
-// K tile's loads in flight during the MFMAs, double-buffered LDS (64 KiB -> 2 workgroups / CU), XOR-swizzled
-// 16-byte chunks so both the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups are conflict-free.
+// Tile 128x128x64, 256 threads (2x2 waves, each 2x2 MFMA 32x32 tiles), global->LDS by direct DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) with the next K tile's DMA in flight during the
+// MFMAs, double-buffered LDS (64 KiB -> 2 workgroups / CU), 16-byte chunks XOR-swizzled on the SOURCE address so the
+// lane-linear DMA image is conflict-free for the 16-lane ds_read_b128 groups.
 #include "common.h"
 
 namespace epi {
@@ -48,6 +49,16 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// 16 zero bytes in global memory: the source of every out-of-range / padding chunk of a direct-to-LDS load
+__device__ uint4v epi_zero_chunk[1];
+
+// global -> LDS DMA (global_load_lds_dwordx4): each lane supplies its own 16-byte global source; the 64 lanes of the wave
+// land contiguously at lds_base + 16*lane (lds_base must be wave-uniform).  No VGPR round trip, no ds_write pass.
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
 template <bool OUT_F32>
 __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
@@ -62,14 +73,18 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     const int k_begin = blockIdx.y * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
 
-    // ---- staging roles: thread t moves chunk (t & 7) of rows (t >> 3) + 32*pass of both tiles ----
-    const int srow = tid >> 3, schunk = tid & 7;
+    // ---- staging roles (direct-to-LDS): wave w, instruction ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear);
+    //      lane l lands at row 32*w + 8*ps + (l >> 3), PHYSICAL chunk l & 7, so it fetches the LOGICAL chunk
+    //      (l & 7) ^ f(row) of that row from global memory (the XOR swizzle is applied on the source side) ----
+    const int srow = wid * 32 + (lane >> 3), schunk_phys = lane & 7;
     long long a_base[4];
-    int a_iy[4], a_jx[4];
+    int a_iy[4], a_jx[4], s_chunk[4];
     bool a_ok[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-        const int m = m0 + ps * 32 + srow;
+        const int trow = srow + ps * 8;
+        s_chunk[ps] = schunk_phys ^ ((trow >> 1) & 7);
+        const int m = m0 + trow;
         a_ok[ps] = m < p.M;
         if (p.ga.enabled) {
             const int hw = p.ga.Hg * p.ga.Wg;
@@ -83,39 +98,34 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
             a_base[ps] = (long long)m * p.lda;
         }
     }
-    uint4v ra[4], rb[4];
-    auto load_tiles = [&](int k0) {
+    const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
+    auto load_tiles = [&](int k0, int buf) {
         int tap = 0, c0 = k0;
         if (p.ga.enabled) { tap = k0 / p.ga.Cs; c0 = k0 - tap * p.ga.Cs; }
+        char* a_s = smem + buf * 2 * TILE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
+        char* b_s = a_s + TILE_BYTES;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             bool ok = a_ok[ps];
             long long off;
+            const int kc = k0 + s_chunk[ps] * 8;
             if (p.ga.enabled) {
                 // ConvTranspose phases: oh = 2*ih - 1 + kh, so tap (ty, tx) of phase (ph, pw) reads (i + ph - ty, j + pw - tx)
                 const int tdy = p.deconv_phases ? ph - (tap >> 1) : p.ga.dy[tap];
                 const int tdx = p.deconv_phases ? pw - (tap & 1) : p.ga.dx[tap];
                 const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
                 ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
-                off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + schunk * 8;
+                off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + s_chunk[ps] * 8;
             } else {
-                off = a_base[ps] + k0 + schunk * 8;
+                off = a_base[ps] + kc;
             }
-            const bool kok = k0 + schunk * 8 < k_end;           // K tail (K % 8 == 0): zero-filled chunks
-            uint4v z; z.x = z.y = z.z = z.w = 0u;
-            ra[ps] = (ok && kok) ? *reinterpret_cast<const uint4v*>(p.A + off) : z;
-            const int n = n0 + ps * 32 + srow;
-            rb[ps] = (n < p.N && kok) ? *reinterpret_cast<const uint4v*>(Bt + (long long)n * p.ldb + k0 + schunk * 8) : z;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* a_s = smem + buf * 2 * TILE_BYTES;
-        char* b_s = a_s + TILE_BYTES;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int o = lds_off(ps * 32 + srow, schunk);
-            *reinterpret_cast<uint4v*>(a_s + o) = ra[ps];
-            *reinterpret_cast<uint4v*>(b_s + o) = rb[ps];
+            const bool kok = kc < k_end;             // K tail (K % 8 == 0): zero-filled chunks
+            const void* asrc = (ok && kok) ? reinterpret_cast<const void*>(p.A + off) : reinterpret_cast<const void*>(zero_src);
+            glds16(asrc, a_s + ps * 1024);
+            const int n = n0 + srow + ps * 8;
+            const void* bsrc = (n < p.N && kok) ? reinterpret_cast<const void*>(Bt + (long long)n * p.ldb + kc)
+                                                : reinterpret_cast<const void*>(zero_src);
+            glds16(bsrc, b_s + ps * 1024);
         }
     };
 
@@ -128,13 +138,12 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + GBK - 1) / GBK;
-    load_tiles(k_begin);
-    store_tiles(0);
-    __syncthreads();
+    load_tiles(k_begin, 0);
+    __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
     const int frow = lane & 31, fhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * GBK);
+        if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * GBK, buf ^ 1);   // next tile's DMA flies during the MFMAs
         const char* a_s = smem + buf * 2 * TILE_BYTES;
         const char* b_s = a_s + TILE_BYTES;
 #pragma unroll
@@ -155,7 +164,6 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[tj], af[ti], acc[ti][tj], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
     }
 

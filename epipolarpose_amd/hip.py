@@ -45,7 +45,7 @@ _SIGNATURES = {
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
-                            _vp, _vp, _vp, _vp, _vp]),
+                            _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
@@ -444,8 +444,8 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     return dx
 
 
-def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, training, momentum, eps,
-               relu):
+def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, bwd_sums, training, momentum,
+               eps, relu):
     """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last).
     -> (y, mean, rstd, scale_shift); mean/rstd are None in inference."""
     lib = load()
@@ -463,18 +463,21 @@ def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_
     with _on(dev):
         _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
                                   int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
-                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(y), _stream()), "epi_bn_act_fwd")
+                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(bwd_sums if training else None), _ptr(y),
+                                  _stream()), "epi_bn_act_fwd")
     return y, mean, rstd, scale_shift
 
 
-def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres):
-    """-> (dx, dres or None, dgamma, dbeta)."""
+def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres, sums=None):
+    """-> (dx, dres or None, dgamma, dbeta).  ``sums``: a zeroed [2C] f32 accumulator (the layer's ``bwd_sums``, cleared by
+    its forward pass); a fresh one is allocated when omitted."""
     lib = load()
     dy = _nhwc_bf16(dy, "dy")
     b, c, h, w = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
+    if sums is None:
+        sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
     with _on(x.device):
         _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
                                   int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")

@@ -24,8 +24,8 @@ class _BNActFunction(torch.autograd.Function):
         training = module.training
         y, mean, rstd, scale_shift = hip.bn_act_fwd(
             x, residual, weight, bias, module.running_mean, module.running_var, module.num_batches_tracked,
-            module.sums_ws, training, module.momentum, module.eps, relu)
-        ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
+            module.sums_ws, module.bwd_sums, training, module.momentum, module.eps, relu)
+        ctx.relu, ctx.has_res, ctx.training, ctx.module = relu, residual is not None, training, module
         if training:
             ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, rstd, scale_shift)
         return y
@@ -35,7 +35,9 @@ class _BNActFunction(torch.autograd.Function):
         if not ctx.training:
             raise RuntimeError("FusedBatchNormAct: backward through inference-mode statistics is not supported")
         x, y, weight, mean, rstd, scale_shift = ctx.saved_tensors
-        dx, dres, dgamma, dbeta = hip.bn_act_bwd(dy, x, y, weight, mean, rstd, scale_shift, ctx.relu, ctx.has_res)
+        # bwd_sums was cleared by this layer's forward pass (one backward per forward: the training loop's pattern)
+        dx, dres, dgamma, dbeta = hip.bn_act_bwd(dy, x, y, weight, mean, rstd, scale_shift, ctx.relu, ctx.has_res,
+                                                 sums=ctx.module.bwd_sums)
         return dx, dgamma, dbeta, dres, None, None
 
 
@@ -52,6 +54,7 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
+        self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
 
     def forward(self, x, residual=None):
         x = _nhwc_bf16(x)

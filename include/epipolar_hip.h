@@ -179,13 +179,15 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  *                    layer: graph replays then need no memset)
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
  *                    num_batches_tracked += 1;   training == 0: running statistics.
+ *   bwd_sums       : [2C] f32 or NULL: zeroed by the forward so that it can serve as `dbeta_dgamma` of this
+ *                    layer's next backward pass without a separate memset
  * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
  *   = gradient of the residual input;  y = saved forward output, required when relu && dres.
  * ------------------------------------------------------------------------------------------------ */
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
                    long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
-                   void* y, epi_stream_t stream);
+                   float* bwd_sums, void* y, epi_stream_t stream);
 int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma,
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, epi_stream_t stream);

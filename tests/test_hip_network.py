@@ -121,19 +121,21 @@ def test_fused_adam_matches_torch_adam():
                          nn.Linear(8 * 6 * 5, 7)).to(dev).to(memory_format=torch.channels_last)
     x, y = torch.randn(4, 8, 6, 5, device=dev), torch.randn(4, 7, device=dev)
 
-    def run(opt_factory, steps=4):
+    def run(opt_factory, steps=4, autocast=False):
         m = copy.deepcopy(base)
         opt = opt_factory(m)
         for _ in range(steps):
             opt.zero_grad(set_to_none=True)
-            ((m(x).float() - y) ** 2).mean().backward()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                out = m(x)
+            ((out.float() - y) ** 2).mean().backward()
             opt.step()
         return [p.detach().float().clone() for p in m.parameters()], opt
     ref, _ = run(lambda m: torch.optim.Adam(m.parameters(), lr=1e-2))
     got, _ = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=False))
     for a, b in zip(got, ref):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
-    got_lp, opt = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=True))
+    got_lp, opt = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=True), autocast=True)
     assert len(opt.training_copies()) == 1                  # only the bias-free conv trains through a bf16 copy
     for a, b in zip(got_lp, ref):
         torch.testing.assert_close(a, b, rtol=5e-2, atol=2e-2)
