@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--fp32", action="store_true", help="disable bf16 autocast (diagnostic; not the bench line)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as one hipGraph (N=1 only); 0: eager (default: "
                     "the step is GPU-bound and hipGraph replay measured 6 %% slower than eager launches on ROCm 7.2)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + --same-device lets "
+                    "the N>1 code path be exercised on a single-GPU box")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (functional testing only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
@@ -143,7 +146,11 @@ def main():
     from epipolarpose_amd import hip
     from epipolarpose_amd.core.function import GraphedTrainStep, train_step
 
-    rank, world, local = epd.init_from_env()
+    if args.same_device:
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    rank, world, local = epd.init_from_env(backend=args.backend, set_device=not args.same_device)
+    if args.same_device:
+        local = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
                          % (args.gpus, world, args.gpus))
