@@ -137,8 +137,11 @@ def test_fused_adam_matches_torch_adam():
         torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6)
     got_lp, opt = run(lambda m: FusedAdam(m, lr=1e-2, low_precision_convs=True), autocast=True)
     assert len(opt.training_copies()) == 1                  # only the bias-free conv trains through a bf16 copy
+    # Adam moves every weight by ~lr per step whatever the gradient's size, so a bf16-rounded gradient near zero can flip
+    # a step's sign: elementwise the two runs may differ by up to 2*steps*lr, but on average they agree closely
     for a, b in zip(got_lp, ref):
-        torch.testing.assert_close(a, b, rtol=5e-2, atol=2e-2)
+        assert (a - b).abs().max().item() <= 2 * 4 * 1e-2 + 1e-3
+        assert (a - b).abs().mean().item() <= 1e-2
     for i, lp in opt.training_copies().items():             # copy == bf16(master), same layout
         assert torch.equal(lp.detach().float(), opt._params[i].detach().to(torch.bfloat16).float())
     sd = opt.state_dict()
