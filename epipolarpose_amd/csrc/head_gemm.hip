@@ -49,6 +49,15 @@ struct GemmArgs {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// XCD-aware workgroup order (8 XCDs, each with a private 4 MiB L2; the dispatcher is observed to place linear workgroup
+// id b on XCD b % 8).  The bijective remap gives every XCD a CONTIGUOUS range of logical ids, so tiles that share an
+// operand panel (consecutive logical ids) hit the same L2 instead of re-fetching the panel from HBM on 8 different XCDs
+// (PMC: the final 1x1 conv read A 8.8x before this remap).  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // 16 zero bytes in global memory: the source of every out-of-range / padding chunk of a direct-to-LDS load
 __device__ uint4v epi_zero_chunk[1];
 
@@ -65,12 +74,18 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_n = (p.N + GBN - 1) / GBN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    // logical id: tile_n fastest, then tile_m, then split, then phase -> neighbours share the A panel (and B)
+    const int total_wg = gridDim.x * gridDim.y * gridDim.z;
+    int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total_wg);
+    const int tile_id = lid % (int)gridDim.x;
+    lid /= (int)gridDim.x;
+    const int split_id = lid % (int)gridDim.y, phase = lid / (int)gridDim.y;
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
-    const int phase = blockIdx.z, ph = phase >> 1, pw = phase & 1;
+    const int ph = phase >> 1, pw = phase & 1;
     const unsigned short* Bt = p.Bt + (p.deconv_phases ? (long long)phase * p.N * p.ldb : 0);
     const int sc_oy = p.deconv_phases ? ph : p.sc.oy, sc_ox = p.deconv_phases ? pw : p.sc.ox;
-    const int k_begin = blockIdx.y * p.k_per_split;
+    const int k_begin = split_id * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
 
     // ---- staging roles (direct-to-LDS): wave w, instruction ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear);
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*64 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
     if (gridDim.y > 1) {        // split-K partial: fp32, plain rows, finished by splitk_finish_kernel
-        float* slab = p.slabs + ((long long)blockIdx.y * gridDim.z + phase) * p.M * p.N;
+        float* slab = p.slabs + ((long long)split_id * gridDim.z + phase) * p.M * p.N;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int m = m0 + wm * 64 + ti * 32 + frow;
@@ -429,9 +444,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_tn_kernel(GemmTnArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_j = (p.J + GBN - 1) / GBN;
-    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    // logical id: tile fastest, then split, then tap: the tiles of one split (same rows r) stay on one XCD
+    const int total_wg = gridDim.x * gridDim.y * gridDim.z;
+    int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total_wg);
+    const int tile_id = lid % (int)gridDim.x;
+    lid /= (int)gridDim.x;
+    const int split = lid % (int)gridDim.y, tap = lid / (int)gridDim.y;
+    const int tile_i = tile_id / tiles_j, tile_j = tile_id - tile_i * tiles_j;
     const int i0 = tile_i * GBM, j0 = tile_j * GBN;
-    const int split = blockIdx.y, tap = blockIdx.z;
     const int r_begin = split * p.rows_per_split;
     const int r_end = min(p.R, r_begin + p.rows_per_split);
 
