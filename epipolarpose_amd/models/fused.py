@@ -100,11 +100,14 @@ class _Conv1x1Function(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         b, cin, h, w = x.shape
         cout = weight.shape[0]
-        w2 = weight.detach().reshape(cout, cin).to(torch.bfloat16)
+        w2 = weight.detach().reshape(cout, cin)
+        if w2.dtype != torch.bfloat16:
+            w2 = w2.to(torch.bfloat16)
         x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, cin)          # NHWC view, no copy
         out = hip.gemm_bf16(x2, w2, bias=None if bias is None else bias.detach().float())
         ctx.save_for_backward(x, w2)
         ctx.has_bias = bias is not None
+        ctx.lp = weight.dtype == torch.bfloat16
         return out.reshape(b, h, w, cout).permute(0, 3, 1, 2)       # logical NCHW, NHWC memory
 
     @staticmethod
@@ -119,22 +122,32 @@ class _Conv1x1Function(torch.autograd.Function):
             dx = hip.gemm_bf16(dy2, w2.t().contiguous()).reshape(b, h, w, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = hip.gemm_tn_bf16(dy2, x2).reshape(cout, cin, 1, 1)
+            if ctx.lp:
+                dw = dw.to(torch.bfloat16)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = hip.column_sum_bf16(dy2)
         return dx, dw, db
 
 
 class Conv1x1(nn.Module):
-    """1x1 convolution with bias; weight [Cout, Cin, 1, 1] as ``nn.Conv2d`` (pose3d_resnet.py:116-122)."""
+    """1x1 stride-1 convolution as an MFMA GEMM; weight [Cout, Cin, 1, 1] (+ bias [Cout]) named as in ``nn.Conv2d``
+    (final layer: pose3d_resnet.py:116-122; bottleneck conv1/conv3: :56,61).  When an optimizer installs a bf16 training
+    copy (``weight_lp``, see optim.FusedAdam) the forward reads it instead of casting the fp32 master every step."""
 
-    def __init__(self, in_channels, out_channels):
+    supports_training_copy = True
+
+    def __init__(self, in_channels, out_channels, bias=True):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
-        self.bias = nn.Parameter(torch.empty(out_channels))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.Conv2d default initialisation
-        bound = 1.0 / in_channels ** 0.5
-        nn.init.uniform_(self.bias, -bound, bound)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+            bound = 1.0 / in_channels ** 0.5
+            nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter("bias", None)
 
     def forward(self, x):
-        return _Conv1x1Function.apply(_nhwc_bf16(x), self.weight, self.bias)
+        w = getattr(self, "weight_lp", None)
+        return _Conv1x1Function.apply(_nhwc_bf16(x), self.weight if w is None else w, self.bias)

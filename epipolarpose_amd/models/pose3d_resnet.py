@@ -21,6 +21,7 @@ import torch.nn as nn
 from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct
 
 BN_MOMENTUM = 0.1
+MFMA_1X1_CONVS = os.environ.get("EPI_MFMA_1X1", "1") != "0"     # bottleneck 1x1 stride-1 convs on the hand-written GEMM
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -42,8 +43,12 @@ class ResidualUnit(nn.Module):
         cin = inplanes
         for i, (k, mult, strided) in enumerate(plan, start=1):
             cout = planes * mult
-            setattr(self, "conv%d" % i, nn.Conv2d(cin, cout, kernel_size=k, stride=stride if strided else 1,
-                                                  padding=k // 2, bias=False))
+            s_i = stride if strided else 1
+            if k == 1 and s_i == 1 and cin % 8 == 0 and cout % 8 == 0 and MFMA_1X1_CONVS:
+                conv = Conv1x1(cin, cout, bias=False)            # plain GEMM [B*H*W, Cin] x [Cin, Cout] on the MFMA kernel
+            else:
+                conv = nn.Conv2d(cin, cout, kernel_size=k, stride=s_i, padding=k // 2, bias=False)
+            setattr(self, "conv%d" % i, conv)
             setattr(self, "bn%d" % i, FusedBatchNormAct(cout, momentum=BN_MOMENTUM, relu=True))
             cin = cout
         self.out_planes = cin

@@ -36,7 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
             params = [p for p in model_or_params.parameters() if p.requires_grad]
             if low_precision_convs:
                 lp_modules = [m for m in model_or_params.modules()
-                              if type(m) is nn.Conv2d and m.bias is None and m.weight.is_cuda and m.weight.requires_grad]
+                              if (type(m) is nn.Conv2d or getattr(m, "supports_training_copy", False)) and m.bias is None
+                              and m.weight.is_cuda and m.weight.requires_grad]
         else:
             params = [p for p in model_or_params if p.requires_grad]
         if not params or not all(p.is_cuda and p.dtype == torch.float32 and _dense(p) for p in params):
@@ -62,7 +63,8 @@ class FusedAdam(torch.optim.Optimizer):
             lp.copy_(w.detach())
             lp.requires_grad_(True)
             object.__setattr__(m, "weight_lp", lp)
-            m.forward = types.MethodType(_lp_conv_forward, m)
+            if type(m) is nn.Conv2d:
+                m.forward = types.MethodType(_lp_conv_forward, m)
             self._lp_of[idx] = lp
         # two pinned staging copies of the table: the host may run a step ahead of the asynchronous upload
         self._table_hosts = [torch.zeros(len(params) * _ROW, dtype=torch.int64).pin_memory() for _ in range(2)]

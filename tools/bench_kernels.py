@@ -56,6 +56,34 @@ def bench_gemm():
             m, n, k, t, fl / t / 1e9, fl / t / 1e9 / MFMA, tt, fl / tt / 1e9), flush=True)
 
 
+def bench_conv1x1():
+    """ResNet-50 bottleneck 1x1 convolutions at B=32: our GEMM entry points vs MIOpen through torch (fwd, bwd-data, bwd-weight)."""
+    import torch.nn.functional as F
+    for hw, cin, cout in ((64, 64, 256), (64, 256, 64), (32, 512, 128), (32, 128, 512), (16, 1024, 256), (16, 256, 1024),
+                          (8, 2048, 512), (8, 512, 2048)):
+        b = 32
+        m = b * hw * hw
+        x = torch.randn(b, cin, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, 1, 1, device=DEV) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(b, cout, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        x2 = x.permute(0, 2, 3, 1).reshape(m, cin)
+        dy2 = dy.permute(0, 2, 3, 1).reshape(m, cout)
+        w2 = w.reshape(cout, cin)
+        w2t = w2.t().contiguous()
+        fl = 2.0 * m * cin * cout
+        t_f = timeit(lambda: hip.gemm_bf16(x2, w2))
+        t_b = timeit(lambda: hip.gemm_bf16(dy2, w2t))
+        t_w = timeit(lambda: hip.gemm_tn_bf16(dy2, x2))
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        s_f = timeit(lambda: F.conv2d(xr, wr))
+        y = F.conv2d(xr, wr)
+        s_b = timeit(lambda: torch.autograd.grad(y, xr, dy, retain_graph=True))
+        s_w = timeit(lambda: torch.autograd.grad(y, wr, dy, retain_graph=True))
+        print("conv1x1 %3dx%-3d %4d->%-4d fwd ours %.4f (%5.0f TF) MIOpen %.4f | bwd-data ours %.4f MIOpen %.4f | bwd-w ours %.4f MIOpen %.4f ms" % (
+            hw, hw, cin, cout, t_f, fl / t_f / 1e9, s_f, t_b, s_b, t_w, s_w), flush=True)
+
+
 def bench_deconv():
     import torch.nn.functional as F
     for b, h, cin, cout in ((32, 8, 2048, 256), (32, 16, 256, 256), (32, 32, 256, 256)):
