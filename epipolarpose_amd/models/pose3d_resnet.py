@@ -21,7 +21,10 @@ import torch.nn as nn
 from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct
 
 BN_MOMENTUM = 0.1
-MFMA_1X1_CONVS = os.environ.get("EPI_MFMA_1X1", "1") != "0"     # bottleneck 1x1 stride-1 convs on the hand-written GEMM
+# Experimental: bottleneck 1x1 stride-1 convolutions on the hand-written GEMM instead of MIOpen.  Measured round 1
+# (B=32): 14.4 ms/step vs 9.8 ms with MIOpen -- at these small shapes the per-call host cost and the extra weight
+# transposes outweigh the kernel gain -- so it is OFF unless EPI_MFMA_1X1=1.
+MFMA_1X1_CONVS = os.environ.get("EPI_MFMA_1X1", "0") == "1"
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
