@@ -193,6 +193,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_elapsed = time.perf_counter() - t0          # host-side enqueue time (diagnostic: how far the CPU runs ahead)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -284,7 +285,8 @@ def main():
                                     "batch=%d/GPU") % (args.layers, args.image, args.image, args.batch),
                        "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
                        "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6),
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
