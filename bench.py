@@ -186,6 +186,10 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    th = time.perf_counter()
+    step()                                           # diagnostic (untimed, part of warm-up): host cost of enqueueing ONE step
+    host_one = time.perf_counter() - th              # into an empty queue, i.e. without back-pressure from the GPU
+    torch.cuda.synchronize()
     barrier()
     hip.timer.reset()
     hip.timer.enabled = not use_graph            # events cannot be recorded inside a replayed graph
@@ -286,7 +290,8 @@ def main():
                        "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
                        "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6),
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3)},
+                       "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
+                       "host_enqueue_ms_one_step_empty_queue": round(host_one * 1e3, 3)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
