@@ -122,8 +122,8 @@ def _stream(device_index=None):
     """Raw hipStream_t of torch's current stream.  The fast private accessor keeps the per-call Python overhead low
     (hundreds of launches per step); it follows stream switches (side streams, graph capture) like the public API."""
     if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if device_index is None else device_index))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
+    return torch.cuda.current_stream().cuda_stream
 
 
 class _NoCtx:
@@ -153,7 +153,8 @@ def _dev(t, dtype=None, name="tensor"):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Device address as a plain int (ctypes converts it for c_void_p parameters; None -> NULL)."""
+    return t.data_ptr() if t is not None else None
 
 
 def _logits_format(logits):
@@ -444,44 +445,42 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     return dx
 
 
-def bn_act_fwd(x, residual, gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, bwd_sums, training, momentum,
-               eps, relu):
-    """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last).
-    -> (y, mean, rstd, scale_shift); mean/rstd are None in inference."""
-    lib = load()
-    x = _nhwc_bf16(x, "x")
+def bn_module_pointers(gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, bwd_sums):
+    """Raw addresses of a BatchNorm module's persistent tensors (cached by the module; revalidated on gamma's address)."""
+    return (gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), num_batches_tracked.data_ptr(),
+            sums_ws.data_ptr(), bwd_sums.data_ptr())
+
+
+def bn_act_fwd(x, residual, ptrs, training, momentum, eps, relu):
+    """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last, checked by the
+    caller).  ptrs = bn_module_pointers(...).  -> (y, stats) with stats = [mean | rstd | scale | shift] (4C f32)."""
+    lib = _lib or load()
     b, c, h, w = x.shape
-    if residual is not None:
-        residual = _nhwc_bf16(residual, "residual")
-        if residual.shape != x.shape:
-            raise ValueError("residual shape mismatch")
     y = torch.empty_like(x)
-    dev = x.device
-    mean = torch.empty(c, dtype=torch.float32, device=dev) if training else None
-    rstd = torch.empty(c, dtype=torch.float32, device=dev) if training else None
-    scale_shift = torch.empty(2 * c, dtype=torch.float32, device=dev)
-    with _on(dev):
-        _check(lib.epi_bn_act_fwd(_ptr(x), _ptr(residual), b * h * w, c, _ptr(gamma), _ptr(beta), eps, momentum, int(training),
-                                  int(relu), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean),
-                                  _ptr(rstd), _ptr(scale_shift), _ptr(sums_ws), _ptr(bwd_sums if training else None), _ptr(y),
-                                  _stream()), "epi_bn_act_fwd")
-    return y, mean, rstd, scale_shift
+    stats = torch.empty(4 * c, dtype=torch.float32, device=x.device)
+    sp = stats.data_ptr()
+    st = lib.epi_bn_act_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, b * h * w, c, ptrs[0], ptrs[1], eps,
+                            momentum, 1 if training else 0, 1 if relu else 0, ptrs[2], ptrs[3], ptrs[4], sp, sp + 4 * c, sp + 8 * c,
+                            ptrs[5], ptrs[6] if training else None, y.data_ptr(), _stream())
+    if st:
+        _check(st, "epi_bn_act_fwd")
+    return y, stats
 
 
-def bn_act_bwd(dy, x, y, gamma, mean, rstd, scale_shift, relu, want_dres, sums=None):
-    """-> (dx, dres or None, dgamma, dbeta).  ``sums``: a zeroed [2C] f32 accumulator (the layer's ``bwd_sums``, cleared by
-    its forward pass); a fresh one is allocated when omitted."""
-    lib = load()
-    dy = _nhwc_bf16(dy, "dy")
+def bn_act_bwd(dy, x, y, gamma_ptr, stats, relu, want_dres, sums):
+    """-> (dx, dres or None).  ``sums`` [2C] f32 = (dbeta | dgamma) accumulator, zero on entry (the layer's ``bwd_sums``,
+    cleared by its forward pass)."""
+    lib = _lib or load()
     b, c, h, w = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    if sums is None:
-        sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device)
-    with _on(x.device):
-        _check(lib.epi_bn_act_bwd(_ptr(dy), _ptr(x), _ptr(y), b * h * w, c, _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(scale_shift),
-                                  int(relu), _ptr(sums), _ptr(dx), _ptr(dres), _stream()), "epi_bn_act_bwd")
-    return dx, dres, sums[c:], sums[:c]
+    sp = stats.data_ptr()
+    st = lib.epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, b * h * w, c, gamma_ptr, sp, sp + 4 * c,
+                            sp + 8 * c, 1 if relu else 0, sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
+                            _stream())
+    if st:
+        _check(st, "epi_bn_act_bwd")
+    return dx, dres
 
 
 def gemm_tn_bf16(a, b):

@@ -22,23 +22,25 @@ class _BNActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, module, relu):
         training = module.training
-        y, mean, rstd, scale_shift = hip.bn_act_fwd(
-            x, residual, weight, bias, module.running_mean, module.running_var, module.num_batches_tracked,
-            module.sums_ws, module.bwd_sums, training, module.momentum, module.eps, relu)
+        y, stats = hip.bn_act_fwd(x, residual, module.pointers(), training, module.momentum, module.eps, relu)
         ctx.relu, ctx.has_res, ctx.training, ctx.module = relu, residual is not None, training, module
         if training:
-            ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, mean, rstd, scale_shift)
+            ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("FusedBatchNormAct: backward through inference-mode statistics is not supported")
-        x, y, weight, mean, rstd, scale_shift = ctx.saved_tensors
+        x, y, stats = ctx.saved_tensors
+        module = ctx.module
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
         # bwd_sums was cleared by this layer's forward pass (one backward per forward: the training loop's pattern)
-        dx, dres, dgamma, dbeta = hip.bn_act_bwd(dy, x, y, weight, mean, rstd, scale_shift, ctx.relu, ctx.has_res,
-                                                 sums=ctx.module.bwd_sums)
-        return dx, dgamma, dbeta, dres, None, None
+        sums = module.bwd_sums
+        dx, dres = hip.bn_act_bwd(dy, x, y, module.pointers()[0], stats, ctx.relu, ctx.has_res, sums)
+        c = x.shape[1]
+        return dx, sums[c:], sums[:c], dres, None, None
 
 
 class FusedBatchNormAct(nn.Module):
@@ -55,11 +57,24 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
         self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
+        self._ptrs = None
+
+    def pointers(self):
+        """Device addresses of the persistent tensors, cached (hundreds of BatchNorm calls per step: the host-side cost
+        of re-deriving them is measurable); re-derived whenever the weight tensor has moved (``.to()``, reload)."""
+        p = self._ptrs
+        if p is None or p[0] != self.weight.data_ptr() or p[2] != self.running_mean.data_ptr():
+            p = self._ptrs = hip.bn_module_pointers(self.weight, self.bias, self.running_mean, self.running_var,
+                                                    self.num_batches_tracked, self.sums_ws, self.bwd_sums)
+        return p
 
     def forward(self, x, residual=None):
-        x = _nhwc_bf16(x)
-        if residual is not None:
+        if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            x = _nhwc_bf16(x)
+        if residual is not None and (residual.dtype != torch.bfloat16 or not residual.is_contiguous(memory_format=torch.channels_last)):
             residual = _nhwc_bf16(residual)
+        if not x.is_cuda:
+            raise RuntimeError("FusedBatchNormAct: input must live on the GPU (no CPU fallback in epipolarpose_amd)")
         return _BNActFunction.apply(x, self.weight, self.bias, residual, self, self.relu)
 
     def extra_repr(self):
