@@ -81,6 +81,33 @@ class FusedBatchNormAct(nn.Module):
         return "{num_features}, eps={eps}, momentum={momentum}, relu={relu}".format(**self.__dict__)
 
 
+class PointwiseConv(nn.Module):
+    """Bias-free 1x1 stride-1 convolution of an NHWC tensor as a plain library GEMM (hipBLASLt through ``F.linear`` on the
+    zero-copy [B*H*W, Cin] view); weight [Cout, Cin, 1, 1] keeps the ``nn.Conv2d`` name and shape (bottleneck conv1 / conv3,
+    pose3d_resnet.py:56,61).  At batch 32 hipBLASLt runs these shapes at 0.7-1.0 PFLOP/s where MIOpen's implicit-GEMM
+    convolution kernels reach ~0.3; forward and both backward GEMMs are stock autograd (no custom Function, no host cost)."""
+
+    supports_training_copy = True
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.Conv2d default initialisation
+        self.register_parameter("bias", None)
+
+    def forward(self, x):
+        w = getattr(self, "weight_lp", None)
+        if w is None:
+            w = self.weight
+        if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+            x = _nhwc_bf16(x)
+        if w.dtype != torch.bfloat16:
+            w = w.to(torch.bfloat16)
+        y = torch.nn.functional.linear(x.permute(0, 2, 3, 1), w.reshape(self.out_channels, self.in_channels))
+        return y.permute(0, 3, 1, 2)                                # logical NCHW, NHWC memory
+
+
 class _DeconvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):

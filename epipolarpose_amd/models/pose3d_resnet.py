@@ -18,13 +18,13 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct
+from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, PointwiseConv
 
 BN_MOMENTUM = 0.1
-# Experimental: bottleneck 1x1 stride-1 convolutions on the hand-written GEMM instead of MIOpen.  Measured round 1
-# (B=32): 14.4 ms/step vs 9.8 ms with MIOpen -- at these small shapes the per-call host cost and the extra weight
-# transposes outweigh the kernel gain -- so it is OFF unless EPI_MFMA_1X1=1.
-MFMA_1X1_CONVS = os.environ.get("EPI_MFMA_1X1", "0") == "1"
+# Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1): "blaslt" (default) = plain hipBLASLt GEMM on the NHWC view;
+# "miopen" = nn.Conv2d; "mfma" = the hand-written head GEMM (measured round 1, B=32: 14.4 ms/step vs 9.8 with MIOpen --
+# its per-call host cost and weight transposes outweigh the kernel at these small shapes).
+POINTWISE_BACKEND = os.environ.get("EPI_1X1", "blaslt")
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -47,8 +47,10 @@ class ResidualUnit(nn.Module):
         for i, (k, mult, strided) in enumerate(plan, start=1):
             cout = planes * mult
             s_i = stride if strided else 1
-            if k == 1 and s_i == 1 and cin % 8 == 0 and cout % 8 == 0 and MFMA_1X1_CONVS:
-                conv = Conv1x1(cin, cout, bias=False)            # plain GEMM [B*H*W, Cin] x [Cin, Cout] on the MFMA kernel
+            if k == 1 and s_i == 1 and POINTWISE_BACKEND == "blaslt":
+                conv = PointwiseConv(cin, cout)                  # plain GEMM [B*H*W, Cin] x [Cin, Cout] (hipBLASLt)
+            elif k == 1 and s_i == 1 and cin % 8 == 0 and cout % 8 == 0 and POINTWISE_BACKEND == "mfma":
+                conv = Conv1x1(cin, cout, bias=False)            # the same GEMM on the hand-written MFMA kernel
             else:
                 conv = nn.Conv2d(cin, cout, kernel_size=k, stride=s_i, padding=k // 2, bias=False)
             setattr(self, "conv%d" % i, conv)
