@@ -21,10 +21,11 @@ import torch.nn as nn
 from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, PointwiseConv
 
 BN_MOMENTUM = 0.1
-# Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1): "blaslt" (default) = plain hipBLASLt GEMM on the NHWC view;
-# "miopen" = nn.Conv2d; "mfma" = the hand-written head GEMM (measured round 1, B=32: 14.4 ms/step vs 9.8 with MIOpen --
-# its per-call host cost and weight transposes outweigh the kernel at these small shapes).
-POINTWISE_BACKEND = os.environ.get("EPI_1X1", "blaslt")
+# Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1).  Measured round 1 at B=32 (ms/step, whole training step):
+#   "miopen" (default, nn.Conv2d)                                  9.8
+#   "blaslt" (plain hipBLASLt GEMM on the NHWC view, F.linear)    13.4
+#   "mfma"   (the hand-written head GEMM + TN weight gradient)    14.4   (per-call host cost + weight transposes)
+POINTWISE_BACKEND = os.environ.get("EPI_1X1", "miopen")
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
