@@ -11,10 +11,13 @@ Same signature and logging ("Speed ... samples/s").  Differences that matter on 
 import logging
 import time
 
+import numpy as np
 import torch
 
+from .. import hip
 from ..utils.img_utils import self_supervision_device
 from ..utils.utils import AverageMeter
+from .integral_loss import joint_location_result_device
 
 logger = logging.getLogger(__name__)
 
@@ -112,3 +115,49 @@ def train_integral(config, train_loader, model, criterion, optimizer, epoch, gra
             batch_time.update(time.time() - end)
         end = time.time()
     return losses.avg
+
+
+def validate_integral(val_loader, model, num_joints=None):
+    """function.py:66-110: run the network over the validation loader and decode every sample.
+
+    Same contract as the reference -- returns ``preds_in_patch_with_score``: float64 ndarray [len(dataset), J, 4] (x, y, z
+    in 256-pixel patch units, score 1) -- but the soft-argmax decode stays on the GPU and the host sees ONE copy at the
+    end (the reference copies and reshapes per batch and patches ragged last batches by hand, :92-106)."""
+    print("Validation stage")
+    model.eval()
+    chunks = []
+    with torch.no_grad():
+        for data in val_loader:
+            batch_data = data[0].cuda(non_blocking=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                preds = model(batch_data)
+            chunks.append(joint_location_result_device(256, 256, preds, num_joints))        # [B, 3J] f32, normalised
+    xyz = torch.cat(chunks, dim=0)[:len(val_loader.dataset)]
+    coords = xyz.cpu().numpy().astype(float)
+    coords = coords.reshape((coords.shape[0], coords.shape[1] // 3, 3))
+    coords[:, :, 0] = (coords[:, :, 0] + 0.5) * 256                                          # integral_loss.py:199-201
+    coords[:, :, 1] = (coords[:, :, 1] + 0.5) * 256
+    coords[:, :, 2] = coords[:, :, 2] * 256
+    return np.concatenate((coords, np.ones((coords.shape[0], coords.shape[1], 1))), axis=2)
+
+
+def eval_integral(epoch, preds_in_patch_with_score, val_loader, final_output_path, debug=False):
+    """function.py:113-135: patch -> original-image coordinates for every sample (scale 1, rotation 0, 2000 mm box), then
+    ``dataset.evaluate``.  The per-sample Python loop over ``trans_coords_from_patch_to_org_3d`` becomes one
+    ``epi_decode_to_image`` launch over the whole validation set."""
+    print("Evaluation stage")
+    imdb = val_loader.dataset
+    db = imdb.db
+    n = len(imdb)
+    p = np.asarray(preds_in_patch_with_score, dtype=np.float64)[:n]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xyz = np.stack([p[:, :, 0] / 256 - 0.5, p[:, :, 1] / 256 - 0.5, p[:, :, 2] / 256], axis=2).reshape(n, -1)
+    meta = {"center_x": np.array([r["center_x"] for r in db], dtype=np.float64), "center_y": np.array([r["center_y"] for r in db], dtype=np.float64),
+            "width": np.array([r["width"] for r in db], dtype=np.float64), "height": np.array([r["height"] for r in db], dtype=np.float64),
+            "scale": np.ones(n), "rot": np.zeros(n)}
+    kps = hip.decode_to_image(torch.from_numpy(xyz.astype(np.float32)).to(dev), hip.DeviceMeta(meta, dev), 256.0, 256.0, 2000.0)
+    preds_in_img = np.concatenate([kps.cpu().numpy(), p[:, :, 3:4]], axis=2)
+    name_value, perf = imdb.evaluate(preds_in_img.copy(), final_output_path, debug=debug)
+    for name, value in name_value:
+        logger.info('Epoch[%d] Validation-%s %f', epoch, name, value)
+    return perf

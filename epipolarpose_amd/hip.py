@@ -54,6 +54,7 @@ _SIGNATURES = {
     "epi_adam_tensor_bytes": (_sz, []),
     "epi_adam_chunk_elems": (_i, []),
     "epi_adam_step": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _vp]),
+    "epi_evaluate_poses": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -538,3 +539,19 @@ def adam_step(table_dev, chunks_dev, nchunks, lr, beta1, beta2, eps, step):
     ev = timer.start("epi_adam_step")
     _check(lib.epi_adam_step(_ptr(table_dev), _ptr(chunks_dev), nchunks, lr, beta1, beta2, eps, step, _stream()), "epi_adam_step")
     timer.stop(ev)
+
+
+def evaluate_poses(pred_img, gt_img, pelvis_z, fl, c_p, root, j14):
+    """pred_img / gt_img [N, J, 3] f64 CUDA (image coordinates + root-relative depth) -> (metrics [N, 9] f64, per_joint [N, J] f64).
+    Reference: lib/dataset/h36m.py:168-378."""
+    lib = load()
+    for t in (pred_img, gt_img, pelvis_z, fl, c_p):
+        _dev(t, torch.float64)
+    pred_img, gt_img = pred_img.contiguous(), gt_img.contiguous()
+    n, j, _ = pred_img.shape
+    j14_t = torch.tensor(list(j14), dtype=torch.int32, device=pred_img.device)
+    metrics = torch.empty((n, 9), dtype=torch.float64, device=pred_img.device)
+    per_joint = torch.empty((n, j), dtype=torch.float64, device=pred_img.device)
+    _check(lib.epi_evaluate_poses(_ptr(pred_img), _ptr(gt_img), _ptr(pelvis_z.contiguous()), _ptr(fl.contiguous()), _ptr(c_p.contiguous()),
+                                  n, j, root, _ptr(j14_t), len(j14), _ptr(metrics), _ptr(per_joint), _stream()), "epi_evaluate_poses")
+    return metrics, per_joint

@@ -218,6 +218,18 @@ int epi_adam_chunk_elems(void);
 int epi_adam_step(const void* table, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
                   long long step, epi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pose evaluation -- replaces the per-sample loop of H36M_Integral.evaluate
+ * (lib/dataset/h36m.py:168-378) incl. compute_similarity_transform (lib/utils/prep_h36m.py:108-168).
+ *   pred_img, gt_img [N][J][3] f64: (u, v, root-relative depth mm) in image coordinates; pelvis_z [N]: camera-space
+ *   root depth; fl, c_p [N][2]; root: root joint index; j14 [n14] int32 (device): joints of the 14-joint protocol.
+ *   metrics [N][9] f64: MPJPE, PA-MPJPE, N-MPJPE, the same three over j14, mean |dx|, |dy|, |dz|  (all root-centred);
+ *   per_joint [N][J] f64: per-joint errors.  J <= 32.
+ * ------------------------------------------------------------------------------------------------ */
+int epi_evaluate_poses(const double* pred_img, const double* gt_img, const double* pelvis_z, const double* fl,
+                       const double* c_p, int N, int J, int root, const int32_t* j14, int n14, double* metrics,
+                       double* per_joint, epi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

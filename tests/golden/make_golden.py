@@ -254,7 +254,65 @@ def gen_network():
     save("network.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------------
+# 6. evaluation: H36M_Integral.evaluate executed live on a synthetic ground-truth db
+# --------------------------------------------------------------------------------------------------
+def eval_scene(n_group, j, seed, noise_mm):
+    """gt db records in the reference's format + noisy predictions in image coordinates."""
+    sc = SyntheticScenes(n_group=n_group, n_view=4, num_joints=j, seed=seed, augment=False)
+    rng = np.random.default_rng(seed + 1)
+    gts, preds = [], []
+    for i in range(sc.batch_size):
+        v, g = divmod(i, n_group)
+        cam = sc.cams[v]
+        xc = (sc.world[g] - cam["T"].reshape(3)) @ cam["R"].T
+        root = 6 if j == 16 else 0
+        uv = xc[:, :2] / xc[:, 2:3] * cam["f"] + cam["c"]
+        joints = np.concatenate([uv, xc[:, 2:3] - xc[root, 2]], axis=1)
+        xp = xc + rng.normal(0, noise_mm, size=xc.shape)
+        uvp = xp[:, :2] / xp[:, 2:3] * cam["f"] + cam["c"]
+        preds.append(np.concatenate([uvp, xp[:, 2:3] - xc[root, 2], np.ones((j, 1))], axis=1))
+        gts.append({"fl": cam["f"].copy(), "c_p": cam["c"].copy(), "pelvis": xc[root].copy(), "joints_3d": joints,
+                    "joints_3d_vis": np.ones((j, 3))})
+    return gts, np.asarray(preds)
+
+
+def gen_evaluation():
+    import importlib
+    h36m = importlib.import_module("lib.dataset.h36m")
+    out = {}
+    for tag, j, mpii in (("h36m", 17, False), ("mpii", 16, True)):
+        gts, preds = eval_scene(5, j, 200 + j, noise_mm=25.0)
+        if mpii:   # the reference permutes the 17-joint gt into MPII order itself (h36m.py:219-220): give it 17-joint records
+            gts17, _ = eval_scene(5, 17, 200 + j, noise_mm=25.0)
+            perm = h36m.H36M_TO_MPII_PERM
+            preds = np.stack([p for p in eval_scene(5, 17, 200 + j, noise_mm=25.0)[1]])[:, perm, :]
+            gts = gts17
+        obj = object.__new__(h36m.H36M_Integral)
+        obj.db = gts
+        obj.cfg = REF.EasyDict({"DATASET": {"MPII_ORDER": mpii}, "DEBUG": {"DEBUG": False}})
+        obj.root = ""
+        name_value, perf = h36m.H36M_Integral.evaluate(obj, preds.copy())
+        out[tag + "/preds"] = preds
+        out[tag + "/gt_joints"] = np.stack([g["joints_3d"] for g in gts])
+        out[tag + "/pelvis"] = np.stack([g["pelvis"] for g in gts])
+        out[tag + "/fl"] = np.stack([g["fl"] for g in gts])
+        out[tag + "/c_p"] = np.stack([g["c_p"] for g in gts])
+        out[tag + "/metrics"] = np.array([v for _, v in name_value])
+        out[tag + "/names"] = np.array([k for k, _ in name_value])
+        out[tag + "/perf"] = np.float64(perf)
+    rng = np.random.default_rng(9)
+    x = rng.normal(0, 300, size=(6, 17, 3))
+    y = np.stack([1.3 * (xi @ np.linalg.qr(rng.normal(size=(3, 3)))[0]) + rng.normal(0, 20, size=xi.shape) + 50 for xi in x])
+    out["procrustes/x"], out["procrustes/y"] = x, y
+    res = [REF.prep_h36m.compute_similarity_transform(x[i], y[i], compute_optimal_scale=True) for i in range(6)]
+    out["procrustes/T"] = np.stack([r[2] for r in res])
+    out["procrustes/b"] = np.array([r[3] for r in res])
+    out["procrustes/c"] = np.stack([r[4] for r in res])
+    save("evaluation.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network"]
+    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation"]
     for w in which:
         globals()["gen_" + w]()

@@ -143,3 +143,28 @@ def test_get_max_preds(golden):
     preds, maxvals = inference.get_max_preds(g["heatmaps"])
     np.testing.assert_array_equal(preds, g["preds"])
     np.testing.assert_array_equal(maxvals, g["maxvals"])
+
+
+@pytest.mark.parametrize("tag,mpii", [("h36m", False), ("mpii", True)])
+def test_evaluation_metrics(golden, tag, mpii):
+    from oracle import evaluation
+    g = golden("evaluation")
+    gt = g[tag + "/gt_joints"]
+    if mpii:        # the reference permutes its 17-joint records into MPII order (h36m.py:219-220)
+        from epipolarpose_amd.dataset.h36m_eval import H36M_TO_MPII_PERM
+        gt = gt[:, H36M_TO_MPII_PERM, :]
+    metrics, per_sample, per_joint = evaluation.evaluate(g[tag + "/preds"], gt, g[tag + "/pelvis"], g[tag + "/fl"], g[tag + "/c_p"],
+                                                         mpii_order=mpii)
+    np.testing.assert_allclose(metrics, g[tag + "/metrics"], rtol=1e-10, atol=1e-9)
+    assert list(evaluation.METRIC_NAMES) == g[tag + "/names"].tolist()
+    np.testing.assert_allclose(metrics[0], g[tag + "/perf"], rtol=1e-12)
+
+
+def test_procrustes(golden):
+    from oracle import evaluation
+    g = golden("evaluation")
+    for i in range(6):
+        t, b, c = evaluation.similarity_transform(g["procrustes/x"][i], g["procrustes/y"][i])
+        np.testing.assert_allclose(t, g["procrustes/T"][i], atol=1e-12)
+        np.testing.assert_allclose(b, g["procrustes/b"][i], rtol=1e-12)
+        np.testing.assert_allclose(c, g["procrustes/c"][i], atol=1e-9)
