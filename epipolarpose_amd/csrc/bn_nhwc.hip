@@ -37,54 +37,10 @@ __device__ __forceinline__ void slab_reduce_and_add(const float (&s)[8], const f
     }
 }
 
-// Per-channel epilogue of the statistics: mean / rstd from the batch sums, running statistics (momentum, unbiased
-// variance), fused affine scale/shift; clears the forward sums and this layer's backward accumulator.
-// Inference (sums == nullptr): scale/shift from the running statistics.
-struct BnFinalizeArgs {
-    const float* gamma; const float* beta; float eps, momentum; float* running_mean; float* running_var; long long* num_batches;
-    float* mean; float* rstd; float* scale; float* shift; float* bwd_sums;
-};
-
-__device__ __forceinline__ void bn_finalize_channel(int c, float* __restrict__ sums, float s1, float s2, long long R, int C,
-                                                    const BnFinalizeArgs& f) {
-    if (f.bwd_sums) { f.bwd_sums[c] = 0.f; f.bwd_sums[C + c] = 0.f; }     // accumulator of this layer's NEXT backward pass
-    double m, var;
-    if (sums) {                        // (s1, s2) = (sum x, sum x^2) of channel c, already read by the caller
-        m = (double)s1 / (double)R;
-        var = (double)s2 / (double)R - m * m;
-        if (var < 0) var = 0;
-        sums[c] = 0.f;                 // leave the accumulator clean for the next call (and graph replays)
-        sums[C + c] = 0.f;
-        if (f.running_mean) {
-            const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
-            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
-            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
-        }
-    } else {
-        m = f.running_mean[c];
-        var = f.running_var[c];
-    }
-    const float rs = (float)(1.0 / sqrt(var + (double)f.eps));
-    if (f.mean) { f.mean[c] = (float)m; f.rstd[c] = rs; }
-    const float sc = f.gamma[c] * rs;
-    f.scale[c] = sc;
-    f.shift[c] = f.beta[c] - (float)m * sc;
-}
-
-__global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, BnFinalizeArgs f) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && f.num_batches && sums) f.num_batches[0] += 1;
-    if (c < C) bn_finalize_channel(c, sums, sums ? sums[c] : 0.f, sums ? sums[C + c] : 0.f, R, C, f);
-}
-
-// sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry).  FINALIZE: the last workgroup to arrive (agent-scope
-// ticket after an agent-scope release of its atomics; acquire before it reads the sums -- HIP guide, Guideline 16) runs the
-// per-channel epilogue, so the forward pass needs no separate finalize launch.  ticket word = sums[2C] (as uint), kept 0.
-template <bool FINALIZE>
+// sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
-                                                              int rows_per_wg, float* __restrict__ sums, BnFinalizeArgs fin) {
+                                                              int rows_per_wg, float* __restrict__ sums) {
     __shared__ float red[BN_RLANES * 128];
-    __shared__ int is_last;
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
     const int ch0 = slab * BN_SLAB + g * 8;
     float s[8], q[8];
@@ -117,31 +73,41 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
         }
     }
     slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
-    if (FINALIZE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave drains the atomics it issued
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned int* ticket = reinterpret_cast<unsigned int*>(sums + 2 * C);
-            const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == gridDim.x * gridDim.y - 1u);
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
-                if (fin.num_batches) fin.num_batches[0] += 1;
-            }
-            is_last = last;
+}
+
+// Training: mean / rstd from the batch sums, running statistics (momentum, unbiased variance), fused affine
+// scale/shift; clears the sums for the next call and bumps num_batches_tracked.
+// Inference (sums == nullptr): scale/shift from the running statistics.
+__global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ num_batches, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ bwd_sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches && sums) num_batches[0] += 1;
+    if (c >= C) return;
+    if (bwd_sums) { bwd_sums[c] = 0.f; bwd_sums[C + c] = 0.f; }     // accumulator of this layer's NEXT backward pass
+    double m, var;
+    if (sums) {
+        m = (double)sums[c] / (double)R;
+        var = (double)sums[C + c] / (double)R - m * m;
+        if (var < 0) var = 0;
+        sums[c] = 0.f;                 // leave the accumulator clean for the next call (and graph replays)
+        sums[C + c] = 0.f;
+        if (running_mean) {
+            const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
-        __syncthreads();
-        if (is_last)
-            for (int c = threadIdx.x; c < C; c += BN_THREADS) {
-                // the sums were produced by L2 atomics of other workgroups: read them past this CU's L1
-                const float s1 = __hip_atomic_load(sums + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float s2 = __hip_atomic_load(sums + C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bn_finalize_channel(c, sums, s1, s2, R, C, fin);
-            }
+    } else {
+        m = running_mean[c];
+        var = running_var[c];
     }
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    if (mean) { mean[c] = (float)m; rstd[c] = rs; }
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
 }
 
 // y = act(x * scale[c] + shift[c] (+ res))
@@ -285,20 +251,16 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     if ((running_mean == nullptr) != (running_var == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    BnFinalizeArgs fin;
-    fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum; fin.running_mean = running_mean;
-    fin.running_var = running_var; fin.num_batches = num_batches_tracked; fin.mean = mean; fin.rstd = rstd;
-    fin.scale = scale_shift; fin.shift = scale_shift + C; fin.bwd_sums = training ? bwd_sums : nullptr;
-    if (training) {       // statistics + per-channel epilogue in one launch (the last workgroup finalizes)
+    if (training) {
         int rpw = 0;
         dim3 rgrid;
         reduce_blocking(R, C, &rpw, &rgrid);
-        hipLaunchKernelGGL((bn_stats_kernel<true>), rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws, fin);
-        EPI_CHECK_LAUNCH();
-    } else {
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, nullptr, R, C, fin);
+        hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws);
         EPI_CHECK_LAUNCH();
     }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C, bwd_sums);
+    EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     const unsigned short* xs = (const unsigned short*)x;
@@ -352,8 +314,7 @@ extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* su
     int rpw = 0;
     dim3 rgrid;
     reduce_blocking(R, C, &rpw, &rgrid);
-    BnFinalizeArgs none = {};
-    hipLaunchKernelGGL((bn_stats_kernel<false>), rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums, none);
+    hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

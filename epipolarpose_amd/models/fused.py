@@ -55,7 +55,7 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-        self.register_buffer("sums_ws", torch.zeros(2 * num_features + 1), persistent=False)   # accumulator + ticket, kept zero
+        self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
         self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
         self._ptrs = None
 

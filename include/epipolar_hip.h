@@ -175,8 +175,8 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  * (+ `out += residual`) of lib/models/pose3d_resnet.py:31-47,68-88,158-183,186-188.
  *   x, residual, y : [R][C] bf16 (R = B*H*W, C % 8 == 0);  gamma, beta, running_mean, running_var, mean, rstd : [C] f32
  *   scale_shift    : [2C] f32 out (scale = gamma*rstd, shift = beta - mean*scale), reused by the backward
- *   sums_ws        : [2C + 1] f32 accumulator (+ 1 arrival-ticket word) that must be ZERO on entry; it is zero again
- *                    on return (keep one per layer: graph replays then need no memset)
+ *   sums_ws        : [2C] f32 accumulator that must be ZERO on entry; it is zero again on return (keep one per
+ *                    layer: graph replays then need no memset)
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
  *                    num_batches_tracked += 1;   training == 0: running statistics.
  *   bwd_sums       : [2C] f32 or NULL: zeroed by the forward so that it can serve as `dbeta_dgamma` of this
