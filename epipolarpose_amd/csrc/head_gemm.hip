@@ -418,7 +418,8 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
 namespace epi {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-constexpr int TN_ROW_BYTES = 288;                       // 128 cols * 2 B + 32 B pad: 4 consecutive rows hit disjoint banks
+constexpr int TN_ROW_BYTES = 320;                       // 128 cols * 2 B + 64 B pad: the 4 rows x 64 B a 32-lane transpose-read group touches
+                                                        // land on 4 disjoint 16-bank quarters (288 B left a 2-way conflict, PMC: 7 %)
 constexpr int TN_TILE_BYTES = GBK * TN_ROW_BYTES;       // 18 KiB per operand tile
 
 struct GemmTnArgs {
