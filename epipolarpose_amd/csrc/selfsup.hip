@@ -248,33 +248,15 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ 
     if (t >= (long long)G * J) return;
     const int g = (int)(t / J), j = (int)(t - (long long)g * J);
     T u[NV][2], P[NV][12], x[3];
-    // 16-byte loads of the projection matrices (3 per view instead of 12 scalar loads: the bulk kernel is otherwise bound by
-    // load-instruction issue, not by HBM) and one 8/16-byte load of (u, v)
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(Pm) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(kps) & (2 * sizeof(S) - 1)) == 0) &&
-                        (kstride % 2 == 0);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (v < V) {
             const long long s = (long long)v * G + g;                  // img_utils.py:197-202
             const S* kp = kps + (s * J + j) * kstride;
+            u[v][0] = (T)kp[0]; u[v][1] = (T)kp[1];
             const S* pp = Pm + s * 12;
-            if (vec_ok) {
-                struct alignas(2 * sizeof(S)) S2 { S a, b; };
-                struct alignas(16) S16 { S e[16 / sizeof(S)]; };
-                const S2 uv = *reinterpret_cast<const S2*>(kp);
-                u[v][0] = (T)uv.a; u[v][1] = (T)uv.b;
-                constexpr int PER = 16 / sizeof(S);
 #pragma unroll
-                for (int q = 0; q < 12 / PER; ++q) {
-                    const S16 t4 = *reinterpret_cast<const S16*>(pp + q * PER);
-#pragma unroll
-                    for (int e = 0; e < PER; ++e) P[v][q * PER + e] = (T)t4.e[e];
-                }
-            } else {
-                u[v][0] = (T)kp[0]; u[v][1] = (T)kp[1];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) P[v][k] = (T)pp[k];
-            }
+            for (int k = 0; k < 12; ++k) P[v][k] = (T)pp[k];
         } else {
             u[v][0] = u[v][1] = 0;
 #pragma unroll
