@@ -409,7 +409,7 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
 
 // ---------------------------------------------------------------------------------------------------------------
 // "TN" GEMM for the weight gradients:  C[i][j] = sum_r A[r][i] * B(r)[j]   (reduction over the ROW index of both
-// operands: r enumerates batch*pixels).  Both tiles are staged row-major ([r][i], [r][j], 288-byte padded rows) and
+// operands: r enumerates batch*pixels).  Both tiles are staged row-major ([r][i], [r][j], 320-byte padded rows) and
 // the MFMA operands (8 consecutive r per lane) are produced by the LDS transpose read ds_read_b64_tr_b16
 // (a 16-lane group reads a 4(r) x 16(col) block; lane c receives column c).  B may be an implicit gather
 // (ConvTranspose2d weight gradient: rows of dOut at (2*ih-1+kh, 2*iw-1+kw) for tap blockIdx.z).
