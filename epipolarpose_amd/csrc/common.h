@@ -6,6 +6,8 @@
 #include "../../include/epipolar_hip.h"
 
 #define EPI_WAVE 64
+// float64 per-thread math that the CPU test-suite also compiles for the host (tests/hostcheck): never called on the host by the library
+#define EPI_HD __host__ __device__
 #define EPI_LOG2E 1.4426950408889634f
 
 #define EPI_CHECK_LAUNCH()                                   \

@@ -6,6 +6,7 @@
 //   lib/utils/img_utils.py:63-111,141-243, lib/utils/triangulation.py:8-181, lib/utils/prep_h36m.py:170-204.
 // One thread owns one (group, joint); the fused kernel keeps the whole SS step in ONE launch.
 #include "common.h"
+#include "linalg3.h"
 
 namespace epi {
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P
 // triangulation.py:8-27 == cv2.triangulatePoints: homogeneous 2Vx4 system, right-singular vector of the
 // smallest singular value.  One-sided (Hestenes) Jacobi SVD in float64 on the columns of M.
 template <int NV>
-__device__ __forceinline__ int tri_dlt(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
+EPI_HD __forceinline__ int tri_dlt(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
     double M[4][2 * NV];      // column-major: M[c][row]
     double Vm[4][4];
 #pragma unroll
@@ -218,7 +219,187 @@ __device__ __forceinline__ int tri_dlt(const double (&u)[NV][2], const double (&
     return (mx <= 1.0e16) ? 1 : 0;                                               // :25 (NaN -> 0)
 }
 
-enum { TRI_ITER = 0, TRI_LS = 1, TRI_DLT = 2 };
+// ---------------------------------------------------------------------------------------------------------------------
+// Polynomial ("optimal") two-view triangulation, triangulation.py:184-220: F from the two projection matrices,
+// cv2.correctMatches (Hartley & Sturm; HZ Algorithm 12.1), then the linear-eigen solve on the corrected matches.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// triangulation.py:196-204.  P_full = [P; 0 0 0 1];  P_canon = P2_full inv(P1_full) = [M2 M1^-1 | p2 - M2 M1^-1 p1];
+// F = [t]_x R with R = P_canon[:3,:3], t = P_canon[:3,3].
+EPI_HD __forceinline__ void fundamental_from_P(const double (&P1)[12], const double (&P2)[12], double (&F)[3][3]) {
+    const double m00 = P1[0], m01 = P1[1], m02 = P1[2], m10 = P1[4], m11 = P1[5], m12 = P1[6], m20 = P1[8], m21 = P1[9], m22 = P1[10];
+    double inv[3][3];
+    inv[0][0] = m11 * m22 - m12 * m21; inv[0][1] = m02 * m21 - m01 * m22; inv[0][2] = m01 * m12 - m02 * m11;
+    inv[1][0] = m12 * m20 - m10 * m22; inv[1][1] = m00 * m22 - m02 * m20; inv[1][2] = m02 * m10 - m00 * m12;
+    inv[2][0] = m10 * m21 - m11 * m20; inv[2][1] = m01 * m20 - m00 * m21; inv[2][2] = m00 * m11 - m01 * m10;
+    const double det = m00 * inv[0][0] + m01 * inv[1][0] + m02 * inv[2][0];
+    const double rd = 1.0 / det;
+    double R[3][3], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            R[r][c] = (P2[4 * r] * inv[0][c] + P2[4 * r + 1] * inv[1][c] + P2[4 * r + 2] * inv[2][c]) * rd;
+        t[r] = P2[4 * r + 3] - (R[r][0] * P1[3] + R[r][1] * P1[7] + R[r][2] * P1[11]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                      // F[:, c] = t x R[:, c]
+        F[0][c] = t[1] * R[2][c] - t[2] * R[1][c];
+        F[1][c] = t[2] * R[0][c] - t[0] * R[2][c];
+        F[2][c] = t[0] * R[1][c] - t[1] * R[0][c];
+    }
+}
+
+EPI_HD __forceinline__ double horner(const double* c, int n, double x) {
+    double v = c[n];
+    for (int k = n - 1; k >= 0; --k) v = fma(v, x, c[k]);
+    return v;
+}
+
+// Real roots in [-1, 1] of the polynomial c[0..N] (ascending powers), by the derivative chain: the roots of p^(k+1) cut
+// [-1, 1] into pieces on which p^(k) is monotonic, each piece with a sign change is bisected (then Newton-polished).
+// Needs no bound on the roots and tolerates vanishing leading coefficients.  `out` also receives the break points that
+// were examined on the way (roots of p'), which callers may use as extra candidates.
+template <int N>
+EPI_HD int real_roots_unit(const double (&c)[N + 1], double (&out)[N]) {
+    double D[N][N + 1];                          // D[k] = coefficients of the k-th derivative (degree N-k)
+    for (int i = 0; i <= N; ++i) D[0][i] = c[i];
+    for (int k = 1; k < N; ++k)
+        for (int i = 0; i <= N - k; ++i) D[k][i] = D[k - 1][i + 1] * (double)(i + 1);
+    double prev[N + 2], cur[N + 2];
+    int np_ = 0;
+    for (int k = N - 1; k >= 0; --k) {           // roots of D[k] (degree N-k) from the roots of D[k+1] in `prev`
+        const int deg = N - k;
+        int nc = 0;
+        double lo = -1.0, flo = horner(D[k], deg, lo);
+        for (int s = 0; s <= np_; ++s) {
+            const double hi = (s < np_) ? prev[s] : 1.0;
+            const double fhi = horner(D[k], deg, hi);
+            if (hi > lo) {
+                if (flo == 0.0) { if (s == 0) cur[nc++] = lo; }
+                else if ((flo < 0) != (fhi < 0) && fhi != 0.0) {
+                    double a = lo, b = hi;
+                    const bool up = flo < 0;
+                    for (int it = 0; it < 56; ++it) {
+                        const double m = 0.5 * (a + b);
+                        const double fm = horner(D[k], deg, m);
+                        if ((fm < 0) == up) a = m; else b = m;
+                    }
+                    double r = 0.5 * (a + b);
+                    if (k + 1 < N) {                                   // Newton polish for relative accuracy near 0
+                        for (int it = 0; it < 2; ++it) {
+                            const double d = horner(D[k + 1], deg - 1, r);
+                            if (d != 0.0) {
+                                const double r2 = r - horner(D[k], deg, r) / d;
+                                if (r2 > lo && r2 < hi) r = r2;
+                            }
+                        }
+                    }
+                    cur[nc++] = r;
+                }
+                if (fhi == 0.0) cur[nc++] = hi;
+            }
+            lo = hi; flo = fhi;
+        }
+        for (int i = 0; i < nc && i < N; ++i) prev[i] = cur[i];
+        np_ = nc < N ? nc : N;
+        if (k == 0) for (int i = 0; i < np_; ++i) out[i] = prev[i];
+    }
+    return np_;
+}
+
+// cv2.correctMatches for one pair: (x1, y1) <-> (x2, y2) moved onto the closest pair with x2^T F x1 = 0.
+EPI_HD void correct_match(const double (&F)[3][3], double (&p1)[2], double (&p2)[2]) {
+    double Ft[3][3];                                                    // (ii) T2^T F T1,  T = [[1,0,x],[0,1,y],[0,0,1]]
+    {
+        double FT[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { FT[r][0] = F[r][0]; FT[r][1] = F[r][1]; FT[r][2] = F[r][0] * p1[0] + F[r][1] * p1[1] + F[r][2]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { Ft[0][c] = FT[0][c]; Ft[1][c] = FT[1][c]; Ft[2][c] = p2[0] * FT[0][c] + p2[1] * FT[1][c] + FT[2][c]; }
+    }
+    double U[3][3], sv[3], V[3][3];
+    svd3(Ft, U, sv, V);
+    double e1[3] = {V[0][2], V[1][2], V[2][2]};                         // (iii) F e1 = 0
+    double e2[3] = {U[1][0] * U[2][1] - U[2][0] * U[1][1],              //       e2^T F = 0: e2 = u0 x u1
+                    U[2][0] * U[0][1] - U[0][0] * U[2][1],
+                    U[0][0] * U[1][1] - U[1][0] * U[0][1]};
+    const double n1 = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1]), n2 = 1.0 / sqrt(e2[0] * e2[0] + e2[1] * e2[1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { e1[i] *= n1; e2[i] *= n2; }
+    // (iv)-(v)  R = [[ex, ey, 0], [-ey, ex, 0], [0, 0, 1]];  Fr = R2 Ft R1^T -- only the lower-right 2x2 block is needed
+    double G1[3][3];                                                    // Ft R1^T
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        G1[r][0] = Ft[r][0] * e1[0] + Ft[r][1] * e1[1];
+        G1[r][1] = -Ft[r][0] * e1[1] + Ft[r][1] * e1[0];
+        G1[r][2] = Ft[r][2];
+    }
+    const double a = -e2[1] * G1[0][1] + e2[0] * G1[1][1], b = -e2[1] * G1[0][2] + e2[0] * G1[1][2];
+    const double c = G1[2][1], d = G1[2][2], f1 = e1[2], f2 = e2[2];   // (vi)
+    // (vii) g(t) = t((at+b)^2 + f2^2 (ct+d)^2)^2 - (ad-bc)(1+f1^2 t^2)^2 (at+b)(ct+d), ascending coefficients
+    const double q0 = b * b + f2 * f2 * d * d, q1 = 2.0 * (a * b + f2 * f2 * c * d), q2 = a * a + f2 * f2 * c * c;
+    const double k = a * d - b * c, w = f1 * f1;
+    const double r0 = b * d, r1 = a * d + b * c, r2 = a * c;           // (at+b)(ct+d)
+    double g[7];
+    g[0] = -k * r0;
+    g[1] = q0 * q0 - k * r1;
+    g[2] = 2.0 * q0 * q1 - k * (r2 + 2.0 * w * r0);
+    g[3] = q1 * q1 + 2.0 * q0 * q2 - k * 2.0 * w * r1;
+    g[4] = 2.0 * q1 * q2 - k * (2.0 * w * r2 + w * w * r0);
+    g[5] = q2 * q2 - k * w * w * r1;
+    g[6] = -k * w * w * r2;
+    double gmax = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gmax = fmax(gmax, fabs(g[i]));
+    // (viii) candidates: real roots with |t| <= 1, and with |t| >= 1 through the reversed polynomial in 1/t; t = infinity.
+    double best_t = 0.0, best_cost = 1.0e300;
+    bool at_inf = false;
+    auto cost = [&](double t) {
+        const double n = c * t + d, m = a * t + b;
+        return t * t / (1.0 + w * t * t) + n * n / (m * m + f2 * f2 * n * n);
+    };
+    if (gmax > 0) {
+        double roots[6];
+        int nr = real_roots_unit<6>(g, roots);
+        for (int i = 0; i < nr; ++i) {
+            const double cs = cost(roots[i]);
+            if (cs < best_cost) { best_cost = cs; best_t = roots[i]; }
+        }
+        double gr[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gr[i] = g[6 - i];
+        nr = real_roots_unit<6>(gr, roots);
+        for (int i = 0; i < nr; ++i) {
+            if (roots[i] == 0.0) continue;
+            const double t = 1.0 / roots[i];
+            const double cs = cost(t);
+            if (cs < best_cost) { best_cost = cs; best_t = t; }
+        }
+    } else {
+        best_cost = cost(0.0);                                          // g == 0: every t is stationary
+    }
+    if (w > 0) {
+        const double c_inf = 1.0 / w + c * c / (a * a + f2 * f2 * c * c);
+        if (c_inf < best_cost) at_inf = true;
+    }
+    double l1[3], l2[3];                                                // (ix)
+    if (at_inf) { l1[0] = f1; l1[1] = 0.0; l1[2] = -1.0; l2[0] = -f2 * c; l2[1] = a; l2[2] = c; }
+    else {
+        const double t = best_t;
+        l1[0] = t * f1; l1[1] = 1.0; l1[2] = -t;
+        l2[0] = -f2 * (c * t + d); l2[1] = a * t + b; l2[2] = c * t + d;
+    }
+    // closest point of each line to the origin, then (x) back through R^T and T
+    const double x1[3] = {-l1[0] * l1[2], -l1[1] * l1[2], l1[0] * l1[0] + l1[1] * l1[1]};
+    const double x2[3] = {-l2[0] * l2[2], -l2[1] * l2[2], l2[0] * l2[0] + l2[1] * l2[1]};
+    const double y1[3] = {e1[0] * x1[0] - e1[1] * x1[1], e1[1] * x1[0] + e1[0] * x1[1], x1[2]};
+    const double y2[3] = {e2[0] * x2[0] - e2[1] * x2[1], e2[1] * x2[0] + e2[0] * x2[1], x2[2]};
+    p1[0] = (y1[0] + p1[0] * y1[2]) / y1[2]; p1[1] = (y1[1] + p1[1] * y1[2]) / y1[2];
+    p2[0] = (y2[0] + p2[0] * y2[2]) / y2[2]; p2[1] = (y2[1] + p2[1] * y2[2]) / y2[2];
+}
+
+enum { TRI_ITER = 0, TRI_LS = 1, TRI_DLT = 2, TRI_POLY = 3 };
 
 template <typename T, int NV, int METHOD>
 __device__ __forceinline__ int triangulate_one(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
@@ -264,10 +445,30 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ 
         }
     }
     int st;
-    if constexpr (METHOD == TRI_DLT) st = tri_dlt<NV>(u, P, V, x);
+    if constexpr (METHOD == TRI_POLY) {
+        double F[3][3];
+        fundamental_from_P(P[0], P[1], F);
+        correct_match(F, u[0], u[1]);
+        st = tri_dlt<NV>(u, P, V, x);
+    } else if constexpr (METHOD == TRI_DLT) st = tri_dlt<NV>(u, P, V, x);
     else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
     X[3 * t] = (S)x[0]; X[3 * t + 1] = (S)x[1]; X[3 * t + 2] = (S)x[2];
     if (status) status[t] = st;
+}
+
+// cv2.correctMatches over G fundamental matrices x J pairs each (float64).
+__global__ __launch_bounds__(256) void correct_matches_kernel(const double* __restrict__ Fm, const double* __restrict__ u1,
+                                                              const double* __restrict__ u2, int G, int J,
+                                                              double* __restrict__ o1, double* __restrict__ o2) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)G * J) return;
+    const double* f = Fm + (t / J) * 9;
+    double F[3][3], a[2] = {u1[2 * t], u1[2 * t + 1]}, b[2] = {u2[2 * t], u2[2 * t + 1]};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = f[i];
+    correct_match(F, a, b);
+    o1[2 * t] = a[0]; o1[2 * t + 1] = a[1];
+    o2[2 * t] = b[0]; o2[2 * t + 1] = b[1];
 }
 
 struct MetaDev {
@@ -368,7 +569,12 @@ __global__ __launch_bounds__(SS_THREADS) void self_supervision_kernel(const floa
                 for (int k = 0; k < 12; ++k) P[v][k] = 0;
             }
         }
-        if constexpr (METHOD == TRI_DLT) tri_dlt<NV>(u, P, V, x);
+        if constexpr (METHOD == TRI_POLY) {
+            double F[3][3];
+            fundamental_from_P(P[0], P[1], F);
+            correct_match(F, u[0], u[1]);
+            tri_dlt<NV>(u, P, V, x);
+        } else if constexpr (METHOD == TRI_DLT) tri_dlt<NV>(u, P, V, x);
         else triangulate_one<double, NV, METHOD>(u, P, V, tol, max_iter, x);
         double* xs = Xs + (gl * J + j) * 3;
         xs[0] = x[0]; xs[1] = x[1]; xs[2] = x[2];
@@ -452,6 +658,22 @@ extern "C" int epi_triangulate_dlt(const void* kps, int kps_stride, const void* 
     return tri_entry<TRI_DLT>(kps, kps_stride, P, dtype, G, V, J, 0.0, 1, X, status, stream);
 }
 
+extern "C" int epi_triangulate_poly(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J, void* X,
+                                    int32_t* status, epi_stream_t stream) {
+    if (V != 2) return EPI_ERR_UNSUPPORTED;                             // a two-view method (triangulation.py:184)
+    return tri_entry<TRI_POLY>(kps, kps_stride, P, dtype, G, V, J, 0.0, 1, X, status, stream);
+}
+extern "C" int epi_correct_matches(const double* F, const double* u1, const double* u2, int G, int J, double* out1, double* out2,
+                                   epi_stream_t stream) {
+    if (!F || !u1 || !u2 || !out1 || !out2 || G <= 0 || J <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    const long long total = (long long)G * J;
+    if (total > 0x7fffffffLL * 128) return EPI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(correct_matches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, u1, u2,
+                       G, J, out1, out2);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
 extern "C" int epi_decode_to_image(const float* xyz, int B, int J, const epi_view_meta* meta_host, double patch_w,
                                    double patch_h, double rect3d, double* kps_img, epi_stream_t stream) {
     if (!xyz || !kps_img || B <= 0 || J <= 0 || !meta_ok(meta_host, false, false)) return EPI_ERR_INVALID_ARGUMENT;
@@ -486,7 +708,9 @@ static int launch_ss(const float* xyz, int G, int V, int J, MetaDev m, double pw
                        rect3d, root, tol, max_iter, label, weight, Xout)
     if (method == TRI_ITER) EPI_SS_LAUNCH(TRI_ITER);
     else if (method == TRI_LS) EPI_SS_LAUNCH(TRI_LS);
-    else EPI_SS_LAUNCH(TRI_DLT);
+    else if (method == TRI_DLT) EPI_SS_LAUNCH(TRI_DLT);
+    else if constexpr (NV == 2) EPI_SS_LAUNCH(TRI_POLY);
+    else return EPI_ERR_UNSUPPORTED;
 #undef EPI_SS_LAUNCH
     EPI_CHECK_LAUNCH();
     return EPI_OK;
@@ -497,8 +721,8 @@ extern "C" int epi_self_supervision(const float* xyz, int G, int V, int J, const
                                     float* label, float* weight, double* X_out, epi_stream_t stream) {
     if (!xyz || !label || !weight || G <= 0 || J <= 0 || root_joint < 0 || root_joint >= J || !meta_ok(meta_host, true, true))
         return EPI_ERR_INVALID_ARGUMENT;
-    if (method < 0 || method > 2 || max_iter < 1) return EPI_ERR_INVALID_ARGUMENT;
-    if (V < 2 || V > 8 || J > SS_THREADS) return EPI_ERR_UNSUPPORTED;
+    if (method < 0 || method > 3 || max_iter < 1) return EPI_ERR_INVALID_ARGUMENT;
+    if (V < 2 || V > 8 || J > SS_THREADS || (method == TRI_POLY && V != 2)) return EPI_ERR_UNSUPPORTED;
     const MetaDev m = to_dev(meta_host);
     hipStream_t st = (hipStream_t)stream;
     if (V == 2) return launch_ss<2>(xyz, G, V, J, m, patch_w, patch_h, rect3d, root_joint, method, tolerance, max_iter, label, weight, X_out, st);

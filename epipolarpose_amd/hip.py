@@ -15,7 +15,7 @@ _lib = None
 EPI_F32, EPI_BF16, EPI_F64 = 0, 1, 2
 EPI_NCHW, EPI_NHWC = 0, 1
 LOSS_KINDS = {"l1": 0, "l2": 1, "smoothl1": 2}
-TRI_METHODS = {"iterative": 0, "ls": 1, "dlt": 2}
+TRI_METHODS = {"iterative": 0, "ls": 1, "dlt": 2, "poly": 3}
 
 _vp, _i, _d, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t
 
@@ -37,6 +37,8 @@ _SIGNATURES = {
     "epi_triangulate_iterls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp]),
     "epi_triangulate_ls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_triangulate_poly": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_correct_matches": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
     "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
     "epi_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -320,10 +322,26 @@ def triangulate(kps, proj, n_view, method="iterative", tolerance=3.0e-5, max_ite
             st = lib.epi_triangulate_ls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
         elif method == "dlt":
             st = lib.epi_triangulate_dlt(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
+        elif method == "poly":
+            st = lib.epi_triangulate_poly(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
         else:
             raise ValueError(method)
     _check(st, "epi_triangulate_" + method)
     return x, status
+
+
+def correct_matches(f, u1, u2):
+    """cv2.correctMatches, batched.  f [G,3,3], u1/u2 [G,J,2] float64 -> (u1', u2') [G,J,2]."""
+    lib = load()
+    f = _dev(f, torch.float64, "f").contiguous()
+    u1, u2 = _dev(u1, torch.float64, "u1").contiguous(), _dev(u2, torch.float64, "u2").contiguous()
+    g, j, _ = u1.shape
+    if f.shape != (g, 3, 3) or u2.shape != u1.shape or u1.shape[2] != 2:
+        raise ValueError("f must be [G,3,3] and u1, u2 [G,J,2]")
+    o1, o2 = torch.empty_like(u1), torch.empty_like(u2)
+    with _on(u1.device):
+        _check(lib.epi_correct_matches(_ptr(f), _ptr(u1), _ptr(u2), g, j, _ptr(o1), _ptr(o2), _stream()), "epi_correct_matches")
+    return o1, o2
 
 
 def reproject_labels(x_world, meta, n_view, patch_w=256.0, patch_h=256.0, rect3d=2000.0, root_joint=0):

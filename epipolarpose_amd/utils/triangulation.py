@@ -46,3 +46,19 @@ def linear_eigen_triangulation(u1, P1, u2, P2, max_coordinate_value=1.e16):
     with np.errstate(invalid="ignore"):
         status = np.max(np.abs(x), axis=1) <= max_coordinate_value
     return x, status
+
+
+def polynomial_triangulation(u1, P1, u2, P2):
+    """triangulation.py:184-220: optimal (Hartley & Sturm) correction of the matches, then the linear-eigen solve."""
+    x, st = triangulate_views(np.stack([u1, u2]), np.stack([P1[0:3, 0:4], P2[0:3, 0:4]]), "poly")
+    return x, st.astype(bool)
+
+
+def correct_matches(F, points1, points2, device=None):
+    """cv2.correctMatches(F, points1, points2) with points [1,N,2] (or [N,2]) -> arrays of the same shape."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    p1, p2 = np.asarray(points1, np.float64), np.asarray(points2, np.float64)
+    f = torch.as_tensor(np.asarray(F, np.float64).reshape(1, 3, 3), device=device)
+    o1, o2 = hip.correct_matches(f, torch.as_tensor(p1.reshape(1, -1, 2), device=device),
+                                 torch.as_tensor(p2.reshape(1, -1, 2), device=device))
+    return o1.cpu().numpy().reshape(p1.shape), o2.cpu().numpy().reshape(p2.shape)

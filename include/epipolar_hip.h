@@ -124,6 +124,19 @@ int epi_triangulate_ls(const void* kps, int kps_stride, const void* P, int dtype
 int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                         void* X, int32_t* status, epi_stream_t stream);
 
+/* triangulation.py:184-220 (polynomial_triangulation), V must be 2: F = [t]_x R from the two projection
+ * matrices (:196-204), the matches moved onto the closest exactly-epipolar pair (cv2.correctMatches, :210;
+ * Hartley & Sturm / HZ Alg. 12.1, the degree-6 polynomial solved by real-root isolation in float64), then
+ * the dlt solve above on the corrected matches (:220).  The reference's fallback to an 8-point F when the
+ * correction returns NaN (:213-217) is not implemented: such points get status 0. */
+int epi_triangulate_poly(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
+                         void* X, int32_t* status, epi_stream_t stream);
+
+/* cv2.correctMatches(F, points1, points2) (called at triangulation.py:210,216), batched: F [G][3][3],
+ * u1/u2/out1/out2 [G][J][2], all f64 device pointers.  out may alias in. */
+int epi_correct_matches(const double* F, const double* u1, const double* u2, int G, int J,
+                        double* out1, double* out2, epi_stream_t stream);
+
 /* img_utils.py:212-243 + prep_h36m.py:177-204 (get_batch_labels_from_global_coords):
  * world joints X [G][J][3] f64 -> per-view pseudo labels label [B][3J] f32, weight [B][3J] f32 (ones). */
 int epi_reproject_labels(const double* X, int G, int V, int J, const epi_view_meta* meta_host,
@@ -131,7 +144,7 @@ int epi_reproject_labels(const double* X, int G, int V, int J, const epi_view_me
                          float* label, float* weight, epi_stream_t stream);
 
 /* img_utils.py:166-190 (self_supervision) fused into ONE launch: decode -> triangulate -> re-project.
- * method: 0 iterative LS (reference), 1 linear LS, 2 DLT.  X_out [G][J][3] f64 may be NULL. */
+ * method: 0 iterative LS (reference), 1 linear LS, 2 DLT, 3 polynomial (V = 2 only).  X_out [G][J][3] f64 may be NULL. */
 int epi_self_supervision(const float* xyz, int G, int V, int J, const epi_view_meta* meta_host,
                          double patch_w, double patch_h, double rect3d, int root_joint,
                          int method, double tolerance, int max_iter,

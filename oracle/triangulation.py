@@ -114,7 +114,8 @@ def triangulate_pairs(kps, projection_matrices, n_view=2, method="iterative"):
     kps = np.asarray(kps, np.float64)
     pm = np.asarray(projection_matrices, np.float64)
     n_group = kps.shape[0] // n_view
-    fn = {"iterative": iterative_ls_triangulation, "ls": linear_ls_triangulation, "dlt": dlt_triangulation}[method]
+    fn = {"iterative": iterative_ls_triangulation, "ls": linear_ls_triangulation, "dlt": dlt_triangulation,
+          "poly": polynomial_triangulation}[method]
     pts = []
     for g in range(n_group):
         idx = [v * n_group + g for v in range(n_view)]
@@ -122,3 +123,82 @@ def triangulate_pairs(kps, projection_matrices, n_view=2, method="iterative"):
         pts.append(x)
     pts = np.asarray(pts)
     return np.concatenate([pts] * n_view, axis=0)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Polynomial ("optimal", Hartley & Sturm) two-view triangulation -- triangulation.py:184-220.
+# The reference delegates the correction of the matches to OpenCV (cv2.correctMatches, calib3d triangulate.cpp, which
+# implements Hartley & Zisserman Algorithm 12.1).  Restated here from the published algorithm; validated by its defining
+# properties (corrected pairs satisfy the epipolar constraint exactly and minimise the summed squared displacement).
+# --------------------------------------------------------------------------------------------------------------------
+def fundamental_from_projections(p1, p2):
+    """triangulation.py:196-204: P_canon = P2_full inv(P1_full);  F = [t]_x R  (np.cross(t, R, axisb=0).T)."""
+    p1f, p2f = np.eye(4), np.eye(4)
+    p1f[0:3, :] = np.asarray(p1, np.float64)[0:3, :]
+    p2f[0:3, :] = np.asarray(p2, np.float64)[0:3, :]
+    pc = p2f @ np.linalg.inv(p1f)
+    return np.cross(pc[0:3, 3], pc[0:3, 0:3], axisb=0).T
+
+
+def correct_matches(f, u1, u2):
+    """cv2.correctMatches(F, points1, points2): move each pair (x1, x2) by the smallest amount (sum of squared distances)
+    onto a pair that satisfies x2^T F x1 = 0 exactly.  HZ Algorithm 12.1, steps (i)-(x).  u1, u2: [N, 2] -> ([N,2], [N,2])."""
+    f = np.asarray(f, np.float64)
+    u1, u2 = np.asarray(u1, np.float64), np.asarray(u2, np.float64)
+    o1, o2 = np.empty_like(u1), np.empty_like(u2)
+    for i in range(u1.shape[0]):
+        t1 = np.array([[1, 0, u1[i, 0]], [0, 1, u1[i, 1]], [0, 0, 1.0]])       # T^-1: takes the origin to the point
+        t2 = np.array([[1, 0, u2[i, 0]], [0, 1, u2[i, 1]], [0, 0, 1.0]])
+        ft = t2.T @ f @ t1                                                      # (ii) F <- T2^-T F T1^-1
+        uu, _, vt = np.linalg.svd(ft)
+        e1, e2 = vt[2], uu[:, 2]                                                # (iii) F e1 = 0, e2^T F = 0
+        e1 = e1 / np.hypot(e1[0], e1[1])
+        e2 = e2 / np.hypot(e2[0], e2[1])
+        r1 = np.array([[e1[0], e1[1], 0], [-e1[1], e1[0], 0], [0, 0, 1.0]])     # (iv)
+        r2 = np.array([[e2[0], e2[1], 0], [-e2[1], e2[0], 0], [0, 0, 1.0]])
+        fr = r2 @ ft @ r1.T                                                     # (v)
+        a, b, c, d, f1, f2 = fr[1, 1], fr[1, 2], fr[2, 1], fr[2, 2], e1[2], e2[2]   # (vi)
+        coeffs = polynomial_g(a, b, c, d, f1, f2)                               # (vii) g(t), degree 6, highest power first
+        roots = np.roots(coeffs)
+        cand = list(np.real(roots))                                             # (viii) cost at the real part of every root ...
+
+        def cost(t):
+            return t * t / (1 + f1 * f1 * t * t) + (c * t + d) ** 2 / ((a * t + b) ** 2 + f2 * f2 * (c * t + d) ** 2)
+        costs = [cost(t) for t in cand]
+        c_inf = 1.0 / (f1 * f1) + c * c / (a * a + f2 * f2 * c * c) if f1 != 0 else np.inf   # ... and at t = infinity
+        k = int(np.argmin(costs))
+        if c_inf < costs[k]:
+            l1 = np.array([f1, 0.0, -1.0])                                      # lambda(t)/t and lambda'(t)/t as t -> infinity
+            l2 = np.array([-f2 * c, a, c])
+        else:
+            t = cand[k]
+            l1 = np.array([t * f1, 1.0, -t])                                    # (ix)
+            l2 = np.array([-f2 * (c * t + d), a * t + b, c * t + d])
+        x1 = np.array([-l1[0] * l1[2], -l1[1] * l1[2], l1[0] ** 2 + l1[1] ** 2])    # closest point of a line to the origin
+        x2 = np.array([-l2[0] * l2[2], -l2[1] * l2[2], l2[0] ** 2 + l2[1] ** 2])
+        x1 = t1 @ r1.T @ x1                                                     # (x) back to the original frames
+        x2 = t2 @ r2.T @ x2
+        o1[i], o2[i] = x1[:2] / x1[2], x2[:2] / x2[2]
+    return o1, o2
+
+
+def polynomial_g(a, b, c, d, f1, f2):
+    """g(t) = t((at+b)^2 + f2^2 (ct+d)^2)^2 - (ad-bc)(1+f1^2 t^2)^2 (at+b)(ct+d)   (HZ eq. 12.7), coefficients t^6 ... t^0."""
+    p = np.polynomial.polynomial
+    atb, ctd = np.array([b, a]), np.array([d, c])                               # ascending powers
+    q = p.polyadd(p.polymul(atb, atb), f2 * f2 * p.polymul(ctd, ctd))
+    g = p.polysub(p.polymul([0.0, 1.0], p.polymul(q, q)),
+                  (a * d - b * c) * p.polymul(p.polymul([1.0, 0.0, f1 * f1], [1.0, 0.0, f1 * f1]), p.polymul(atb, ctd)))
+    g = np.concatenate([g, np.zeros(7 - len(g))])
+    return g[::-1]
+
+
+def polynomial_triangulation(us, ps):
+    """triangulation.py:184-220 (two views): F from the projection matrices, optimal correction of the matches, then the
+    linear-eigen (DLT) triangulation of the corrected points."""
+    us = np.asarray(us, np.float64)
+    ps = np.asarray(ps, np.float64)
+    assert us.shape[0] == 2, "polynomial triangulation is a two-view method"
+    f = fundamental_from_projections(ps[0], ps[1])
+    c1, c2 = correct_matches(f, us[0], us[1])
+    return dlt_triangulation(np.stack([c1, c2]), ps)

@@ -122,6 +122,16 @@ def gen_triangulation():
     u1 = REF_project(pts, cam1)
     x, st = tri.iterative_LS_triangulation(u0, ps[0], u1, ps[1])
     out["behind/u0"], out["behind/u1"], out["behind/x"], out["behind/status"] = u0, u1, x, st
+    # polynomial (optimal) triangulation, triangulation.py:184-220: the reference's F construction + hand-over run live
+    u_n = out["u/noise2"]
+    out["poly/u1"], out["poly/u2"] = u_n[0].reshape(-1, 2), u_n[3].reshape(-1, 2)
+    out["poly/P1"], out["poly/P2"] = ps[0], ps[3]
+    x, st = tri.polynomial_triangulation(out["poly/u1"], ps[0], out["poly/u2"], ps[3])
+    out["poly/X"], out["poly/status"] = x, st
+    p1f, p2f = np.eye(4), np.eye(4)
+    p1f[:3], p2f[:3] = ps[0], ps[3]
+    pc = p2f.dot(np.linalg.inv(p1f))
+    out["poly/F"] = np.cross(pc[0:3, 3], pc[0:3, 0:3], axisb=0).T                 # the expression of triangulation.py:204
     save("triangulation.npz", **out)
 
 

@@ -6,8 +6,9 @@ skipped when ``/root/reference`` is absent (it does not exist on the GPU box).
 The reference's own Python executes unmodified.  What is substituted is third-party code that is not
 installed here and cannot be (no network):
 
-* ``cv2``      -> a stub with float64 NumPy equivalents of the three primitives the hot path calls:
-  ``solve(A, b, dst, DECOMP_SVD)``, ``getAffineTransform`` and ``triangulatePoints``
+* ``cv2``      -> a stub with float64 NumPy equivalents of the primitives the hot path calls:
+  ``solve(A, b, dst, DECOMP_SVD)``, ``getAffineTransform``, ``triangulatePoints``, ``invert`` and
+  ``correctMatches`` (the last by an independent algorithm, see ``_cv2_correct_matches``)
   (OpenCV 4.1.0 documented algorithms; see oracle/triangulation.py, oracle/geometry.py headers).
 * ``easydict`` -> a 10-line attribute dict.        * ``h5py`` -> empty stub (never called here).
 * ``np.int`` / ``np.float`` -> the builtins they aliased before NumPy 1.24 (prep_h36m.py:179-180,202).
@@ -76,6 +77,37 @@ def _cv2_triangulate_points(p1, p2, pts1, pts2):
     return out
 
 
+def _cv2_invert(a, flags=0):
+    return 1.0, np.linalg.inv(np.asarray(a, np.float64))
+
+
+def _cv2_correct_matches(f, points1, points2):
+    """Stand-in for cv2.correctMatches.  DELIBERATELY a different algorithm from the oracle's (and OpenCV's)
+    Hartley-Sturm polynomial: Kanatani/Sugaya/Niitsuma's iterated first-order optimal correction, which converges to the
+    same minimiser of |x1-x1'|^2 + |x2-x2'|^2 subject to x2'^T F x1' = 0.  The golden vectors therefore cross-check the
+    oracle's polynomial solution against an independent solver, through the reference's own glue code."""
+    f = np.asarray(f, np.float64)
+    p1 = np.asarray(points1, np.float64).reshape(-1, 2)
+    p2 = np.asarray(points2, np.float64).reshape(-1, 2)
+    o1, o2 = np.empty_like(p1), np.empty_like(p2)
+    for i in range(len(p1)):
+        x, xp = np.array([p1[i, 0], p1[i, 1], 1.0]), np.array([p2[i, 0], p2[i, 1], 1.0])
+        xh, xph, xt, xpt = x.copy(), xp.copy(), np.zeros(3), np.zeros(3)
+        for _ in range(100):
+            a, b = f.T @ xph, f @ xh                      # gradients of the constraint w.r.t. x and x'
+            a[2] = b[2] = 0.0
+            lam = (xph @ f @ xh + xph @ f @ xt + xpt @ f @ xh) / (a @ a + b @ b)
+            xt_new, xpt_new = lam * a, lam * b
+            done = max(np.abs(xt_new - xt).max(), np.abs(xpt_new - xpt).max()) < 1e-14 * (1 + np.abs(x).max())
+            xt, xpt = xt_new, xpt_new
+            xh, xph = x - xt, xp - xpt
+            if done:
+                break
+        o1[i], o2[i] = xh[:2], xph[:2]
+    shape = np.asarray(points1).shape
+    return o1.reshape(shape), o2.reshape(shape)
+
+
 def _install_stubs():
     if "cv2" not in sys.modules:
         cv2 = types.ModuleType("cv2")
@@ -83,6 +115,8 @@ def _install_stubs():
         cv2.solve = _cv2_solve
         cv2.getAffineTransform = _cv2_get_affine_transform
         cv2.triangulatePoints = _cv2_triangulate_points
+        cv2.invert = _cv2_invert
+        cv2.correctMatches = _cv2_correct_matches
         cv2.__stub__ = True
         sys.modules["cv2"] = cv2
     if "easydict" not in sys.modules:

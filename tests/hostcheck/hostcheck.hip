@@ -1,0 +1,50 @@
+// TEST INFRASTRUCTURE (CPU suite): compiles the float64 per-thread device math of csrc/selfsup.hip for the HOST so that
+// `pytest -m "not gpu"` can compare it with the oracle without a GPU.  Built by tests/hostcheck/build.py into
+// tests/hostcheck/_build/libhostcheck.so; never linked into, loaded by, or shipped with the product library.
+#include "../../epipolarpose_amd/csrc/selfsup.hip"
+
+extern "C" void hostcheck_correct_matches(const double* F, const double* u1, const double* u2, int n, double* o1, double* o2) {
+    double Fm[3][3];
+    for (int i = 0; i < 9; ++i) Fm[i / 3][i % 3] = F[i];
+    for (int i = 0; i < n; ++i) {
+        double a[2] = {u1[2 * i], u1[2 * i + 1]}, b[2] = {u2[2 * i], u2[2 * i + 1]};
+        epi::correct_match(Fm, a, b);
+        o1[2 * i] = a[0]; o1[2 * i + 1] = a[1]; o2[2 * i] = b[0]; o2[2 * i + 1] = b[1];
+    }
+}
+
+extern "C" void hostcheck_fundamental(const double* P1, const double* P2, double* F) {
+    double a[12], b[12], Fm[3][3];
+    for (int i = 0; i < 12; ++i) { a[i] = P1[i]; b[i] = P2[i]; }
+    epi::fundamental_from_P(a, b, Fm);
+    for (int i = 0; i < 9; ++i) F[i] = Fm[i / 3][i % 3];
+}
+
+extern "C" void hostcheck_poly_triangulate(const double* u1, const double* u2, const double* P1, const double* P2, int n, double* X,
+                                           int* status) {
+    double P[2][12], Fm[3][3];
+    for (int i = 0; i < 12; ++i) { P[0][i] = P1[i]; P[1][i] = P2[i]; }
+    epi::fundamental_from_P(P[0], P[1], Fm);
+    for (int i = 0; i < n; ++i) {
+        double u[2][2] = {{u1[2 * i], u1[2 * i + 1]}, {u2[2 * i], u2[2 * i + 1]}}, x[3];
+        epi::correct_match(Fm, u[0], u[1]);
+        status[i] = epi::tri_dlt<2>(u, P, 2, x);
+        X[3 * i] = x[0]; X[3 * i + 1] = x[1]; X[3 * i + 2] = x[2];
+    }
+}
+
+extern "C" int hostcheck_real_roots6(const double* c, double* roots) {
+    double cc[7], r[6];
+    for (int i = 0; i < 7; ++i) cc[i] = c[i];
+    const int n = epi::real_roots_unit<6>(cc, r);
+    for (int i = 0; i < n; ++i) roots[i] = r[i];
+    return n;
+}
+
+extern "C" void hostcheck_svd3(const double* A, double* U, double* s, double* V) {
+    double a[3][3], u[3][3], v[3][3], sv[3];
+    for (int i = 0; i < 9; ++i) a[i / 3][i % 3] = A[i];
+    epi::svd3(a, u, sv, v);
+    for (int i = 0; i < 9; ++i) { U[i] = u[i / 3][i % 3]; V[i] = v[i / 3][i % 3]; }
+    for (int i = 0; i < 3; ++i) s[i] = sv[i];
+}

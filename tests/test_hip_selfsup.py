@@ -119,6 +119,13 @@ def test_reprojection_and_fused_ss_golden(golden, dev, tag, n_group, j):
     np.testing.assert_allclose(xw.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(lab3.cpu().numpy(), lab2.cpu().numpy(), rtol=0, atol=1e-7)
     assert torch.equal(wt3, torch.ones_like(wt3))
+    # the same fused launch with the polynomial (optimal) two-view solver == staged poly solve == oracle pipeline
+    lab4, _, xw4 = hip.self_supervision(xyz, meta, 2, "poly", want_world=True)
+    x4, _ = hip.triangulate(kps, meta.tensors["projection_matrix"], 2, "poly")
+    np.testing.assert_allclose(xw4.cpu().numpy(), x4.cpu().numpy(), rtol=0, atol=1e-7)
+    ref_x = o_tri.triangulate_pairs(kps.cpu().numpy(), sc.meta["projection_matrix"], n_view=2, method="poly")
+    np.testing.assert_allclose(xw4.cpu().numpy(), ref_x[:n_group], atol=1e-5)
+    np.testing.assert_allclose(lab4.cpu().numpy(), o_geo.labels_from_global_coords(ref_x, sc.meta)[0], atol=1e-6)
 
 
 def test_self_supervision_from_logits_golden(golden, dev):
@@ -185,3 +192,91 @@ def test_bulk_properties(dev):
     a, _ = hip.triangulate(noisy, pm, v_n, "dlt")
     b, _ = hip.triangulate(noisy, pm * 3.7, v_n, "dlt")
     assert (a - b).abs().max().item() <= 1e-6
+
+
+# ------------------------------------------------------------------ polynomial (optimal) two-view triangulation
+def test_polynomial_triangulation_golden_and_reference_signature(golden, dev):
+    """triangulation.py:184-220 -- golden vectors from the live reference (tests/golden/make_golden.py)."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.utils import triangulation as tri
+    g = golden("triangulation")
+    x, st = tri.polynomial_triangulation(g["poly/u1"], g["poly/P1"], g["poly/u2"], g["poly/P2"])
+    np.testing.assert_allclose(x, g["poly/X"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_array_equal(st, g["poly/status"].astype(bool))
+    # cv2.correctMatches mirror: [1, N, 2] in and out; result is exactly epipolar and equals the oracle's
+    c1, c2 = tri.correct_matches(g["poly/F"], g["poly/u1"][None], g["poly/u2"][None])
+    assert c1.shape == (1,) + g["poly/u1"].shape
+    o1, o2 = o_tri.correct_matches(g["poly/F"], g["poly/u1"], g["poly/u2"])
+    np.testing.assert_allclose(c1[0], o1, atol=1e-9)
+    np.testing.assert_allclose(c2[0], o2, atol=1e-9)
+    # f32 storage (arithmetic stays f64): inputs rounded to f32 move the answer by ~1e-4 px * depth/f
+    us = torch.from_numpy(np.stack([g["poly/u1"], g["poly/u2"]])).to(dev)
+    pp = torch.from_numpy(np.stack([g["poly/P1"], g["poly/P2"]])).to(dev)
+    x32, _ = hip.triangulate(us.float(), pp.float(), 2, "poly")
+    np.testing.assert_allclose(x32[0].double().cpu().numpy(), g["poly/X"], atol=0.5)
+    with pytest.raises(RuntimeError):
+        hip.triangulate(torch.cat([us, us[:1]]), torch.cat([pp, pp[:1]]), 3, "poly")        # two views only
+
+
+@pytest.mark.parametrize("noise", [0.0, 1.0, 20.0])
+def test_polynomial_triangulation_vs_oracle_batched(dev, noise):
+    from epipolarpose_amd import hip
+    sc = scene(6, 17, 321, n_view=2, noise_px=noise)
+    kps = torch.from_numpy(sc.kps_img).to(dev)
+    pm = torch.from_numpy(sc.meta["projection_matrix"]).to(dev)
+    x, st = hip.triangulate(kps, pm, 2, "poly")
+    for grp in range(6):
+        idx = [grp, 6 + grp]
+        ref, rst = o_tri.polynomial_triangulation(sc.kps_img[idx][:, :, :2], sc.meta["projection_matrix"][idx])
+        np.testing.assert_allclose(x[grp].cpu().numpy(), ref, atol=1e-4 if noise == 0.0 else 1e-6)
+        np.testing.assert_array_equal(st[grp].cpu().numpy().astype(bool), rst)
+
+
+def test_polynomial_bulk_properties(dev):
+    """2^18 pairs: corrected matches are exactly epipolar, at the Sampson distance to first order, invariant to the
+    scale of F; poly == dlt on noise-free input; swapping the two views gives the same 3-D point."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.synthetic import make_cameras, project
+    g_n, j = 1 << 14, 16
+    gen = torch.Generator().manual_seed(9)
+    world = torch.randn((g_n, j, 3), generator=gen, dtype=torch.float64) * 300 + torch.tensor([0.0, 0.0, 900.0], dtype=torch.float64)
+    cams = make_cameras(4)
+    ca, cb = cams[0], cams[2]
+    ua = torch.from_numpy(project(world.reshape(-1, 3).numpy(), ca)[0]).reshape(g_n, j, 2)
+    ub = torch.from_numpy(project(world.reshape(-1, 3).numpy(), cb)[0]).reshape(g_n, j, 2)
+    pa, pb = torch.from_numpy(ca["projection_matrix"]), torch.from_numpy(cb["projection_matrix"])
+    f = torch.from_numpy(o_tri.fundamental_from_projections(pa.numpy(), pb.numpy()))
+    kps = torch.cat([ua, ub]).to(dev)
+    pm = torch.cat([pa.expand(g_n, 3, 4), pb.expand(g_n, 3, 4)]).contiguous().to(dev)
+    xp, st = hip.triangulate(kps, pm, 2, "poly")
+    xd, _ = hip.triangulate(kps, pm, 2, "dlt")
+    assert (st == 1).all()
+    assert (xp - world.to(dev)).abs().max().item() <= 1e-3 and (xp - xd).abs().max().item() <= 1e-3
+    noisy = kps + torch.randn(kps.shape, generator=gen, dtype=torch.float64).to(dev) * 3.0
+    n1, n2 = noisy[:g_n].contiguous(), noisy[g_n:].contiguous()
+    fm = f.to(dev).expand(g_n, 3, 3).contiguous()
+    c1, c2 = hip.correct_matches(fm, n1, n2)
+
+    def hom(u):
+        return torch.cat([u, torch.ones_like(u[..., :1])], dim=-1)
+    fd = f.to(dev)
+    resid = torch.einsum("gji,ik,gjk->gj", hom(c2), fd, hom(c1)).abs() / fd.abs().max()
+    assert resid.max().item() < 1e-9 * (1 + noisy.abs().max().item()) ** 2
+    moved = ((c1 - n1) ** 2).sum(-1) + ((c2 - n2) ** 2).sum(-1)
+    e = torch.einsum("gji,ik,gjk->gj", hom(n2), fd, hom(n1))
+    fx1, ftx2 = hom(n1) @ fd.T, hom(n2) @ fd
+    sampson = e ** 2 / (fx1[..., 0] ** 2 + fx1[..., 1] ** 2 + ftx2[..., 0] ** 2 + ftx2[..., 1] ** 2)
+    rel = (moved - sampson).abs() / (sampson + 1e-12)           # Sampson = first-order approximation of the same distance
+    assert rel.median().item() <= 1e-3 and (rel <= 5e-2).double().mean().item() >= 0.98
+    s1, s2 = hip.correct_matches((fm * -41.0).contiguous(), n1, n2)
+    assert (s1 - c1).abs().max().item() <= 1e-8 and (s2 - c2).abs().max().item() <= 1e-8
+    a, _ = hip.triangulate(noisy, pm, 2, "poly")
+    b, _ = hip.triangulate(torch.cat([n2, n1]), torch.cat([pm[g_n:], pm[:g_n]]).contiguous(), 2, "poly")
+    assert (a - b).abs().max().item() <= 1e-6
+    # the optimal method is never worse than the linear one in reprojection error (it minimises it over epipolar pairs)
+    def reproj(x):
+        ra = torch.from_numpy(project(x.reshape(-1, 3).cpu().numpy(), ca)[0]).reshape(g_n, j, 2).to(dev)
+        rb = torch.from_numpy(project(x.reshape(-1, 3).cpu().numpy(), cb)[0]).reshape(g_n, j, 2).to(dev)
+        return ((ra - n1) ** 2).sum(-1) + ((rb - n2) ** 2).sum(-1)
+    d, _ = hip.triangulate(noisy, pm, 2, "dlt")
+    assert (reproj(a) <= reproj(d) + 1e-6).all()

@@ -1,0 +1,157 @@
+"""CPU: polynomial (Hartley & Sturm) triangulation -- the oracle's defining properties, the reference's own glue around
+cv2.correctMatches run live at golden-generation time, and the DEVICE math compiled for the host (tests/hostcheck) against
+the oracle.  The GPU run of the same kernels is tests/test_hip_selfsup.py."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import triangulation as o_tri
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "hostcheck"))
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    import build as hostcheck_build
+    return ctypes.CDLL(hostcheck_build.build())
+
+
+def _scene(seed, n=64, noise=2.0, pair=(0, 1)):
+    from epipolarpose_amd.synthetic import make_cameras, project
+    cams = make_cameras(4)
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 300, size=(n, 3)) + [0, 0, 900]
+    a, b = pair
+    p1 = np.ascontiguousarray(cams[a]["projection_matrix"], dtype=np.float64)
+    p2 = np.ascontiguousarray(cams[b]["projection_matrix"], dtype=np.float64)
+    u1 = np.ascontiguousarray(project(x, cams[a])[0] + rng.normal(0, noise, (n, 2)))
+    u2 = np.ascontiguousarray(project(x, cams[b])[0] + rng.normal(0, noise, (n, 2)))
+    return x, u1, u2, p1, p2
+
+
+def _h(u):
+    return np.concatenate([u, np.ones((len(u), 1))], axis=1)
+
+
+def _epi_residual(f, u1, u2):
+    """distance-like residual: |x2^T F x1| / |F|"""
+    return np.abs(np.einsum("ni,ij,nj->n", _h(u2), f, _h(u1))) / np.abs(f).max()
+
+
+@pytest.mark.parametrize("pair", [(0, 1), (0, 3), (1, 2)])
+def test_oracle_correction_is_epipolar_and_minimal(pair):
+    _, u1, u2, p1, p2 = _scene(3, n=24, noise=3.0, pair=pair)
+    f = o_tri.fundamental_from_projections(p1, p2)
+    c1, c2 = o_tri.correct_matches(f, u1, u2)
+    assert _epi_residual(f, c1, c2).max() < 1e-9 * (1 + np.abs(u1).max()) ** 2
+    moved = ((c1 - u1) ** 2).sum(1) + ((c2 - u2) ** 2).sum(1)
+    # minimality (HZ 12.5): no exactly-epipolar pair is closer.  Candidates: for y1 near c1, the closest point of the
+    # epipolar line F y1 to u2.
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        y1 = c1 + rng.normal(0, 0.5, c1.shape)
+        line = _h(y1) @ f.T                                   # l2 = F y1
+        nrm = np.hypot(line[:, 0], line[:, 1])
+        dist = (line * _h(u2)).sum(1) / nrm
+        y2 = u2 - (dist / nrm)[:, None] * line[:, :2]
+        cand = ((y1 - u1) ** 2).sum(1) + ((y2 - u2) ** 2).sum(1)
+        assert (cand >= moved - 1e-9).all()
+    # the Sampson correction is the first-order approximation of the same quantity
+    e = np.einsum("ni,ij,nj->n", _h(u2), f, _h(u1))
+    fx1, ftx2 = _h(u1) @ f.T, _h(u2) @ f
+    sampson = e ** 2 / (fx1[:, 0] ** 2 + fx1[:, 1] ** 2 + ftx2[:, 0] ** 2 + ftx2[:, 1] ** 2)
+    np.testing.assert_allclose(moved, sampson, rtol=5e-2)
+
+
+def test_oracle_noise_free_matches_stay_put_and_scale_invariance():
+    x, u1, u2, p1, p2 = _scene(5, n=16, noise=0.0)
+    f = o_tri.fundamental_from_projections(p1, p2)
+    assert _epi_residual(f, u1, u2).max() < 1e-9 * (1 + np.abs(u1).max()) ** 2      # F really is the pair's fundamental matrix
+    c1, c2 = o_tri.correct_matches(f, u1, u2)
+    np.testing.assert_allclose(c1, u1, atol=1e-5)
+    np.testing.assert_allclose(c2, u2, atol=1e-5)
+    xt, st = o_tri.polynomial_triangulation(np.stack([u1, u2]), np.stack([p1, p2]))
+    np.testing.assert_allclose(xt, x, atol=1e-3)
+    assert st.all()
+    _, n1, n2, _, _ = _scene(6, n=16, noise=2.0)
+    a1, a2 = o_tri.correct_matches(f, n1, n2)
+    b1, b2 = o_tri.correct_matches(-37.5 * f, n1, n2)
+    np.testing.assert_allclose(a1, b1, atol=1e-8)
+    np.testing.assert_allclose(a2, b2, atol=1e-8)
+
+
+def test_reference_polynomial_triangulation_golden(golden):
+    """The reference's polynomial_triangulation run live (tests/golden/make_golden.py) -- its own F construction and
+    hand-over to linear_eigen_triangulation -- with cv2.invert / cv2.correctMatches / cv2.triangulatePoints supplied by
+    the shims (OpenCV itself is not in this image: "parity unpinned" at the OpenCV layer, see oracle/__init__.py)."""
+    g = golden("triangulation")
+    x, st = o_tri.polynomial_triangulation(np.stack([g["poly/u1"], g["poly/u2"]]), np.stack([g["poly/P1"], g["poly/P2"]]))
+    np.testing.assert_allclose(x, g["poly/X"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_array_equal(st, g["poly/status"].astype(bool))
+    np.testing.assert_allclose(o_tri.fundamental_from_projections(g["poly/P1"], g["poly/P2"]), g["poly/F"], rtol=1e-12, atol=1e-9)
+
+
+# ------------------------------------------------------------------ device math compiled for the host
+def test_hostcheck_real_root_isolation(hostlib):
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        kind = trial % 4
+        if kind == 0:
+            r = rng.uniform(-3, 3, 6)
+        elif kind == 1:                                         # two complex pairs
+            r = np.concatenate([rng.uniform(-2, 2, 2), [0.3 + 0.4j, 0.3 - 0.4j, -1.5 + 0.1j, -1.5 - 0.1j]])
+        elif kind == 2:                                         # widely spread magnitudes
+            r = rng.uniform(-1, 1, 6) * 10.0 ** rng.uniform(-4, 4, 6)
+        else:                                                   # degree drops (leading coefficients vanish)
+            r = rng.uniform(-0.9, 0.9, 4)
+        c = np.real(np.poly(r))[::-1].copy()
+        c = np.concatenate([c, np.zeros(7 - len(c))]) * 10.0 ** rng.uniform(-3, 3)
+        out = np.zeros(6)
+        n = hostlib.hostcheck_real_roots6(_dp(c), _dp(out))
+        want = np.sort(np.real(r[(np.abs(np.imag(r)) < 1e-12) & (np.abs(np.real(r)) <= 1)]))
+        assert n == len(want), (trial, out[:n], want)
+        np.testing.assert_allclose(np.sort(out[:n]), want, rtol=1e-9, atol=1e-13)
+
+
+def test_hostcheck_svd3(hostlib):
+    rng = np.random.default_rng(2)
+    for trial in range(50):
+        a = rng.normal(size=(3, 3))
+        if trial % 3 == 0:
+            a[2] = 0.3 * a[0] - 2.0 * a[1]                      # rank 2, as a fundamental matrix
+        a = np.ascontiguousarray(a)
+        u, s, v = np.zeros(9), np.zeros(3), np.zeros(9)
+        hostlib.hostcheck_svd3(_dp(a), _dp(u), _dp(s), _dp(v))
+        u, v = u.reshape(3, 3), v.reshape(3, 3)
+        np.testing.assert_allclose(s, np.linalg.svd(a, compute_uv=False), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(v.T @ v, np.eye(3), atol=1e-13)
+        np.testing.assert_allclose(a @ v, u * s, atol=1e-13)
+
+
+@pytest.mark.parametrize("pair", [(0, 1), (0, 3), (1, 2), (2, 3)])
+@pytest.mark.parametrize("noise", [0.0, 0.5, 5.0, 50.0])
+def test_hostcheck_polynomial_triangulation_matches_oracle(hostlib, pair, noise):
+    x, u1, u2, p1, p2 = _scene(7, n=128, noise=noise, pair=pair)
+    f = np.ascontiguousarray(o_tri.fundamental_from_projections(p1, p2))
+    fd = np.zeros(9)
+    hostlib.hostcheck_fundamental(_dp(p1), _dp(p2), _dp(fd))
+    np.testing.assert_allclose(fd.reshape(3, 3), f, rtol=0, atol=1e-13 * np.abs(f).max())
+    c1, c2 = o_tri.correct_matches(f, u1, u2)
+    d1, d2 = np.zeros_like(u1), np.zeros_like(u2)
+    hostlib.hostcheck_correct_matches(_dp(f), _dp(u1), _dp(u2), len(u1), _dp(d1), _dp(d2))
+    tol = 1e-5 if noise == 0.0 else 1e-9                        # noise-free: t = 0 is a multiple root, ill-conditioned for both
+    np.testing.assert_allclose(d1, c1, atol=tol)
+    np.testing.assert_allclose(d2, c2, atol=tol)
+    assert _epi_residual(f, d1, d2).max() < 1e-9 * (1 + np.abs(u1).max()) ** 2
+    xo, so = o_tri.polynomial_triangulation(np.stack([u1, u2]), np.stack([p1, p2]))
+    xd, sd = np.zeros_like(xo), np.zeros(len(u1), np.int32)
+    hostlib.hostcheck_poly_triangulate(_dp(u1), _dp(u2), _dp(p1), _dp(p2), len(u1), _dp(xd), _dp(sd))
+    np.testing.assert_allclose(xd, xo, atol=1e-4 if noise == 0.0 else 1e-6)
+    np.testing.assert_array_equal(sd.astype(bool), so)
