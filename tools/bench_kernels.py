@@ -110,6 +110,17 @@ def bench_tri():
         t = timeit(lambda: hip.triangulate(kps, pm, v_n, method), iters=5, warm=1)
         print("triangulate %-9s f32 storage 2^20 groups x 4 views: %.3f ms  %7.1f GB/s (%.3f of HBM peak)" % (
             method, t, nbytes / t / 1e6, nbytes / t / 1e6 / HBM), flush=True)
+    # polynomial (optimal) two-view solver: compute bound (root isolation, ~20k f64 flops per point), realistic 2 px noise
+    from epipolarpose_amd.synthetic import project
+    g2 = 1 << 16
+    cams = make_cameras(2)
+    world = torch.randn(g2 * j, 3, dtype=torch.float64) * 300 + torch.tensor([0.0, 0.0, 900.0], dtype=torch.float64)
+    kp2 = torch.cat([torch.from_numpy(project(world.numpy(), c)[0]).reshape(g2, j, 2) for c in cams]) + torch.randn(2 * g2, j, 2) * 2.0
+    kp2 = kp2.to(DEV)
+    pm2 = torch.cat([torch.from_numpy(c["projection_matrix"]).expand(g2, 3, 4) for c in cams]).contiguous().to(DEV)
+    for method in ("dlt", "poly"):
+        t = timeit(lambda: hip.triangulate(kp2, pm2, 2, method), iters=5, warm=1)
+        print("triangulate %-9s f64 2^16 groups x 2 views x 17 joints: %.3f ms  %6.1f Mpoints/s" % (method, t, g2 * j / t / 1e3), flush=True)
 
 
 def bench_bn():
