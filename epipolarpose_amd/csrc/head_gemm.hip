@@ -12,14 +12,29 @@
 // MFMAs, double-buffered LDS (64 KiB -> 2 workgroups / CU), 16-byte chunks XOR-swizzled on the SOURCE address so the
 // lane-linear DMA image is conflict-free for the 16-lane ds_read_b128 groups.
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace epi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;
+constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;      // the TN kernel's tile (and the small NT tile)
 constexpr int TILE_BYTES = GBM * GBK * 2;          // 16 KiB per operand tile
+
+// NT kernel tile configurations: 2 x WN waves, each wave TM x 2 MFMA tiles (32x32).
+//   small: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups / CU)   -- short K, few rows, ragged N
+//   big:   256 x 256, 8 waves, 128 KiB LDS (1 workgroup / CU)   -- twice the MFMA work per staged byte and per DMA
+//          instruction, 1.5x less LDS read traffic per MFMA, coalesced (LDS-transposed) epilogue
+template <int TM_, int WN_> struct GemmCfg {
+    static constexpr int TM = TM_, WN = WN_, NW = 2 * WN_, THREADS = 64 * NW;
+    static constexpr int BM = 2 * TM_ * 32, BN = WN_ * 64;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    static_assert(BM / NW == 32 && BN / NW == 32, "each wave stages 32 rows of either operand");
+};
+typedef GemmCfg<2, 2> CfgSmall;
+typedef GemmCfg<4, 4> CfgBig;
 
 struct GemmGather {        // maps GEMM row m / K tile to an NHWC source pixel
     int enabled;           // 0: plain A[m*lda + k]
@@ -68,11 +83,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-template <bool OUT_F32>
-__global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
+template <bool OUT_F32, typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_kernel(GemmArgs p) {
+    constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
     const int tiles_n = (p.N + GBN - 1) / GBN;
     // logical id: tile_n fastest, then tile_m, then split, then phase -> neighbours share the A panel (and B)
     const int total_wg = gridDim.x * gridDim.y * gridDim.z;
@@ -117,8 +133,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     auto load_tiles = [&](int k0, int buf) {
         int tap = 0, c0 = k0;
         if (p.ga.enabled) { tap = k0 / p.ga.Cs; c0 = k0 - tap * p.ga.Cs; }
-        char* a_s = smem + buf * 2 * TILE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
-        char* b_s = a_s + TILE_BYTES;
+        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
+        char* b_s = a_s + Cfg::A_BYTES;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             bool ok = a_ok[ps];
@@ -144,9 +160,9 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -159,22 +175,25 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * GBK, buf ^ 1);   // next tile's DMA flies during the MFMAs
-        const char* a_s = smem + buf * 2 * TILE_BYTES;
-        const char* b_s = a_s + TILE_BYTES;
+        const char* a_s = smem + buf * Cfg::STAGE_BYTES;
+        const char* b_s = a_s + Cfg::A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[TM], bfr[2];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const uint4v va = *reinterpret_cast<const uint4v*>(a_s + lds_off(wm * (TM * 32) + t * 32 + frow, ks * 2 + fhalf));
+                af[t] = __builtin_bit_cast(bf16x8, va);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const uint4v va = *reinterpret_cast<const uint4v*>(a_s + lds_off(wm * 64 + t * 32 + frow, ks * 2 + fhalf));
                 const uint4v vb = *reinterpret_cast<const uint4v*>(b_s + lds_off(wn * 64 + t * 32 + frow, ks * 2 + fhalf));
-                af[t] = __builtin_bit_cast(bf16x8, va);
                 bfr[t] = __builtin_bit_cast(bf16x8, vb);
             }
             // operands swapped: D[i][j] with i = output column n (register rows), j = output row m (lane & 31),
             // so that a lane ends up holding 4 consecutive columns of one row -> 8-byte bf16 stores.
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[tj], af[ti], acc[ti][tj], 0, 0, 0);
@@ -182,13 +201,13 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*64 + ti*32 + (lane & 31),
+    // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*TM*32 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
     if (gridDim.y > 1) {        // split-K partial: fp32, plain rows, finished by splitk_finish_kernel
         float* slab = p.slabs + ((long long)split_id * gridDim.z + phase) * p.M * p.N;
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            const int m = m0 + wm * 64 + ti * 32 + frow;
+        for (int ti = 0; ti < TM; ++ti) {
+            const int m = m0 + wm * (TM * 32) + ti * 32 + frow;
             if (m >= p.M) continue;
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj)
@@ -205,9 +224,57 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_kernel(GemmArgs p) {
         }
         return;
     }
+    if constexpr (!OUT_F32 && Cfg::TM == 4) {
+        // Coalesced epilogue: the wave parks its 128 x 64 bf16 sub-tile in its own 16 KiB of the (now idle) staging LDS
+        // -- 8-byte units XOR-swizzled by (row & 15) so the 16 rows of a ds_write_b64 lane group hit 16 different bank
+        // pairs -- and writes it out as whole 128-byte row segments (8 lanes x 16 B per row, 8 rows per instruction)
+        // instead of 8-byte pieces of 32 different rows.  The main loop's final barrier already separated the last
+        // fragment reads from these writes; afterwards each wave only touches its own region (LDS ops of a wave are ordered).
+        char* mine = smem + wid * 16384;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-        const int m = m0 + wm * 64 + ti * 32 + frow;
+        for (int ti = 0; ti < TM; ++ti) {
+            const int row = ti * 32 + frow;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + tj * 32 + 8 * q + 4 * fhalf;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[ti][tj][4 * q + e];
+                        if (p.bias && n + e < p.N) v[e] += p.bias[n + e];
+                    }
+                    uint2 t;
+                    t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    const int unit = tj * 8 + 2 * q + fhalf;
+                    *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
+                }
+        }
+        const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (lane >> 3), sw = row & 15;
+            const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
+            const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
+            const int m = m0 + wm * (TM * 32) + row;
+            if (m >= p.M || n >= p.N) continue;
+            long long orow = m;
+            if (p.sc.enabled) {
+                const int hw = p.sc.Hg * p.sc.Wg;
+                const int b = m / hw, rem = m - b * hw;
+                const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
+                orow = ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
+            }
+            uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+            *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
+        }
+        return;
+    }
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+        const int m = m0 + wm * (TM * 32) + ti * 32 + frow;
         const bool row_ok = m < p.M;
         long long orow = m;
         if (p.sc.enabled) {
@@ -284,22 +351,86 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
 
 using namespace epi;
 
-// split so that at least ~512 workgroups exist, each split keeping >= 512 of K
-static int gemm_pick_split(long long tiles, int nphase, int K) {
-    const long long wgs = tiles * nphase;
-    if (wgs >= 384) return 1;
-    int nsplit = (int)((512 + wgs - 1) / wgs);
-    const int max_split = K / 512 > 0 ? K / 512 : 1;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit > 16) nsplit = 16;
-    return nsplit < 1 ? 1 : nsplit;
+struct GemmPlan { bool big; int nsplit, kps; long long tiles; };
+
+// EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
+static int gemm_tile_override() {
+    static const int v = [] {
+        const char* e = getenv("EPI_GEMM_TILE");
+        if (!e) return 0;
+        return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
+    }();
+    return v;
+}
+
+// Split-K factor for one tile configuration: split until every CU has a workgroup (small tile: two), each split
+// keeping >= 512 of K.
+static GemmPlan gemm_plan_cfg(bool big, int M, int N, int K, int nphase) {
+    GemmPlan pl;
+    pl.big = big;
+    const int bm = big ? 256 : 128, bn = big ? 256 : 128;
+    pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const long long wgs = pl.tiles * nphase;
+    const long long enough = big ? 200 : 384, target = big ? 256 : 512;
+    int nsplit = 1;
+    if (wgs < enough) {
+        nsplit = (int)((target + wgs - 1) / wgs);
+        const int max_split = K / 512 > 0 ? K / 512 : 1;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit > 16) nsplit = 16;
+        if (nsplit < 1) nsplit = 1;
+    }
+    if (N % 4) nsplit = 1;
+    pl.kps = K;
+    if (nsplit > 1) {
+        pl.kps = ((K + nsplit - 1) / nsplit + GBK - 1) / GBK * GBK;
+        nsplit = (K + pl.kps - 1) / pl.kps;
+    }
+    pl.nsplit = nsplit;
+    return pl;
+}
+
+// Tile configuration.  big (256^2, 1 workgroup / CU) needs 16-byte output row segments, columns that fill 256-wide
+// tiles, and a deep K loop per workgroup: either enough tiles to fill the chip unsplit (K >= 512), or >= 1024 of K
+// left per split (measured on MI355X: below that the 128^2 tile at 2 workgroups / CU hides the pipeline prologue better).
+static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32) {
+    const int ov = gemm_tile_override();
+    const bool can_big = !out_f32 && N % 8 == 0 && ldc % 8 == 0;
+    if (can_big && ov != 1) {
+        const GemmPlan pb = gemm_plan_cfg(true, M, N, K, nphase);
+        const int tiles_n = (N + 255) / 256;
+        const bool fills = M >= 256 && tiles_n * 256 <= N + N / 4;
+        const bool deep = pb.nsplit == 1 ? (K >= 512 && pb.tiles * nphase >= 200) : pb.kps >= 1024;
+        if (ov == 2 || (fills && deep)) return pb;
+    }
+    return gemm_plan_cfg(false, M, N, K, nphase);
 }
 
 extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
     if (M <= 0 || N <= 0 || K <= 0 || nphase <= 0) return 0;
-    const long long tiles = (long long)((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
-    const int nsplit = gemm_pick_split(tiles, nphase, K);
-    return nsplit > 1 ? (size_t)nsplit * nphase * M * N * sizeof(float) : 0;
+    // the larger of the two configurations' needs (the output stride / dtype are not known here)
+    size_t need = 0;
+    for (int f32 = 0; f32 < 2; ++f32) {
+        const GemmPlan pl = gemm_plan(M, N, K, 8, nphase, f32 != 0);
+        if (pl.nsplit > 1) need = std::max(need, (size_t)pl.nsplit * nphase * M * N * sizeof(float));
+    }
+    const GemmPlan ps = gemm_plan(M, N, K, 4, nphase, false);
+    if (ps.nsplit > 1) need = std::max(need, (size_t)ps.nsplit * nphase * M * N * sizeof(float));
+    return need;
+}
+
+template <bool OUT_F32, typename Cfg>
+static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
+    const size_t lds = 2 * Cfg::STAGE_BYTES;
+    if (lds > 65536) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return EPI_ERR_LAUNCH;
+    }
+    const dim3 grid((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)nphase);
+    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg>), grid, dim3(Cfg::THREADS), lds, st, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
 }
 
 static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -307,30 +438,23 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
-    const long long tiles = (long long)((a.M + GBM - 1) / GBM) * ((a.N + GBN - 1) / GBN);
-    if (tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
-    int nsplit = gemm_pick_split(tiles, nphase, a.K);
-    if (a.N % 4) nsplit = 1;
-    int kps = a.K;
-    if (nsplit > 1) {
-        kps = ((a.K + nsplit - 1) / nsplit + GBK - 1) / GBK * GBK;
-        nsplit = (a.K + kps - 1) / kps;
-    }
-    if (nsplit > 1) {
-        if (!workspace || (size_t)nsplit * nphase * a.M * a.N * sizeof(float) > workspace_bytes) return EPI_ERR_WORKSPACE;
+    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
+    if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+    if (pl.nsplit > 1) {
+        if (!workspace || (size_t)pl.nsplit * nphase * a.M * a.N * sizeof(float) > workspace_bytes) return EPI_ERR_WORKSPACE;
         a.slabs = (float*)workspace;
     }
-    a.k_per_split = kps;
-    const size_t lds = 4 * TILE_BYTES;
-    const dim3 grid((unsigned)tiles, (unsigned)nsplit, (unsigned)nphase);
-    if (out_f32) hipLaunchKernelGGL(head_gemm_kernel<true>, grid, dim3(GTHREADS), lds, st, a);
-    else hipLaunchKernelGGL(head_gemm_kernel<false>, grid, dim3(GTHREADS), lds, st, a);
-    EPI_CHECK_LAUNCH();
-    if (nsplit > 1) {
+    a.k_per_split = pl.kps;
+    int rc;
+    if (pl.big) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
+    else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
+    else rc = launch_gemm_cfg<false, CfgSmall>(a, pl, nphase, st);
+    if (rc != EPI_OK) return rc;
+    if (pl.nsplit > 1) {
         const long long n = (long long)nphase * a.M * (a.N >> 2);
         const dim3 fg((unsigned)((n + 255) / 256));
-        if (out_f32) hipLaunchKernelGGL(splitk_finish_kernel<true>, fg, dim3(256), 0, st, a.slabs, nsplit, nphase, a);
-        else hipLaunchKernelGGL(splitk_finish_kernel<false>, fg, dim3(256), 0, st, a.slabs, nsplit, nphase, a);
+        if (out_f32) hipLaunchKernelGGL(splitk_finish_kernel<true>, fg, dim3(256), 0, st, a.slabs, pl.nsplit, nphase, a);
+        else hipLaunchKernelGGL(splitk_finish_kernel<false>, fg, dim3(256), 0, st, a.slabs, pl.nsplit, nphase, a);
         EPI_CHECK_LAUNCH();
     }
     return EPI_OK;
