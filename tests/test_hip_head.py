@@ -36,7 +36,7 @@ def close(got, ref, rel=1.2e-2, outliers=0.0):
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 1088, 256), (1000, 200, 128), (4096, 256, 1088), (77, 36, 192), (512, 256, 24), (300, 40, 200),
                                    # 256x256-tile configuration: ragged M and N, K tail, split-K (few tiles) and no split (many tiles)
-                                   (700, 456, 576), (300, 248, 520), (65536, 256, 512), (2048, 1024, 2048)])
+                                   (5164, 2528, 520), (2000, 2040, 4104), (65536, 256, 512), (2048, 1024, 2048), (700, 456, 576)])
 def test_gemm_vs_torch(dev, m, n, k):
     from epipolarpose_amd import hip
     a = rnd((m, k), dev, 1).to(torch.bfloat16)
@@ -57,16 +57,16 @@ def test_gemm_identity_asymmetric(dev):
     c = hip.gemm_bf16(a, bt, out_dtype=torch.float32)
     assert torch.equal(c, bt.float().t().contiguous())
     # the 256x256-tile configuration (K >= 512, bf16 output through the LDS-transposed epilogue), ragged in M and N
-    a = torch.eye(520, 512, device=dev, dtype=torch.bfloat16)
-    bt = (torch.arange(504 * 512, device=dev).reshape(504, 512) % 251).to(torch.bfloat16)
+    a = torch.eye(5200, 512, device=dev, dtype=torch.bfloat16)
+    bt = (torch.arange(2528 * 512, device=dev).reshape(2528, 512) % 251).to(torch.bfloat16)
     c = hip.gemm_bf16(a, bt)
-    want = torch.zeros(520, 504, device=dev)
+    want = torch.zeros(5200, 2528, device=dev)
     want[:512] = bt.float().t()
     assert c.dtype == torch.bfloat16 and torch.equal(c.float(), want)
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(2, 8, 8, 128, 64), (3, 5, 7, 64, 32), (1, 16, 16, 256, 256), (2, 4, 4, 2048, 256),
-                                            (4, 16, 16, 256, 256), (14, 32, 32, 128, 256)])
+                                            (4, 16, 16, 256, 256), (14, 32, 32, 128, 256), (4, 32, 32, 1024, 256)])
 def test_deconv_fwd_bwd_data_vs_torch(dev, b, h, w, cin, cout):
     from epipolarpose_amd import hip
     x = rnd((b, cin, h, w), dev, 4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
