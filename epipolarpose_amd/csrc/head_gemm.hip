@@ -14,6 +14,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace epi {
 
@@ -83,7 +84,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-template <bool OUT_F32, typename Cfg>
+enum { A_PLAIN = 0, A_GATHER = 1, A_DECONV = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
+
+template <bool OUT_F32, typename Cfg, int MODE>
 __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_kernel(GemmArgs p) {
     constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
@@ -99,25 +102,26 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
     const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
     const int ph = phase >> 1, pw = phase & 1;
-    const unsigned short* Bt = p.Bt + (p.deconv_phases ? (long long)phase * p.N * p.ldb : 0);
-    const int sc_oy = p.deconv_phases ? ph : p.sc.oy, sc_ox = p.deconv_phases ? pw : p.sc.ox;
+    const unsigned short* Bt = p.Bt + (MODE == A_DECONV ? (long long)phase * p.N * p.ldb : 0);
+    const int sc_oy = MODE == A_DECONV ? ph : p.sc.oy, sc_ox = MODE == A_DECONV ? pw : p.sc.ox;
     const int k_begin = split_id * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
 
-    // ---- staging roles (direct-to-LDS): wave w, instruction ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear);
-    //      lane l lands at row 32*w + 8*ps + (l >> 3), PHYSICAL chunk l & 7, so it fetches the LOGICAL chunk
-    //      (l & 7) ^ f(row) of that row from global memory (the XOR swizzle is applied on the source side) ----
+    // ---- staging roles (direct-to-LDS): wave w, piece ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear) of the
+    //      A tile and of the B tile; lane l lands at row 32*w + 8*ps + (l >> 3), PHYSICAL chunk l & 7, so it fetches the
+    //      LOGICAL chunk (l & 7) ^ f(row) of that row from global memory (the XOR swizzle is applied on the source side) ----
     const int srow = wid * 32 + (lane >> 3), schunk_phys = lane & 7;
     long long a_base[4];
     int a_iy[4], a_jx[4], s_chunk[4];
-    bool a_ok[4];
+    bool a_ok[4], b_ok[4];
+    const unsigned short* b_row[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int trow = srow + ps * 8;
         s_chunk[ps] = schunk_phys ^ ((trow >> 1) & 7);
         const int m = m0 + trow;
         a_ok[ps] = m < p.M;
-        if (p.ga.enabled) {
+        if (MODE != A_PLAIN) {
             const int hw = p.ga.Hg * p.ga.Wg;
             const int n = m / hw, rem = m - n * hw;
             const int i = rem / p.ga.Wg, j = rem - i * p.ga.Wg;
@@ -126,38 +130,36 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
             a_base[ps] = (long long)n * p.ga.Hs;
         } else {
             a_iy[ps] = a_jx[ps] = 0;
-            a_base[ps] = (long long)m * p.lda;
+            a_base[ps] = (long long)m * p.lda + s_chunk[ps] * 8;
         }
+        const int n = n0 + trow;
+        b_ok[ps] = n < p.N;
+        b_row[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * p.ldb + s_chunk[ps] * 8;
     }
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
-    auto load_tiles = [&](int k0, int buf) {
-        int tap = 0, c0 = k0;
-        if (p.ga.enabled) { tap = k0 / p.ga.Cs; c0 = k0 - tap * p.ga.Cs; }
+    // one piece = 1 KiB of the A tile + 1 KiB of the B tile for K tile k0 (two DMA instructions per wave)
+    auto issue_piece = [&](int ps, int k0, int buf) {
         char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
         char* b_s = a_s + Cfg::A_BYTES;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            bool ok = a_ok[ps];
-            long long off;
-            const int kc = k0 + s_chunk[ps] * 8;
-            if (p.ga.enabled) {
-                // ConvTranspose phases: oh = 2*ih - 1 + kh, so tap (ty, tx) of phase (ph, pw) reads (i + ph - ty, j + pw - tx)
-                const int tdy = p.deconv_phases ? ph - (tap >> 1) : p.ga.dy[tap];
-                const int tdx = p.deconv_phases ? pw - (tap & 1) : p.ga.dx[tap];
-                const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
-                ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
-                off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + s_chunk[ps] * 8;
-            } else {
-                off = a_base[ps] + kc;
-            }
-            const bool kok = kc < k_end;             // K tail (K % 8 == 0): zero-filled chunks
-            const void* asrc = (ok && kok) ? reinterpret_cast<const void*>(p.A + off) : reinterpret_cast<const void*>(zero_src);
-            glds16(asrc, a_s + ps * 1024);
-            const int n = n0 + srow + ps * 8;
-            const void* bsrc = (n < p.N && kok) ? reinterpret_cast<const void*>(Bt + (long long)n * p.ldb + kc)
-                                                : reinterpret_cast<const void*>(zero_src);
-            glds16(bsrc, b_s + ps * 1024);
+        const int kc = k0 + s_chunk[ps] * 8;
+        const bool kok = kc < k_end;                 // K tail (K % 8 == 0): zero-filled chunks
+        bool ok = a_ok[ps] && kok;
+        long long off;
+        if (MODE != A_PLAIN) {
+            const int tap = k0 / p.ga.Cs, c0 = k0 - tap * p.ga.Cs;
+            // ConvTranspose phases: oh = 2*ih - 1 + kh, so tap (ty, tx) of phase (ph, pw) reads (i + ph - ty, j + pw - tx)
+            const int tdy = MODE == A_DECONV ? ph - (tap >> 1) : p.ga.dy[tap];
+            const int tdx = MODE == A_DECONV ? pw - (tap & 1) : p.ga.dx[tap];
+            const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
+            ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
+            off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + s_chunk[ps] * 8;
+        } else {
+            off = a_base[ps] + k0;
         }
+        const void* asrc = ok ? reinterpret_cast<const void*>(p.A + off) : reinterpret_cast<const void*>(zero_src);
+        glds16(asrc, a_s + ps * 1024);
+        const void* bsrc = (b_ok[ps] && kok) ? reinterpret_cast<const void*>(b_row[ps] + k0) : reinterpret_cast<const void*>(zero_src);
+        glds16(bsrc, b_s + ps * 1024);
     };
 
     f32x16 acc[TM][2];
@@ -169,37 +171,48 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (k_end - k_begin + GBK - 1) / GBK;
-    load_tiles(k_begin, 0);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) issue_piece(ps, k_begin, 0);
     __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
     const int frow = lane & 31, fhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
+    const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
+    // fragment address of (row + 32*t, k step ks): rows 32 apart share the swizzle term -> + t*4096; the k step flips
+    // chunk bits 1..2 of the XOR-swizzled chunk index -> ^ (ks << 5)
+    auto read_frags = [&](const char* a_s, const char* b_s, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[2]) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+            af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + t * 4096)));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + t * 4096)));
+    };
+    // One K tile: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency hidden behind
+    // the matrix pipe), and the next tile's DMA pieces are issued one per k step between the MFMA groups, so a workgroup
+    // that owns the whole CU (256^2 configuration) never has all of its waves in a load-only phase.
+    auto k_tile = [&](int kt, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * GBK, buf ^ 1);   // next tile's DMA flies during the MFMAs
         const char* a_s = smem + buf * Cfg::STAGE_BYTES;
         const char* b_s = a_s + Cfg::A_BYTES;
+        bf16x8 af[2][TM], bfr[2][2];
+        read_frags(a_s, b_s, 0, af[0], bfr[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[TM], bfr[2];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                const uint4v va = *reinterpret_cast<const uint4v*>(a_s + lds_off(wm * (TM * 32) + t * 32 + frow, ks * 2 + fhalf));
-                af[t] = __builtin_bit_cast(bf16x8, va);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint4v vb = *reinterpret_cast<const uint4v*>(b_s + lds_off(wn * 64 + t * 32 + frow, ks * 2 + fhalf));
-                bfr[t] = __builtin_bit_cast(bf16x8, vb);
-            }
+            if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (the scheduler would sink it)
+            if (HAS_NEXT) issue_piece(ks, k_begin + (kt + 1) * GBK, buf ^ 1);
             // operands swapped: D[i][j] with i = output column n (register rows), j = output row m (lane & 31),
-            // so that a lane ends up holding 4 consecutive columns of one row -> 8-byte bf16 stores.
+            // so that a lane ends up holding 4 consecutive columns of one row
 #pragma unroll
             for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[tj], af[ti], acc[ti][tj], 0, 0, 0);
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][tj], af[ks & 1][ti], acc[ti][tj], 0, 0, 0);
         }
         __syncthreads();
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type());
+    k_tile(nk - 1, std::false_type());
 
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*TM*32 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
@@ -419,18 +432,24 @@ extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
     return need;
 }
 
-template <bool OUT_F32, typename Cfg>
-static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
+template <bool OUT_F32, typename Cfg, int MODE>
+static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
     const size_t lds = 2 * Cfg::STAGE_BYTES;
     if (lds > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
     const dim3 grid((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)nphase);
-    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg>), grid, dim3(Cfg::THREADS), lds, st, a);
+    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg, MODE>), grid, dim3(Cfg::THREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
+}
+template <bool OUT_F32, typename Cfg>
+static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
+    if (a.deconv_phases) return launch_gemm_mode<OUT_F32, Cfg, A_DECONV>(a, pl, nphase, st);
+    if (a.ga.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_GATHER>(a, pl, nphase, st);
+    return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN>(a, pl, nphase, st);
 }
 
 static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st) {
