@@ -4,8 +4,12 @@
 // downsample.1, deconv_layers.{1,4,7}), the cuDNN/MIOpen batch-norm kernels (3 forward + 3 backward launches
 // per layer) plus the separate ReLU, residual-add and threshold-backward element-wise kernels.  At batch 32 these
 // HBM-bound passes -- not the convolutions -- dominate the step (profiles/), so they are fused:
-//   forward : stats (1 read) -> finalize (per-channel, tiny) -> apply: y = relu(x*scale + shift [+ res])
-//   backward: reduce (dbeta, dgamma: reads dy, x [, y]) -> apply: dx [and dres] in one pass
+//   forward : stats (1 read) -> apply: y = relu(x*scale + shift [+ res]); every apply workgroup derives scale/shift for
+//             all channels from the batch sums into LDS (a few hundred flops), workgroup 0 also writes the saved
+//             statistics, updates the running estimates and clears the NEXT backward's accumulator -- no separate
+//             per-channel "finalize" launch (56 launches / step at ~4 us each)
+//   backward: reduce (dbeta, dgamma: reads dy, x [, y]) -> apply: dx [and dres] in one pass; workgroup 0 clears the
+//             forward accumulator for the next step
 // x [R][C]: R = B*H*W rows, C channels contiguous (C % 8 == 0); 16 bytes (8 channels) per lane per access;
 // per-channel reductions: registers -> LDS -> one fp32 atomic per channel per workgroup.
 #include "common.h"
@@ -75,55 +79,67 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
     slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
 }
 
-// Training: mean / rstd from the batch sums, running statistics (momentum, unbiased variance), fused affine
-// scale/shift; clears the sums for the next call and bumps num_batches_tracked.
-// Inference (sums == nullptr): scale/shift from the running statistics.
-__global__ void bn_finalize_kernel(float* __restrict__ sums, long long R, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ num_batches, float* __restrict__ mean,
-                                   float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ bwd_sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches && sums) num_batches[0] += 1;
-    if (c >= C) return;
-    if (bwd_sums) { bwd_sums[c] = 0.f; bwd_sums[C + c] = 0.f; }     // accumulator of this layer's NEXT backward pass
-    double m, var;
-    if (sums) {
-        m = (double)sums[c] / (double)R;
-        var = (double)sums[C + c] / (double)R - m * m;
-        if (var < 0) var = 0;
-        sums[c] = 0.f;                 // leave the accumulator clean for the next call (and graph replays)
-        sums[C + c] = 0.f;
-        if (running_mean) {
-            const double unbiased = (R > 1) ? var * (double)R / (double)(R - 1) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
-    } else {
-        m = running_mean[c];
-        var = running_var[c];
-    }
-    const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    if (mean) { mean[c] = (float)m; rstd[c] = rs; }
-    const float sc = gamma[c] * rs;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
-}
+// Per-channel affine of one BatchNorm call, derived inside the apply kernel.
+// Training (sums != nullptr): mean / rstd from the batch sums (float64: E[x^2] - m^2 cancels), running statistics
+// (momentum, unbiased variance) and num_batches_tracked updated by workgroup 0.  Inference: running statistics.
+struct BnAffine {
+    const float* sums;            // [2C] batch sums (sum x | sum x^2) or nullptr
+    long long R;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var;
+    long long* num_batches;
+    float *mean, *rstd, *scale, *shift;   // saved for the backward pass (mean/rstd may be nullptr in inference)
+    float* bwd_sums;              // [2C] or nullptr: accumulator of this layer's NEXT backward pass, cleared here
+};
 
 // y = act(x * scale[c] + shift[c] (+ res))
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
-                                                              long long nvec, int C, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, unsigned short* __restrict__ y) {
+                                                              long long nvec, int C, BnAffine a, unsigned short* __restrict__ y) {
+    extern __shared__ float ss[];                 // [C] scale | [C] shift
+    const bool lead = blockIdx.x == 0;
+    for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+        double m, var;
+        if (a.sums) {
+            m = (double)a.sums[c] / (double)a.R;
+            var = (double)a.sums[C + c] / (double)a.R - m * m;
+            if (var < 0) var = 0;
+        } else {
+            m = a.running_mean[c];
+            var = a.running_var[c];
+        }
+        const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float sc = a.gamma[c] * rs, sh = a.beta[c] - (float)m * sc;
+        ss[c] = sc;
+        ss[C + c] = sh;
+        if (lead) {
+            if (a.mean) { a.mean[c] = (float)m; a.rstd[c] = rs; }
+            a.scale[c] = sc;
+            a.shift[c] = sh;
+            if (a.sums && a.running_mean) {
+                const double unbiased = (a.R > 1) ? var * (double)a.R / (double)(a.R - 1) : var;
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+            }
+            if (a.bwd_sums) { a.bwd_sums[c] = 0.f; a.bwd_sums[C + c] = 0.f; }
+        }
+    }
+    if (lead && threadIdx.x == 0 && a.num_batches && a.sums) a.num_batches[0] += 1;
+    __syncthreads();
     const int cg = C >> 3;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
         const int g = (int)(i % cg);
         float v[8], r[8];
         Elem<unsigned short>::load(x + i * 8, v);
         if (RES) Elem<unsigned short>::load(res + i * 8, r);
+        const float4v s0 = *reinterpret_cast<const float4v*>(ss + g * 8), s1 = *reinterpret_cast<const float4v*>(ss + g * 8 + 4);
+        const float4v h0 = *reinterpret_cast<const float4v*>(ss + C + g * 8), h1 = *reinterpret_cast<const float4v*>(ss + C + g * 8 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float t = v[k] * scale[g * 8 + k] + shift[g * 8 + k];
+            float t = v[k] * sc[k] + sh[k];
             if (RES) t += r[k];
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
@@ -193,7 +209,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
                                                                   const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ sums,
-                                                                  unsigned short* __restrict__ dx, unsigned short* __restrict__ dres) {
+                                                                  unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
+                                                                  float* __restrict__ fwd_sums_clear) {
+    if (fwd_sums_clear && blockIdx.x == 0)         // the forward statistics accumulator of this layer's NEXT forward pass
+        for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
     const int cg = C >> 3;
     const float inv_r = 1.f / (float)R;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
@@ -258,25 +277,28 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
         hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws);
         EPI_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, training ? sums_ws : nullptr, R, C, gamma, beta, eps,
-                       momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale_shift, scale_shift + C, bwd_sums);
-    EPI_CHECK_LAUNCH();
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    if (lds > 65536) return EPI_ERR_UNSUPPORTED;
+    BnAffine a;
+    a.sums = training ? sums_ws : nullptr; a.R = R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
+    a.running_mean = running_mean; a.running_var = running_var; a.num_batches = num_batches_tracked;
+    a.mean = mean; a.rstd = rstd; a.scale = scale_shift; a.shift = scale_shift + C; a.bwd_sums = bwd_sums;
     const unsigned short* xs = (const unsigned short*)x;
     const unsigned short* rs = (const unsigned short*)residual;
     unsigned short* ys = (unsigned short*)y;
-    if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
-    else if (residual) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, 0, st, xs, rs, nvec, C, scale_shift, scale_shift + C, ys);
+    if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else if (residual) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
 extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
                               const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
-                              epi_stream_t stream) {
+                              float* fwd_sums_clear, epi_stream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
@@ -296,7 +318,7 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs)
+#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear)
     if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
     else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }
     else { if (dres) EPI_BN_APP(BN_MASK_FROM_Y, true); else EPI_BN_APP(BN_MASK_FROM_Y, false); }

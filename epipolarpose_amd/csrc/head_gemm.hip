@@ -22,7 +22,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;      // the TN kernel's tile (and the small NT tile)
-constexpr int TILE_BYTES = GBM * GBK * 2;          // 16 KiB per operand tile
 
 // NT kernel tile configurations: 2 x WN waves, each wave TM x 2 MFMA tiles (32x32).
 //   small: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups / CU)   -- short K, few rows, ragged N

@@ -48,7 +48,7 @@ _SIGNATURES = {
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
-    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -486,9 +486,9 @@ def bn_act_fwd(x, residual, ptrs, training, momentum, eps, relu):
     return y, stats
 
 
-def bn_act_bwd(dy, x, y, gamma_ptr, stats, relu, want_dres, sums):
+def bn_act_bwd(dy, x, y, gamma_ptr, stats, relu, want_dres, sums, fwd_sums_ptr=None):
     """-> (dx, dres or None).  ``sums`` [2C] f32 = (dbeta | dgamma) accumulator, zero on entry (the layer's ``bwd_sums``,
-    cleared by its forward pass)."""
+    cleared by its forward pass); ``fwd_sums_ptr``: address of the layer's forward accumulator, zeroed by this call."""
     lib = _lib or load()
     b, c, h, w = x.shape
     dx = torch.empty_like(x)
@@ -496,7 +496,7 @@ def bn_act_bwd(dy, x, y, gamma_ptr, stats, relu, want_dres, sums):
     sp = stats.data_ptr()
     st = lib.epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, b * h * w, c, gamma_ptr, sp, sp + 4 * c,
                             sp + 8 * c, 1 if relu else 0, sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
-                            _stream())
+                            fwd_sums_ptr, _stream())
     if st:
         _check(st, "epi_bn_act_bwd")
     return dx, dres

@@ -22,6 +22,13 @@ class _BNActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, module, relu):
         training = module.training
+        if training:
+            # accumulator hand-over between the two directions (no memsets in the steady fwd -> bwd -> fwd -> ... pattern):
+            # the forward apply clears bwd_sums, the backward apply clears sums_ws.  A second training-mode forward
+            # before the backward finds sums_ws still holding the previous call's sums and clears it here.
+            if module._fwd_dirty:
+                module.sums_ws.zero_()
+            module._fwd_dirty, module._bwd_dirty = True, False
         y, stats = hip.bn_act_fwd(x, residual, module.pointers(), training, module.momentum, module.eps, relu)
         ctx.relu, ctx.has_res, ctx.training, ctx.module = relu, residual is not None, training, module
         if training:
@@ -36,10 +43,13 @@ class _BNActFunction(torch.autograd.Function):
         module = ctx.module
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        # bwd_sums was cleared by this layer's forward pass (one backward per forward: the training loop's pattern)
-        sums = module.bwd_sums
-        dx, dres = hip.bn_act_bwd(dy, x, y, module.pointers()[0], stats, ctx.relu, ctx.has_res, sums)
         c = x.shape[1]
+        # bwd_sums was cleared by this layer's forward pass; a second backward without a forward in between (two calls of
+        # the layer inside one autograd graph) must not touch it again -- the first one's gradients may alias it
+        sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device) if module._bwd_dirty else module.bwd_sums
+        ptrs = module.pointers()
+        dx, dres = hip.bn_act_bwd(dy, x, y, ptrs[0], stats, ctx.relu, ctx.has_res, sums, ptrs[5])
+        module._fwd_dirty, module._bwd_dirty = False, True
         return dx, sums[c:], sums[:c], dres, None, None
 
 
@@ -58,6 +68,8 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
         self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
         self._ptrs = None
+        self._fwd_dirty = False       # sums_ws holds a forward's sums that no backward has cleared yet
+        self._bwd_dirty = False       # bwd_sums holds a backward's sums that no forward has cleared yet
 
     def pointers(self):
         """Device addresses of the persistent tensors, cached (hundreds of BatchNorm calls per step: the host-side cost

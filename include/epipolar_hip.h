@@ -188,14 +188,17 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  * (+ `out += residual`) of lib/models/pose3d_resnet.py:31-47,68-88,158-183,186-188.
  *   x, residual, y : [R][C] bf16 (R = B*H*W, C % 8 == 0);  gamma, beta, running_mean, running_var, mean, rstd : [C] f32
  *   scale_shift    : [2C] f32 out (scale = gamma*rstd, shift = beta - mean*scale), reused by the backward
- *   sums_ws        : [2C] f32 accumulator that must be ZERO on entry; it is zero again on return (keep one per
- *                    layer: graph replays then need no memset)
+ *   sums_ws        : [2C] f32 accumulator (training) that must be ZERO on entry; on return it holds the batch sums.
+ *                    Keep one per layer and hand it to the layer's backward call as `fwd_sums_clear`, which zeroes
+ *                    it again (steady-state training and graph replays then need no memset); a caller that runs a
+ *                    training-mode forward without the backward clears it itself before the next forward.
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
  *                    num_batches_tracked += 1;   training == 0: running statistics.
  *   bwd_sums       : [2C] f32 or NULL: zeroed by the forward so that it can serve as `dbeta_dgamma` of this
  *                    layer's next backward pass without a separate memset
  * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
- *   = gradient of the residual input;  y = saved forward output, required when relu && dres.
+ *   = gradient of the residual input;  y = saved forward output, required when relu && dres;
+ *   fwd_sums_clear [2C] f32 or NULL: zeroed (the forward accumulator above).
  * ------------------------------------------------------------------------------------------------ */
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
@@ -203,7 +206,7 @@ int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, cons
                    float* bwd_sums, void* y, epi_stream_t stream);
 int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma,
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
-                   float* dbeta_dgamma, void* dx, void* dres, epi_stream_t stream);
+                   float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (ntap = 1 for epi_gemm_tn_bf16, 16 for the deconvolution).

@@ -153,3 +153,44 @@ def test_fused_bn_act_vs_torch(dev, relu, res, shape):
         if relu:
             te = torch.relu(te)
     close(ye, te, rel=1e-2)
+
+
+def test_fused_bn_call_patterns(dev):
+    """The forward / backward accumulators are cleared by each other's kernels in the steady fwd -> bwd pattern; every other
+    pattern (forward only, the layer twice in one graph, repeated steps) must give the same numbers as nn.BatchNorm2d."""
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    c, shape = 64, (4, 64, 6, 5)
+    m = FusedBatchNormAct(c, relu=True).to(dev)
+    ref = torch.nn.BatchNorm2d(c).to(dev)
+    xs = [rnd(shape, dev, 40 + i, 1.5).add_(0.2 * i).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for i in range(4)]
+
+    def ref_out(x):
+        return torch.relu(ref(x.float()))
+    # (1) three steady steps
+    for i in range(3):
+        xg, x32 = xs[i].clone().requires_grad_(True), xs[i].float().requires_grad_(True)
+        y, t = m(xg), torch.relu(ref(x32))
+        close(y, t, rel=1e-2)
+        m.weight.grad = m.bias.grad = ref.weight.grad = ref.bias.grad = None
+        y.float().sum().backward()
+        t.sum().backward()
+        close(m.weight.grad, ref.weight.grad, rel=2e-2)
+        close(m.bias.grad, ref.bias.grad, rel=2e-2)
+    # (2) training-mode forwards without a backward
+    with torch.no_grad():
+        for i in range(2):
+            close(m(xs[i]), ref_out(xs[i]), rel=1e-2)
+    # (3) the layer twice inside one autograd graph, then a normal step again
+    for rounds in range(2):
+        xa, xb = xs[2].clone().requires_grad_(True), xs[3].clone().requires_grad_(True)
+        a32, b32 = xs[2].float().requires_grad_(True), xs[3].float().requires_grad_(True)
+        m.weight.grad = m.bias.grad = ref.weight.grad = ref.bias.grad = None
+        (m(xa).float().sum() + 2.0 * m(xb).float().sum()).backward()
+        (torch.relu(ref(a32)).sum() + 2.0 * torch.relu(ref(b32)).sum()).backward()
+        close(m.weight.grad, ref.weight.grad, rel=2e-2)
+        close(m.bias.grad, ref.bias.grad, rel=2e-2)
+        close(xa.grad, a32.grad, rel=2e-2, outliers=1e-3)
+        close(xb.grad, b32.grad, rel=2e-2, outliers=1e-3)
+    close(m.running_mean, ref.running_mean, rel=2e-3)
+    close(m.running_var, ref.running_var, rel=2e-3)
+    assert int(m.num_batches_tracked) == int(ref.num_batches_tracked) == 9
