@@ -464,42 +464,29 @@ def deconv4x4s2_bwd_data(dy, w_bwd):
     return dx
 
 
-def bn_module_pointers(gamma, beta, running_mean, running_var, num_batches_tracked, sums_ws, bwd_sums):
-    """Raw addresses of a BatchNorm module's persistent tensors (cached by the module; revalidated on gamma's address)."""
-    return (gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), num_batches_tracked.data_ptr(),
-            sums_ws.data_ptr(), bwd_sums.data_ptr())
+_glue = None
 
 
-def bn_act_fwd(x, residual, ptrs, training, momentum, eps, relu):
-    """Fused BatchNorm (+ residual) (+ ReLU) forward on an NHWC bf16 tensor [B, C, H, W] (channels_last, checked by the
-    caller).  ptrs = bn_module_pointers(...).  -> (y, stats) with stats = [mean | rstd | scale | shift] (4C f32)."""
-    lib = _lib or load()
-    b, c, h, w = x.shape
-    y = torch.empty_like(x)
-    stats = torch.empty(4 * c, dtype=torch.float32, device=x.device)
-    sp = stats.data_ptr()
-    st = lib.epi_bn_act_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else None, b * h * w, c, ptrs[0], ptrs[1], eps,
-                            momentum, 1 if training else 0, 1 if relu else 0, ptrs[2], ptrs[3], ptrs[4], sp, sp + 4 * c, sp + 8 * c,
-                            ptrs[5], ptrs[6] if training else None, y.data_ptr(), _stream())
-    if st:
-        _check(st, "epi_bn_act_fwd")
-    return y, stats
-
-
-def bn_act_bwd(dy, x, y, gamma_ptr, stats, relu, want_dres, sums, fwd_sums_ptr=None):
-    """-> (dx, dres or None).  ``sums`` [2C] f32 = (dbeta | dgamma) accumulator, zero on entry (the layer's ``bwd_sums``,
-    cleared by its forward pass); ``fwd_sums_ptr``: address of the layer's forward accumulator, zeroed by this call."""
-    lib = _lib or load()
-    b, c, h, w = x.shape
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
-    sp = stats.data_ptr()
-    st = lib.epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if y is not None else None, b * h * w, c, gamma_ptr, sp, sp + 4 * c,
-                            sp + 8 * c, 1 if relu else 0, sums.data_ptr(), dx.data_ptr(), dres.data_ptr() if want_dres else None,
-                            fwd_sums_ptr, _stream())
-    if st:
-        _check(st, "epi_bn_act_bwd")
-    return dx, dres
+def glue():
+    """The C++ autograd glue over the C ABI (csrc/torch_glue.cpp -> _lib/epi_torch_glue*.so), loaded once; built by
+    ``epipolarpose_amd.build.build_glue()`` (``__graft_entry__.build()``).  Fails loudly when missing."""
+    global _glue
+    if _glue is None:
+        import importlib.util
+        from . import build as _build
+        load()
+        path = _build.glue_path()
+        if not os.path.exists(path):
+            raise RuntimeError("epipolarpose_amd: %s is missing -- run `python -m epipolarpose_amd.build` (hipcc + g++, gfx950); "
+                               "there is no Python/CPU fallback for the fused BatchNorm" % path)
+        spec = importlib.util.spec_from_file_location(_build.GLUE_NAME, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ver = load().epi_version().decode()
+        if mod.abi_version() != ver:
+            raise RuntimeError("epipolarpose_amd: glue / library version mismatch (%s vs %s): rebuild" % (mod.abi_version(), ver))
+        _glue = mod
+    return _glue
 
 
 def gemm_tn_bf16(a, b):

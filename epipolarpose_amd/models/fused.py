@@ -1,7 +1,7 @@
 """Network building blocks backed by the HIP kernels of ``libepipolar_hip.so``.
 
-* ``FusedBatchNormAct``  -- BatchNorm2d (+ residual add) (+ ReLU) in one apply pass (``epi_bn_act_fwd/bwd``); same
-  parameters / buffers (and therefore ``state_dict`` keys) as ``nn.BatchNorm2d``.
+* ``FusedBatchNormAct``  -- BatchNorm2d (+ residual add) (+ ReLU) in one apply pass (``epi_bn_act_fwd/bwd``, reached through the
+  C++ autograd glue ``csrc/torch_glue.cpp``); same parameters / buffers (and therefore ``state_dict`` keys) as ``nn.BatchNorm2d``.
 * ``Deconv4x4s2``        -- ``nn.ConvTranspose2d(k=4, s=2, p=1)`` as MFMA implicit GEMMs (``epi_deconv4x4s2_*``).
 * ``Conv1x1``            -- the final 1x1 convolution as an MFMA GEMM (``epi_gemm_bf16``).
 All activations are NHWC (``channels_last``) bf16; parameters stay fp32 (master weights).  No CPU path.
@@ -18,41 +18,6 @@ def _nhwc_bf16(x):
     return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
 
 
-class _BNActFunction(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, residual, module, relu):
-        training = module.training
-        if training:
-            # accumulator hand-over between the two directions (no memsets in the steady fwd -> bwd -> fwd -> ... pattern):
-            # the forward apply clears bwd_sums, the backward apply clears sums_ws.  A second training-mode forward
-            # before the backward finds sums_ws still holding the previous call's sums and clears it here.
-            if module._fwd_dirty:
-                module.sums_ws.zero_()
-            module._fwd_dirty, module._bwd_dirty = True, False
-        y, stats = hip.bn_act_fwd(x, residual, module.pointers(), training, module.momentum, module.eps, relu)
-        ctx.relu, ctx.has_res, ctx.training, ctx.module = relu, residual is not None, training, module
-        if training:
-            ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        if not ctx.training:
-            raise RuntimeError("FusedBatchNormAct: backward through inference-mode statistics is not supported")
-        x, y, stats = ctx.saved_tensors
-        module = ctx.module
-        if not dy.is_contiguous(memory_format=torch.channels_last):
-            dy = dy.contiguous(memory_format=torch.channels_last)
-        c = x.shape[1]
-        # bwd_sums was cleared by this layer's forward pass; a second backward without a forward in between (two calls of
-        # the layer inside one autograd graph) must not touch it again -- the first one's gradients may alias it
-        sums = torch.zeros(2 * c, dtype=torch.float32, device=x.device) if module._bwd_dirty else module.bwd_sums
-        ptrs = module.pointers()
-        dx, dres = hip.bn_act_bwd(dy, x, y, ptrs[0], stats, ctx.relu, ctx.has_res, sums, ptrs[5])
-        module._fwd_dirty, module._bwd_dirty = False, True
-        return dx, sums[c:], sums[:c], dres, None, None
-
-
 class FusedBatchNormAct(nn.Module):
     """y = act(BN(x) [+ residual]);  training-mode semantics of ``nn.BatchNorm2d(momentum)``: biased batch variance
     for normalisation, unbiased for the running estimate (pose3d_resnet.py:24,57,61,65,133,174 use momentum 0.1)."""
@@ -67,27 +32,29 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
         self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
-        self._ptrs = None
-        self._fwd_dirty = False       # sums_ws holds a forward's sums that no backward has cleared yet
-        self._bwd_dirty = False       # bwd_sums holds a backward's sums that no forward has cleared yet
+        # accumulator hand-over state shared with the C++ autograd glue (csrc/torch_glue.cpp): [0] sums_ws holds a forward's
+        # sums that no backward has cleared yet, [1] bwd_sums holds a backward's sums that no forward has cleared yet
+        self._flags = torch.zeros(2, dtype=torch.int32)
+        self._args = None
 
-    def pointers(self):
-        """Device addresses of the persistent tensors, cached (hundreds of BatchNorm calls per step: the host-side cost
-        of re-deriving them is measurable); re-derived whenever the weight tensor has moved (``.to()``, reload)."""
-        p = self._ptrs
-        if p is None or p[0] != self.weight.data_ptr() or p[2] != self.running_mean.data_ptr():
-            p = self._ptrs = hip.bn_module_pointers(self.weight, self.bias, self.running_mean, self.running_var,
-                                                    self.num_batches_tracked, self.sums_ws, self.bwd_sums)
-        return p
+    def _tensors(self):
+        """(weight, bias, running_mean, running_var, num_batches_tracked, sums_ws, bwd_sums), cached: seven nn.Module
+        attribute look-ups per call are measurable at 53 layers x 2 directions per step; refreshed when ``.to()`` /
+        ``load_state_dict`` replaced a buffer or parameter object."""
+        a, bufs, prm = self._args, self._buffers, self._parameters
+        if a is None or a[0] is not prm["weight"] or a[2] is not bufs["running_mean"] or a[5] is not bufs["sums_ws"]:
+            a = self._args = (prm["weight"], prm["bias"], bufs["running_mean"], bufs["running_var"], bufs["num_batches_tracked"],
+                              bufs["sums_ws"], bufs["bwd_sums"])
+        return a
 
     def forward(self, x, residual=None):
         if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
             x = _nhwc_bf16(x)
         if residual is not None and (residual.dtype != torch.bfloat16 or not residual.is_contiguous(memory_format=torch.channels_last)):
             residual = _nhwc_bf16(residual)
-        if not x.is_cuda:
-            raise RuntimeError("FusedBatchNormAct: input must live on the GPU (no CPU fallback in epipolarpose_amd)")
-        return _BNActFunction.apply(x, self.weight, self.bias, residual, self, self.relu)
+        w, b, rm, rv, nbt, sums_ws, bwd_sums = self._tensors()
+        return hip.glue().bn_act(x, w, b, residual, rm, rv, nbt, sums_ws, bwd_sums, self._flags, self.training, self.momentum,
+                                 self.eps, self.relu)
 
     def extra_repr(self):
         return "{num_features}, eps={eps}, momentum={momentum}, relu={relu}".format(**self.__dict__)

@@ -69,3 +69,19 @@ def test_no_cpu_fallback():
     from epipolarpose_amd import hip
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         hip.softargmax3d_fwd(torch.zeros(1, 8, 2, 2), 2)
+
+
+def test_torch_glue_builds_loads_and_links_the_c_abi():
+    """csrc/torch_glue.cpp (C++ autograd glue) compiles against the installed torch, loads without a GPU, reports the
+    library's version and refuses CPU tensors (no CPU fallback)."""
+    import pytest
+    import torch
+    from epipolarpose_amd import build, hip
+    build.build(verbose=False)
+    build.build_glue(verbose=False)
+    g = hip.glue()
+    assert g.abi_version() == hip.load().epi_version().decode()
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    m = FusedBatchNormAct(8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(2, 8, 4, 4, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last))
