@@ -31,12 +31,13 @@ inline bool nhwc_bf16(const Tensor& t) {
 // flags (CPU int32[2], owned by the module): [0] sums_ws still holds a forward's sums, [1] bwd_sums still holds a
 // backward's sums -- the accumulator hand-over protocol of epi_bn_act_fwd / epi_bn_act_bwd (see include/epipolar_hip.h)
 struct BnAct : public torch::autograd::Function<BnAct> {
-    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor weight, Tensor bias, Tensor residual, Tensor running_mean,
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor weight, Tensor bias, c10::optional<Tensor> residual_opt, Tensor running_mean,
                           Tensor running_var, Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training,
                           double momentum, double eps, bool relu) {
         TORCH_CHECK(x.is_cuda(), "FusedBatchNormAct: input must live on the GPU (no CPU fallback in epipolarpose_amd)");
         TORCH_CHECK(nhwc_bf16(x), "FusedBatchNormAct: x must be channels_last bf16");
-        const bool has_res = residual.defined();
+        const bool has_res = residual_opt.has_value() && residual_opt->defined();
+        const Tensor residual = has_res ? *residual_opt : Tensor();
         if (has_res) TORCH_CHECK(nhwc_bf16(residual) && residual.sizes() == x.sizes(), "FusedBatchNormAct: residual layout");
         const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
         int* fl = flags.data_ptr<int>();
@@ -97,7 +98,7 @@ struct BnAct : public torch::autograd::Function<BnAct> {
 
 Tensor bn_act(Tensor x, Tensor weight, Tensor bias, c10::optional<Tensor> residual, Tensor running_mean, Tensor running_var,
               Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
-    return BnAct::apply(x, weight, bias, residual.has_value() ? *residual : Tensor(), running_mean, running_var, num_batches, sums_ws,
+    return BnAct::apply(x, weight, bias, residual, running_mean, running_var, num_batches, sums_ws,
                         bwd_sums, flags, training, momentum, eps, relu);
 }
 
