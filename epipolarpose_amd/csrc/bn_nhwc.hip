@@ -85,6 +85,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
 struct BnAffine {
     const float* sums;            // [2C] batch sums (sum x | sum x^2) or nullptr
     long long R;
+    double inv_r;                 // 1 / R (host-computed: no float64 divide on the device)
     const float *gamma, *beta;
     float eps, momentum;
     float *running_mean, *running_var;
@@ -99,17 +100,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned sho
                                                               long long nvec, int C, BnAffine a, unsigned short* __restrict__ y) {
     extern __shared__ float ss[];                 // [C] scale | [C] shift
     const bool lead = blockIdx.x == 0;
+    const double inv_r = a.inv_r;
     for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+        // every workgroup repeats this for all C channels: keep it to one float64 multiply + fma (E[x^2] - m^2 cancels in
+        // float32) and float32 for the rest -- no float64 divide / sqrt
         double m, var;
         if (a.sums) {
-            m = (double)a.sums[c] / (double)a.R;
-            var = (double)a.sums[C + c] / (double)a.R - m * m;
+            m = (double)a.sums[c] * inv_r;
+            var = fma(-m, m, (double)a.sums[C + c] * inv_r);
             if (var < 0) var = 0;
         } else {
             m = a.running_mean[c];
             var = a.running_var[c];
         }
-        const float rs = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float rs = 1.0f / sqrtf((float)var + a.eps);
         const float sc = a.gamma[c] * rs, sh = a.beta[c] - (float)m * sc;
         ss[c] = sc;
         ss[C + c] = sh;
@@ -282,7 +286,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     const size_t lds = (size_t)2 * C * sizeof(float);
     if (lds > 65536) return EPI_ERR_UNSUPPORTED;
     BnAffine a;
-    a.sums = training ? sums_ws : nullptr; a.R = R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
+    a.sums = training ? sums_ws : nullptr; a.R = R; a.inv_r = 1.0 / (double)R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
     a.running_mean = running_mean; a.running_var = running_var; a.num_batches = num_batches_tracked;
     a.mean = mean; a.rstd = rstd; a.scale = scale_shift; a.shift = scale_shift + C; a.bwd_sums = bwd_sums;
     const unsigned short* xs = (const unsigned short*)x;

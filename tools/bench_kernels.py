@@ -124,32 +124,57 @@ def bench_tri():
 
 
 def bench_bn():
-    import torch.nn.functional as F
-    from epipolarpose_amd.models.fused import FusedBatchNormAct
-    for shape, res in (((32, 64, 128, 128), False), ((32, 256, 64, 64), True), ((32, 64, 64, 64), False), ((32, 512, 32, 32), True),
-                       ((32, 1024, 16, 16), True), ((32, 2048, 8, 8), True), ((32, 256, 64, 64), False)):
+    """epi_bn_act_fwd / epi_bn_act_bwd called through the C ABI in the steady fwd -> bwd order (each direction clears the
+    other's accumulator); stock nn.BatchNorm2d (+ add + relu) timed beside it."""
+    lib = hip.load()
+    shapes = (((32, 64, 128, 128), False), ((32, 64, 64, 64), False), ((32, 256, 64, 64), True), ((32, 256, 64, 64), False),
+              ((32, 128, 32, 32), False), ((32, 512, 32, 32), True), ((32, 256, 16, 16), False), ((32, 1024, 16, 16), True),
+              ((32, 512, 8, 8), False), ((32, 2048, 8, 8), True))
+    for shape, res in shapes:
         b, c, h, w = shape
-        x = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        r = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
-        dy = torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        m = FusedBatchNormAct(c).to(DEV)
+        mk = lambda: torch.randn(shape, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+        x, dy, y, dx = mk(), mk(), mk(), mk()
+        r = mk() if res else None
+        dres = mk() if res else None
+        f32 = lambda n, v=0.0: torch.full((n,), v, dtype=torch.float32, device=DEV)  # noqa: E731
+        gamma, beta, rm, rv = f32(c, 1.0), f32(c), f32(c), f32(c, 1.0)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        stats, sums, bsums = f32(4 * c), f32(2 * c), f32(2 * c)
+        sp, st = stats.data_ptr(), torch.cuda.current_stream().cuda_stream
+        R = b * h * w
+
+        def fwd():
+            rc = lib.epi_bn_act_fwd(x.data_ptr(), r.data_ptr() if res else None, R, c, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, 1, 1,
+                                    rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), sp, sp + 4 * c, sp + 8 * c, sums.data_ptr(),
+                                    bsums.data_ptr(), y.data_ptr(), st)
+            assert rc == 0
+
+        def bwd():
+            rc = lib.epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if res else None, R, c, gamma.data_ptr(), sp, sp + 4 * c,
+                                    sp + 8 * c, 1, bsums.data_ptr(), dx.data_ptr(), dres.data_ptr() if res else None, sums.data_ptr(), st)
+            assert rc == 0
+        tf = tb = 0.0
+        n = 20
+        for it in range(n + 3):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(); fwd(); e[1].record(); bwd(); e[2].record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                tf += e[0].elapsed_time(e[1]) / n
+                tb += e[1].elapsed_time(e[2]) / n
         ref = torch.nn.BatchNorm2d(c).to(DEV)
-        nbytes = x.numel() * 2
         xg = x.clone().requires_grad_(True)
         rg = r.clone().requires_grad_(True) if res else None
-
-        def ours_fwd():
-            return m(xg, residual=rg)
 
         def stock_fwd():
             t = ref(xg)
             if res:
                 t = t + rg
             return torch.relu(t)
-        tf, ts = timeit(ours_fwd), timeit(stock_fwd)
-        y, t = ours_fwd(), stock_fwd()
-        tb = timeit(lambda: torch.autograd.grad(y, [xg] + ([rg] if res else []) + [m.weight, m.bias], dy, retain_graph=True))
+        ts = timeit(stock_fwd)
+        t = stock_fwd()
         tsb = timeit(lambda: torch.autograd.grad(t, [xg] + ([rg] if res else []) + [ref.weight, ref.bias], dy, retain_graph=True))
+        nbytes = x.numel() * 2
         rf, rb = (3 if res else 2) + 1, (5 if res else 4) + (2 if res else 1)      # passes over the tensor: fwd (stats+apply), bwd
         print("bn %-18s res=%d  fwd ours %.4f ms (%5.0f GB/s) stock %.4f ms | bwd ours %.4f ms (%5.0f GB/s) stock %.4f ms" % (
             shape, res, tf, rf * nbytes / tf / 1e6, ts, tb, rb * nbytes / tb / 1e6, tsb), flush=True)
