@@ -6,7 +6,8 @@
 //   * ConvTranspose2d(k=4,s=2,p=1) forward  (pose3d_resnet.py:158-183) = 4 output-parity phases, each a
 //     2x2-tap gather GEMM with K = 4*Cin;
 //   * its backward-data = a 4x4 stride-2 gather GEMM with K = 16*Cout;
-//   * the final 1x1 convolution (pose3d_resnet.py:116-122) forward / backward-data = plain GEMMs.
+//   * the final 1x1 convolution (pose3d_resnet.py:116-122) forward / backward-data = plain GEMMs (the forward, short K and
+//     wide N, through the A-stationary kernel further down).
 // Tile 128x128x64, 256 threads (2x2 waves, each 2x2 MFMA 32x32 tiles), global->LDS by direct DMA
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass) with the next K tile's DMA in flight during the
 // MFMAs, double-buffered LDS (64 KiB -> 2 workgroups / CU), 16-byte chunks XOR-swizzled on the SOURCE address so the
@@ -326,6 +327,132 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// A-stationary variant for a SHORT K and a WIDE N (the final 1x1 convolution forward: M = B*H*W = 131 072 rows,
+// K = 256 input channels, N = J*D = 1088 output channels).  With only K/64 = 4 K-tiles per output tile the generic
+// kernel is a chain of exposed DMA latencies (310 TF), while the operation itself is bound by writing C (285 MB).
+// Here a workgroup owns 256 rows of A for ALL N: every wave keeps its 32 rows x K of A in registers as MFMA
+// fragments (64 VGPRs at K = 256, loaded once), the workgroup streams [64 n][K] slices of Bt through a double-buffered
+// LDS tile (DMA, source-side XOR swizzle over the 32 16-byte chunks of a row), and each wave writes its 32 x 64 result
+// of every slice as whole 128-byte row segments through a private 4 KiB LDS staging area.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int AS_WAVES = 8, AS_LOADERS = 2, AS_RING = 3;                 // 8 MFMA waves + 2 loader waves, 3-deep ring of B slices
+constexpr int AS_THREADS = 64 * (AS_WAVES + AS_LOADERS), AS_BM = 32 * AS_WAVES, AS_BN = 64;
+
+template <int KSTEPS>          // K = 16 * KSTEPS (64, 128 or 256)
+__global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs p) {
+    constexpr int K = 16 * KSTEPS, ROW_BYTES = 2 * K, CHUNKS = ROW_BYTES / 16;      // one Bt row in LDS
+    constexpr int BTILE = AS_BN * ROW_BYTES;                                           // <= 32 KiB
+    constexpr int ROWS_PER_PIECE = 1024 / ROW_BYTES, PIECES = BTILE / 1024 / AS_LOADERS;  // 1 KiB DMA pieces per slice per loader wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [AS_RING][BTILE] | [AS_WAVES][4 KiB] staging | bias [N] f32
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool loader = wid >= AS_WAVES;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * AS_BM + wid * 32;
+    const int n_tiles = (p.N + AS_BN - 1) / AS_BN;
+    const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
+    float* bias_s = reinterpret_cast<float*>(smem + AS_RING * BTILE + AS_WAVES * 4096);
+    for (int n = tid; n < n_tiles * AS_BN; n += AS_THREADS) bias_s[n] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+
+    // ---- B slice DMA (loader waves only): piece q of loader w covers LDS rows (w*PIECES + q)*ROWS_PER_PIECE ..; lane l
+    //      lands at row r = base + l / CHUNKS, physical chunk l % CHUNKS, and fetches logical chunk (l % CHUNKS) ^ (r % CHUNKS).
+    //      Dedicated loader waves keep vmcnt of the MFMA waves free of loads: those never wait for their result stores,
+    //      which stay in flight across the slice barriers (a wave that issues both must drain both), and the loaders run
+    //      one slice ahead of the slice being consumed (counted vmcnt: loads return in order). ----
+    auto issue_b = [&](int nt) {
+        const int lw = wid - AS_WAVES;
+        char* dst = smem + (nt % AS_RING) * BTILE + lw * (PIECES * 1024);
+#pragma unroll 8
+        for (int q = 0; q < PIECES; ++q) {
+            const int r = (lw * PIECES + q) * ROWS_PER_PIECE + lane / CHUNKS;
+            const int chunk = (lane % CHUNKS) ^ (r % CHUNKS);
+            const int n = nt * AS_BN + r;
+            const void* src = n < p.N ? reinterpret_cast<const void*>(p.Bt + (long long)n * p.ldb + chunk * 8)
+                                      : reinterpret_cast<const void*>(zero_src);
+            glds16(src, dst + q * 1024);
+        }
+    };
+    // ---- A fragments (MFMA waves): row m0 + frow, k = 16*ks + 8*fhalf .. +7, resident for the whole kernel ----
+    bf16x8 af[KSTEPS];
+    if (loader) {
+        issue_b(0);
+        if (n_tiles > 1) issue_b(1);
+    } else {
+        const int m = m0 + frow;
+        const uint4v* arow = reinterpret_cast<const uint4v*>(p.A + (long long)(m < p.M ? m : 0) * p.lda) + fhalf;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            uint4v v = arow[2 * ks];
+            if (m >= p.M) v.x = v.y = v.z = v.w = 0u;
+            af[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    __syncthreads();                         // slices 0 and 1 landed, bias staged, A fragments loaded
+    if (loader) {
+        for (int nt = 0; nt < n_tiles; ++nt) {
+            // slice nt+2 goes where slice nt-1 was: its readers passed barrier nt-1.  Before barrier nt, slice nt+1 must have
+            // landed: everything but the PIECES just issued.
+            if (nt + 2 < n_tiles) {
+                issue_b(nt + 2);
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+        return;
+    }
+    char* stage = smem + AS_RING * BTILE + wid * 4096;
+    const int c8 = lane & 7;
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        const char* b_s = smem + (nt % AS_RING) * BTILE;
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int r = tj * 32 + frow;
+                const uint4v vb = *reinterpret_cast<const uint4v*>(b_s + r * ROW_BYTES + ((((2 * ks + fhalf) ^ r) % CHUNKS) << 4));
+                acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), af[ks], acc[tj], 0, 0, 0);
+            }
+        }
+        // every LDS read of this slice is consumed: release the buffer (the loader refills it two slices ahead)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- lane holds row m0 + frow, columns nt*64 + tj*32 + 8*q + 4*fhalf + e (reg 4*q + e): park as bf16 in the wave's
+        //      staging rows (8-byte units XOR (row & 15)), then whole 128-byte row segments to global ----
+        const int n0 = nt * AS_BN;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = tj * 32 + 8 * q + 4 * fhalf;
+                const float4v bv = *reinterpret_cast<const float4v*>(bias_s + n0 + nl);
+                const float v0 = acc[tj][4 * q] + bv.x, v1 = acc[tj][4 * q + 1] + bv.y, v2 = acc[tj][4 * q + 2] + bv.z,
+                            v3 = acc[tj][4 * q + 3] + bv.w;
+                uint2 t;
+                t.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                t.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                const int unit = tj * 8 + 2 * q + fhalf;
+                *reinterpret_cast<uint2*>(stage + frow * 128 + ((unit ^ (frow & 15)) << 3)) = t;
+            }
+        const int n = n0 + c8 * 8;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), sw = row & 15;
+            const uint2 lo = *reinterpret_cast<const uint2*>(stage + row * 128 + (((2 * c8) ^ sw) << 3));
+            const uint2 hi = *reinterpret_cast<const uint2*>(stage + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
+            const int m = m0 + row;
+            if (m < p.M && n < p.N) {
+                uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+                *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
 // sum the split-K slabs, add the bias, convert and write through the row scatter (N % 4 == 0)
 template <bool OUT_F32>
 __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, int nphase, GemmArgs p) {
@@ -456,6 +583,25 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
+    // short K, wide N, plain operands, bf16 result: the A-stationary kernel (the final 1x1 convolution forward)
+    if (!out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
+        a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
+        const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);
+#define EPI_ASTAT(KS)                                                                                                      \
+        do {                                                                                                               \
+            const size_t lds = AS_RING * (size_t)AS_BN * 32 * KS + AS_WAVES * 4096 + (size_t)((a.N + AS_BN - 1) / AS_BN) * AS_BN * 4;                                              \
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_astat_kernel<KS>),  \
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            if (attr != hipSuccess) return EPI_ERR_LAUNCH;                                                                 \
+            hipLaunchKernelGGL((head_gemm_astat_kernel<KS>), dim3(grid), dim3(AS_THREADS), lds, st, a);                     \
+        } while (0)
+        if (a.K == 256) EPI_ASTAT(16);
+        else if (a.K == 128) EPI_ASTAT(8);
+        else EPI_ASTAT(4);
+#undef EPI_ASTAT
+        EPI_CHECK_LAUNCH();
+        return EPI_OK;
+    }
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
     if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
     if (pl.nsplit > 1) {

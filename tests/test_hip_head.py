@@ -36,7 +36,9 @@ def close(got, ref, rel=1.2e-2, outliers=0.0):
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 1088, 256), (1000, 200, 128), (4096, 256, 1088), (77, 36, 192), (512, 256, 24), (300, 40, 200),
                                    # 256x256-tile configuration: ragged M and N, K tail, split-K (few tiles) and no split (many tiles)
-                                   (5164, 2528, 520), (2000, 2040, 4104), (65536, 256, 512), (2048, 1024, 2048), (700, 456, 576)])
+                                   (5164, 2528, 520), (2000, 2040, 4104), (65536, 256, 512), (2048, 1024, 2048), (700, 456, 576),
+                                   # A-stationary kernel (K in {64,128,256}, wide N, many rows): ragged M and N
+                                   (16500, 1088, 256), (20000, 520, 128), (16384, 264, 64)])
 def test_gemm_vs_torch(dev, m, n, k):
     from epipolarpose_amd import hip
     a = rnd((m, k), dev, 1).to(torch.bfloat16)
