@@ -56,8 +56,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTens
             *reinterpret_cast<float4v*>(t.v + i) = v;
             if (t.shadow) {
                 uint2 o;
-                o.x = (unsigned)f32_to_bf16(pp[0]) | ((unsigned)f32_to_bf16(pp[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(pp[2]) | ((unsigned)f32_to_bf16(pp[3]) << 16);
+                o.x = pack_bf16x2(pp[0], pp[1]);
+                o.y = pack_bf16x2(pp[2], pp[3]);
                 *reinterpret_cast<uint2*>(t.shadow + i) = o;
             }
         }

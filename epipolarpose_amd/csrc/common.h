@@ -24,13 +24,15 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short v) { return __uint_as_float(((unsigned int)v) << 16); }
 
-// round-to-nearest-even float -> bf16 (NaN kept quiet)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// round-to-nearest-even float -> bf16 on the gfx950 conversion instruction (v_cvt_pk_bf16_f32: two values per issue;
+// NaN stays a quiet NaN).  pack_bf16x2(lo, hi) = hi << 16 | lo.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    f32x2_t v; v.x = lo; v.y = hi;
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 // Element-type traits for the streaming kernels: VEC elements == 16 bytes per lane per access.
 template <typename T> struct Elem;
@@ -62,7 +64,7 @@ template <> struct Elem<unsigned short> {   // bf16 storage
         unsigned int w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (unsigned int)f32_to_bf16(v[2 * i]) | ((unsigned int)f32_to_bf16(v[2 * i + 1]) << 16);
+            w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         uint4v t; t.x = w[0]; t.y = w[1]; t.z = w[2]; t.w = w[3];
         *reinterpret_cast<uint4v*>(p) = t;
     }

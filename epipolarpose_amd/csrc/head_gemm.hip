@@ -259,8 +259,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
                         if (p.bias && n + e < p.N) v[e] += p.bias[n + e];
                     }
                     uint2 t;
-                    t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    t.x = pack_bf16x2(v[0], v[1]);
+                    t.y = pack_bf16x2(v[2], v[3]);
                     const int unit = tj * 8 + 2 * q + fhalf;
                     *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
                 }
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
                         unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n;
                         if (n + 3 < p.N) {
                             uint2 t;
-                            t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                            t.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                            t.x = pack_bf16x2(v[0], v[1]);
+                            t.y = pack_bf16x2(v[2], v[3]);
                             *reinterpret_cast<uint2*>(c) = t;
                         } else for (int e = 0; e < 4 && n + e < p.N; ++e) c[e] = f32_to_bf16(v[e]);
                     }
@@ -404,20 +404,34 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
     char* stage = smem + AS_RING * BTILE + wid * 4096;
     const int c8 = lane & 7;
     for (int nt = 0; nt < n_tiles; ++nt) {
-        const char* b_s = smem + (nt % AS_RING) * BTILE;
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
+        // B fragments are requested two k steps (four ds_read_b128) ahead of the MFMAs that consume them.  Address of
+        // (row r, k step ks) = slice base + r*ROW_BYTES + (((2ks + fhalf) ^ r) % CHUNKS) * 16 = (ks = 0 address) ^ (ks << 5):
+        // one XOR with a constant per read, on an offset that changes with nt (so that the 32 addresses are not hoisted
+        // out of the slice loop into 32 live registers)
+        const unsigned slice_off = (unsigned)(nt % AS_RING) * BTILE;
+        auto read_b = [&](int ks, uint4v (&f)[2]) {
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) {
                 const int r = tj * 32 + frow;
-                const uint4v vb = *reinterpret_cast<const uint4v*>(b_s + r * ROW_BYTES + ((((2 * ks + fhalf) ^ r) % CHUNKS) << 4));
-                acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vb), af[ks], acc[tj], 0, 0, 0);
+                const unsigned off = (slice_off + r * ROW_BYTES + (((fhalf ^ r) % CHUNKS) << 4)) ^ (unsigned)(((2 * ks) % CHUNKS) << 4);
+                f[tj] = *reinterpret_cast<const uint4v*>(smem + off);
             }
+        };
+        uint4v fb[3][2];
+        read_b(0, fb[0]);
+        if (KSTEPS > 1) read_b(1, fb[1]);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 2 < KSTEPS) read_b(ks + 2, fb[(ks + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+                acc[tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[ks % 3][tj]), af[ks], acc[tj], 0, 0, 0);
         }
         // every LDS read of this slice is consumed: release the buffer (the loader refills it two slices ahead)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -433,8 +447,8 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
                 const float v0 = acc[tj][4 * q] + bv.x, v1 = acc[tj][4 * q + 1] + bv.y, v2 = acc[tj][4 * q + 2] + bv.z,
                             v3 = acc[tj][4 * q + 3] + bv.w;
                 uint2 t;
-                t.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-                t.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                t.x = pack_bf16x2(v0, v1);
+                t.y = pack_bf16x2(v2, v3);
                 const int unit = tj * 8 + 2 * q + fhalf;
                 *reinterpret_cast<uint2*>(stage + frow * 128 + ((unit ^ (frow & 15)) << 3)) = t;
             }
@@ -480,8 +494,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
         *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = a;
     } else {
         uint2 o;
-        o.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
-        o.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+        o.x = pack_bf16x2(a.x, a.y);
+        o.y = pack_bf16x2(a.z, a.w);
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
     }
 }
