@@ -268,8 +268,9 @@ def main():
                    "avg_ms": round(ms_f, 5), "launches": n_f}}
         if head_ms > 0:
             ach = head_flops / (head_ms * 1e-3) / 1e12
-            roofline = {"kernel": "head_gemm_kernel (deconvolution head fwd + bwd-data, final 1x1 conv fwd + bwd-data: %d launches "
-                                  "per step; the hand-written kernel with the largest share of the step)" % round(head_launches),
+            roofline = {"kernel": "head_gemm_kernel + head_gemm_astat_kernel (deconvolution head fwd + bwd-data, final 1x1 conv bwd-data; "
+                                  "final 1x1 conv fwd on the A-stationary variant: %d launches per step; the hand-written kernel "
+                                  "family with the largest share of the step)" % round(head_launches),
                         "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
                         "traffic": traffic, "algorithmic_flops_per_launch": head_flops / max(head_launches, 1),
                         "avg_ms": round(head_ms / max(head_launches, 1), 5), "launches_per_step": head_launches,

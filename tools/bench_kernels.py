@@ -180,6 +180,29 @@ def bench_bn():
             shape, res, tf, rf * nbytes / tf / 1e6, ts, tb, rb * nbytes / tb / 1e6, tsb), flush=True)
 
 
+def bench_wrw1x1():
+    """Weight gradient of the backbone's 1x1 convolutions: our TN GEMM (fp32 out, split over rows) vs MIOpen/CK through
+    aten.convolution_backward (weight only)."""
+    shapes = [(131072, 64, 64, 1), (131072, 256, 64, 3), (131072, 64, 256, 2), (131072, 128, 256, 1), (32768, 512, 128, 4),
+              (32768, 128, 512, 3), (32768, 256, 512, 1), (8192, 1024, 256, 6), (8192, 256, 1024, 5), (8192, 512, 1024, 1),
+              (2048, 2048, 512, 3), (2048, 512, 2048, 2)]
+    tot_o = tot_s = 0.0
+    for r, cout, cin, count in shapes:
+        hw = int((r // 32) ** 0.5)
+        x = torch.randn(32, cin, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(32, cout, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(cout, cin, 1, 1, device=DEV).to(torch.bfloat16)
+        a2, b2 = dy.permute(0, 2, 3, 1).reshape(r, cout), x.permute(0, 2, 3, 1).reshape(r, cin)
+        to = timeit(lambda: hip.gemm_tn_bf16(a2, b2))
+        ts = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False]))
+        fl = 2.0 * r * cout * cin
+        tot_o += to * count
+        tot_s += ts * count
+        print("wrw1x1 R=%6d %4d<-%4d x%d  ours %.4f ms %6.1f TF   stock %.4f ms %6.1f TF" % (r, cout, cin, count, to, fl / to / 1e9, ts, fl / ts / 1e9),
+              flush=True)
+    print("wrw1x1 total per step: ours %.3f ms, stock %.3f ms (stock includes its fill / cast launches)" % (tot_o, tot_s))
+
+
 if __name__ == "__main__":
     hip.load()
     what = sys.argv[1:] or ["softargmax", "gemm", "deconv", "tri", "bn"]
