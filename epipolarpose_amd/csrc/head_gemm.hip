@@ -22,7 +22,7 @@ namespace epi {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GBM = 128, GBN = 128, GBK = 64, GTHREADS = 256;      // the TN kernel's tile (and the small NT tile)
+constexpr int GBK = 64;                            // K (reduction) depth of one staged tile, every kernel
 
 // NT kernel tile configurations: 2 x WN waves, each wave TM x 2 MFMA tiles (32x32).
 //   small: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups / CU)   -- short K, few rows, ragged N
@@ -527,7 +527,7 @@ static GemmPlan gemm_plan_cfg(bool big, int M, int N, int K, int nphase) {
     const long long enough = big ? 200 : 384, target = big ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
-        nsplit = (int)((target + wgs - 1) / wgs);
+        nsplit = (int)(target / wgs);               // floor: one workgroup over the resident capacity costs a whole extra round
         const int max_split = K / 512 > 0 ? K / 512 : 1;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit > 16) nsplit = 16;
@@ -711,7 +711,7 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
 
 // ---------------------------------------------------------------------------------------------------------------
 // "TN" GEMM for the weight gradients:  C[i][j] = sum_r A[r][i] * B(r)[j]   (reduction over the ROW index of both
-// operands: r enumerates batch*pixels).  Both tiles are staged row-major ([r][i], [r][j], 320-byte padded rows) and
+// operands: r enumerates batch*pixels).  Both tiles are row-major [r][cols] images of global memory filled by DMA, and
 // the MFMA operands (8 consecutive r per lane) are produced by the LDS transpose read ds_read_b64_tr_b16
 // (a 16-lane group reads a 4(r) x 16(col) block; lane c receives column c).  B may be an implicit gather
 // (ConvTranspose2d weight gradient: rows of dOut at (2*ih-1+kh, 2*iw-1+kw) for tap blockIdx.z).
@@ -720,9 +720,6 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
 namespace epi {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-constexpr int TN_ROW_BYTES = 320;                       // 128 cols * 2 B + 64 B pad: the 4 rows x 64 B a 32-lane transpose-read group touches
-                                                        // land on 4 disjoint 16-bank quarters (288 B left a 2-way conflict, PMC: 7 %)
-constexpr int TN_TILE_BYTES = GBK * TN_ROW_BYTES;       // 18 KiB per operand tile
 
 struct GemmTnArgs {
     const unsigned short* A;      // [R][lda]
@@ -733,20 +730,44 @@ struct GemmTnArgs {
     GemmGather gb;                // gather for B (enabled = 0: plain)
 };
 
+// Tile configurations of the TN kernel (64 reduction rows per K tile; both operand tiles are row-major [r][cols] images
+// of global memory, UNPADDED rows of COLS*2 bytes, filled by direct-to-LDS DMA):
+//   small: 128(i) x 128(j), 4 waves (2 x 2, each 64 x 64),  64 KiB LDS, 2 workgroups / CU
+//   big:   256(i) x 256(j), 8 waves (2 x 4, each 128 x 64), 128 KiB LDS, 1 workgroup / CU  (half the operand traffic per flop)
+// Bank conflicts of the transpose reads are avoided by XOR-ing the 16-byte chunk index with 4*(row & 3) -- applied on the
+// SOURCE address of the DMA, like the NT kernel: a 32-lane ds_read_b64_tr_b16 group touches rows r..r+3 at two adjacent
+// 32-byte column blocks, which then fall into four disjoint 64-byte bank windows.
+template <int TI_, int WJ_> struct TnCfg {
+    static constexpr int TI = TI_, WJ = WJ_, NW = 2 * WJ_, THREADS = 64 * NW;
+    static constexpr int BI = 2 * TI_ * 32, BJ = WJ_ * 64;
+    static constexpr int A_ROWB = BI * 2, B_ROWB = BJ * 2;                      // bytes per tile row
+    static constexpr int A_BYTES = GBK * A_ROWB, B_BYTES = GBK * B_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_PIECES = A_BYTES / 1024 / NW, B_PIECES = B_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave
+    static_assert(A_PIECES == 4 && B_PIECES == 4, "one A and one B piece per k step");
+};
+typedef TnCfg<2, 2> TnSmall;
+typedef TnCfg<4, 4> TnBig;
+
+// MFMA operand (8 consecutive r per lane) by two transpose reads: a 16-lane group reads a 4(r) x 16(col) block, lane c
+// receives column c.  Lane c addresses row row0 + (c >> 2) (and +4), 4 columns at col + 4*(c & 3); col % 32 == 0, row0 % 8 == 0.
+template <int ROWB>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col, int lane_c) {
-    // lane c of a 16-lane group addresses row row0 + (c >> 2) (and +4 for the second half), 4 columns at col + 4*(c & 3)
-    const char* p = tile + (row0 + (lane_c >> 2)) * TN_ROW_BYTES + (col + 4 * (lane_c & 3)) * 2;
+    const int row = row0 + (lane_c >> 2);
+    const int chunk = (col >> 3) + ((lane_c & 3) >> 1);
+    const char* p = tile + row * ROWB + ((chunk ^ (4 * (row & 3))) << 4) + 8 * (lane_c & 1);
     struct { s16x4 lo, hi; } v;
     v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TN_ROW_BYTES));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROWB));
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(GTHREADS, 2) void head_gemm_tn_kernel(GemmTnArgs p) {
+template <typename Cfg, bool GATHER>
+__global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn_kernel(GemmTnArgs p) {
+    constexpr int TI = Cfg::TI, BI = Cfg::BI, BJ = Cfg::BJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int tiles_j = (p.J + GBN - 1) / GBN;
+    const int wm = wid / Cfg::WJ, wn = wid % Cfg::WJ;
+    const int tiles_j = (p.J + BJ - 1) / BJ;
     // logical id: tile fastest, then split, then tap: the tiles of one split (same rows r) stay on one XCD
     const int total_wg = gridDim.x * gridDim.y * gridDim.z;
     int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total_wg);
@@ -754,49 +775,53 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_tn_kernel(GemmTnArgs p)
     lid /= (int)gridDim.x;
     const int split = lid % (int)gridDim.y, tap = lid / (int)gridDim.y;
     const int tile_i = tile_id / tiles_j, tile_j = tile_id - tile_i * tiles_j;
-    const int i0 = tile_i * GBM, j0 = tile_j * GBN;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
     const int r_begin = split * p.rows_per_split;
     const int r_end = min(p.R, r_begin + p.rows_per_split);
+    const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
 
-    const int srow = tid >> 4, schunk = tid & 15;          // 16 rows x 16 chunks(16 B) per pass, 4 passes per 64-row tile
-    const bool a_col_ok = i0 + schunk * 8 < p.I, b_col_ok = j0 + schunk * 8 < p.J;
-    uint4v ra[4], rb[4];
-    auto load_tiles = [&](int r0) {
+    // ---- DMA roles: piece q (0..3) of wave w covers tile rows (4w + q) * RPP .. + RPP-1 (RPP = 1024 / row bytes); lane l
+    //      lands at row base + l / CH, physical chunk l % CH and fetches logical chunk (l % CH) ^ 4*(row & 3) ----
+    constexpr int A_CH = Cfg::A_ROWB / 16, A_RPP = 1024 / Cfg::A_ROWB, B_CH = Cfg::B_ROWB / 16, B_RPP = 1024 / Cfg::B_ROWB;
+    int a_row[4], a_col[4], b_row[4], b_col[4];
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int r = r0 + ps * 16 + srow;
-            const bool rok = r < r_end;
-            uint4v z; z.x = z.y = z.z = z.w = 0u;
-            ra[ps] = (rok && a_col_ok) ? *reinterpret_cast<const uint4v*>(p.A + (long long)r * p.lda + i0 + schunk * 8) : z;
-            bool ok = rok && b_col_ok;
+    for (int q = 0; q < 4; ++q) {
+        a_row[q] = (wid * 4 + q) * A_RPP + lane / A_CH;
+        a_col[q] = i0 + (((lane % A_CH) ^ (4 * (a_row[q] & 3))) << 3);
+        b_row[q] = (wid * 4 + q) * B_RPP + lane / B_CH;
+        b_col[q] = j0 + (((lane % B_CH) ^ (4 * (b_row[q] & 3))) << 3);
+    }
+    auto issue_piece = [&](int q, int r0, int buf) {
+        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
+        char* b_s = a_s + Cfg::A_BYTES;
+        {
+            const int r = r0 + a_row[q];
+            const bool ok = r < r_end && a_col[q] < p.I;
+            const void* src = ok ? reinterpret_cast<const void*>(p.A + (long long)r * p.lda + a_col[q]) : reinterpret_cast<const void*>(zero_src);
+            glds16(src, a_s + q * 1024);
+        }
+        {
+            const int r = r0 + b_row[q];
+            bool ok = r < r_end && b_col[q] < p.J;
             long long off;
-            if (p.gb.enabled) {
+            if (GATHER) {
                 const int hw = p.gb.Hg * p.gb.Wg;
                 const int n = r / hw, rem = r - n * hw;
                 const int ih = rem / p.gb.Wg, iw = rem - ih * p.gb.Wg;
                 const int y = ih * p.gb.stride + p.gb.dy[tap], x = iw * p.gb.stride + p.gb.dx[tap];
                 ok = ok && (unsigned)y < (unsigned)p.gb.Hs && (unsigned)x < (unsigned)p.gb.Ws;
-                off = (((long long)n * p.gb.Hs + y) * p.gb.Ws + x) * p.ldb + j0 + schunk * 8;
+                off = (((long long)n * p.gb.Hs + y) * p.gb.Ws + x) * p.ldb + b_col[q];
             } else {
-                off = (long long)r * p.ldb + j0 + schunk * 8;
+                off = (long long)r * p.ldb + b_col[q];
             }
-            rb[ps] = ok ? *reinterpret_cast<const uint4v*>(p.B + off) : z;
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* a_s = smem + buf * 2 * TN_TILE_BYTES;
-        char* b_s = a_s + TN_TILE_BYTES;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int o = (ps * 16 + srow) * TN_ROW_BYTES + schunk * 16;
-            *reinterpret_cast<uint4v*>(a_s + o) = ra[ps];
-            *reinterpret_cast<uint4v*>(b_s + o) = rb[ps];
+            const void* src = ok ? reinterpret_cast<const void*>(p.B + off) : reinterpret_cast<const void*>(zero_src);
+            glds16(src, b_s + q * 1024);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -804,45 +829,53 @@ __global__ __launch_bounds__(GTHREADS, 2) void head_gemm_tn_kernel(GemmTnArgs p)
 
     const int nk = (r_end - r_begin + GBK - 1) / GBK;
     if (nk > 0) {
-        load_tiles(r_begin);
-        store_tiles(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(q, r_begin, 0);
     }
     __syncthreads();
     const int lane_c = lane & 15, grp = lane >> 4;
     const int cblk = 16 * (grp & 1), khalf = grp >> 1;
-    for (int kt = 0; kt < nk; ++kt) {
+    auto read_frags = [&](const char* a_s, const char* b_s, int ks, bf16x8 (&af)[TI], bf16x8 (&bfr)[2]) {
+#pragma unroll
+        for (int t = 0; t < TI; ++t) af[t] = tr_frag<Cfg::A_ROWB>(a_s, ks * 16 + 8 * khalf, wm * (TI * 32) + t * 32 + cblk, lane_c);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bfr[t] = tr_frag<Cfg::B_ROWB>(b_s, ks * 16 + 8 * khalf, wn * 64 + t * 32 + cblk, lane_c);
+    };
+    // one K tile (64 reduction rows): fragments of k step ks+1 requested before the MFMAs of step ks, the next tile's DMA
+    // pieces issued one per k step between the MFMA groups (same structure as head_gemm_kernel)
+    auto k_tile = [&](int kt, auto has_next_tag) {
+        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(r_begin + (kt + 1) * GBK);
-        const char* a_s = smem + buf * 2 * TN_TILE_BYTES;
-        const char* b_s = a_s + TN_TILE_BYTES;
+        const char* a_s = smem + buf * Cfg::STAGE_BYTES;
+        const char* b_s = a_s + Cfg::A_BYTES;
+        bf16x8 af[2][TI], bfr[2][2];
+        read_frags(a_s, b_s, 0, af[0], bfr[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
+            if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAS_NEXT) issue_piece(ks, r_begin + (kt + 1) * GBK, buf ^ 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = tr_frag(a_s, ks * 16 + 8 * khalf, wm * 64 + t * 32 + cblk, lane_c);
-                bfr[t] = tr_frag(b_s, ks * 16 + 8 * khalf, wn * 64 + t * 32 + cblk, lane_c);
-            }
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < 2; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti], bfr[tj], acc[ti][tj], 0, 0, 0);
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][ti], bfr[ks & 1][tj], acc[ti][tj], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type());
+    if (nk > 0) k_tile(nk - 1, std::false_type());
     // D[i][j]: lane holds column j = lane & 31, rows i = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
     float* slab = p.C + ((long long)split * gridDim.z + tap) * p.I * p.J;
     const int fcol = lane & 31, fhalf = lane >> 5;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
             const int j = j0 + wn * 64 + tj * 32 + fcol;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int i = i0 + wm * 64 + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
+                const int i = i0 + wm * (TI * 32) + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
                 if (i < p.I && j < p.J) slab[(long long)i * p.J + j] = acc[ti][tj][reg];
             }
         }
@@ -858,39 +891,65 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, 
 
 }  // namespace epi
 
-static int pick_split(int R, long long tiles, int ntap) {
-    // enough workgroups to fill 256 CUs x 2, but at least 1024 reduction rows per split
-    int nsplit = (int)((1024 + tiles * ntap - 1) / (tiles * ntap));
-    const int max_split = (R + 1023) / 1024;
+struct TnPlan { bool big; long long tiles; int nsplit, rps; };
+
+// big (256 x 256, 1 workgroup / CU) when both output dimensions fill 256-wide tiles; the reduction is split until every CU
+// has a workgroup (small tile: four), each split keeping >= 512 (small tile: 1024) rows
+static TnPlan tn_plan(int R, int I, int J, int ntap) {
+    TnPlan pl;
+    auto fills = [](int n) { const int t = (n + 255) / 256; return n >= 192 && t * 256 <= n + n / 4; };
+    pl.big = fills(I) && fills(J) && gemm_tile_override() != 1;
+    if (gemm_tile_override() == 2) pl.big = true;
+    const int b = pl.big ? 256 : 128;
+    pl.tiles = (long long)((I + b - 1) / b) * ((J + b - 1) / b);
+    const long long wgs = pl.tiles * ntap, target = pl.big ? 256 : 1024;
+    int nsplit = (int)(target / wgs);               // floor: never one workgroup more than the CUs can hold at once
+    const int min_rows = pl.big ? 512 : 1024;
+    const int max_split = (R + min_rows - 1) / min_rows;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit < 1) nsplit = 1;
-    return nsplit;
+    int rps = (R + nsplit - 1) / nsplit;
+    rps = (rps + GBK - 1) / GBK * GBK;
+    pl.rps = rps;
+    pl.nsplit = (R + rps - 1) / rps;
+    return pl;
+}
+
+template <typename Cfg, bool GATHER>
+static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, int ntap, hipStream_t st) {
+    const size_t lds = 2 * Cfg::STAGE_BYTES;
+    if (lds > 65536) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_tn_kernel<Cfg, GATHER>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return EPI_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((head_gemm_tn_kernel<Cfg, GATHER>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)ntap), dim3(Cfg::THREADS),
+                       lds, st, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
 }
 
 static int launch_tn(GemmTnArgs a, int ntap, float* out, float* slab_ws, size_t slab_bytes, hipStream_t st) {
     if (!a.A || !a.B || !out || !slab_ws || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15u) return EPI_ERR_UNSUPPORTED;
-    const long long tiles = (long long)((a.I + GBM - 1) / GBM) * ((a.J + GBN - 1) / GBN);
-    const int nsplit = pick_split(a.R, tiles, ntap);
-    int rps = (a.R + nsplit - 1) / nsplit;
-    rps = (rps + GBK - 1) / GBK * GBK;
-    const int nsplit2 = (a.R + rps - 1) / rps;
+    const TnPlan pl = tn_plan(a.R, a.I, a.J, ntap);
     const long long n = (long long)ntap * a.I * a.J;
-    if ((size_t)nsplit2 * n * sizeof(float) > slab_bytes) return EPI_ERR_WORKSPACE;
-    a.rows_per_split = rps;
+    if ((size_t)pl.nsplit * n * sizeof(float) > slab_bytes) return EPI_ERR_WORKSPACE;
+    a.rows_per_split = pl.rps;
     a.C = slab_ws;
-    hipLaunchKernelGGL(head_gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)nsplit2, (unsigned)ntap), dim3(GTHREADS), 4 * TN_TILE_BYTES, st, a);
-    EPI_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab_ws, nsplit2, n, out);
+    int rc;
+    if (pl.big) rc = a.gb.enabled ? launch_tn_cfg<TnBig, true>(a, pl, ntap, st) : launch_tn_cfg<TnBig, false>(a, pl, ntap, st);
+    else rc = a.gb.enabled ? launch_tn_cfg<TnSmall, true>(a, pl, ntap, st) : launch_tn_cfg<TnSmall, false>(a, pl, ntap, st);
+    if (rc != EPI_OK) return rc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
 extern "C" size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap) {
     if (R <= 0 || I <= 0 || J <= 0 || ntap <= 0) return 0;
-    const long long tiles = (long long)((I + GBM - 1) / GBM) * ((J + GBN - 1) / GBN);
-    return (size_t)pick_split(R, tiles, ntap) * ntap * I * J * sizeof(float);
+    return (size_t)tn_plan(R, I, J, ntap).nsplit * ntap * I * J * sizeof(float);
 }
 
 // C[I][J] (f32) = A[R][I]^T * B[R][J]   (weight gradient of the 1x1 convolution: A = dlogits, B = activations)
