@@ -881,12 +881,26 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
         }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ out) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// out[e] = sum over the splits.  tap_inner != 0: the slabs are [tap][I][J], the result is written as [I][tap][J] (the memory
+// order of a channels_last convolution weight [Cout][KH][KW][Cin]); out_bf16: bf16 result (J % 2 == 0, two values per thread)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out, int ntap, int I, int J,
+                                   int tap_inner, int out_bf16) {
+    const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[(long long)k * n + e];
-    out[e] = s;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < nsplit; ++k) {
+        const float2 v = *reinterpret_cast<const float2*>(slabs + (long long)k * n + e);
+        s0 += v.x; s1 += v.y;
+    }
+    long long d = e;
+    if (tap_inner) {
+        const int j = (int)(e % J);
+        const long long ti = e / J;
+        const int i = (int)(ti % I), tap = (int)(ti / I);
+        d = ((long long)i * ntap + tap) * J + j;
+    }
+    if (out_bf16) reinterpret_cast<unsigned int*>(out)[d >> 1] = pack_bf16x2(s0, s1);
+    else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + d) = o; }
 }
 
 }  // namespace epi
@@ -929,7 +943,8 @@ static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, int ntap, hipStr
     return EPI_OK;
 }
 
-static int launch_tn(GemmTnArgs a, int ntap, float* out, float* slab_ws, size_t slab_bytes, hipStream_t st) {
+static int launch_tn(GemmTnArgs a, int ntap, void* out, float* slab_ws, size_t slab_bytes, hipStream_t st, int tap_inner = 0,
+                     int out_bf16 = 0) {
     if (!a.A || !a.B || !out || !slab_ws || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15u) return EPI_ERR_UNSUPPORTED;
@@ -942,7 +957,8 @@ static int launch_tn(GemmTnArgs a, int ntap, float* out, float* slab_ws, size_t 
     if (pl.big) rc = a.gb.enabled ? launch_tn_cfg<TnBig, true>(a, pl, ntap, st) : launch_tn_cfg<TnBig, false>(a, pl, ntap, st);
     else rc = a.gb.enabled ? launch_tn_cfg<TnSmall, true>(a, pl, ntap, st) : launch_tn_cfg<TnSmall, false>(a, pl, ntap, st);
     if (rc != EPI_OK) return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, ntap, a.I, a.J,
+                       tap_inner, out_bf16);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
@@ -970,4 +986,25 @@ extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* 
     for (int kh = 0; kh < 4; ++kh)
         for (int kw = 0; kw < 4; ++kw) { a.gb.dy[4 * kh + kw] = kh - 1; a.gb.dx[4 * kh + kw] = kw - 1; }
     return launch_tn(a, 16, dw_taps, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// Weight gradient of a Conv2d (groups = 1, dilation = 1), NHWC bf16:  x [B][H][W][Cin], dy [B][Ho][Wo][Cout]  ->
+// dw [Cout][KH][KW][Cin] (the memory order of a channels_last weight; for KH = KW = 1 also the contiguous one), f32 or bf16.
+//   dW[co][kh][kw][ci] = sum over (n, oh, ow) of dy[n][oh][ow][co] * x[n][oh*stride + kh - pad][ow*stride + kw - pad][ci]
+// = KH*KW taps of the TN GEMM with A = dy (plain rows) and B = x gathered per tap.  Replaces MIOpen's split-K wrw kernels
+// and the memset / zero-fill / cast launches around them.  workspace: epi_gemm_tn_workspace_bytes(B*Ho*Wo, Cout, Cin, KH*KW).
+extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
+                                     int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (KH * KW > 16 || (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16)) return EPI_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    GemmTnArgs a = {};
+    a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.R = B * Ho * Wo; a.I = Cout; a.J = Cin; a.lda = Cout; a.ldb = Cin;
+    if (!(KH == 1 && KW == 1 && stride == 1 && pad == 0)) {
+        a.gb.enabled = 1; a.gb.Hg = Ho; a.gb.Wg = Wo; a.gb.Hs = H; a.gb.Ws = W; a.gb.Cs = Cin; a.gb.stride = stride;
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KW; ++kw) { a.gb.dy[kh * KW + kw] = kh - pad; a.gb.dx[kh * KW + kw] = kw - pad; }
+    }
+    return launch_tn(a, KH * KW, dw, (float*)workspace, workspace_bytes, (hipStream_t)stream, 1, dw_dtype == EPI_BF16);
 }

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -524,6 +525,25 @@ def deconv4x4s2_bwd_weight(x, dy):
                "epi_deconv4x4s2_bwd_weight")
         timer.stop(ev)
     return taps.reshape(4, 4, cin, cout).permute(2, 3, 0, 1).contiguous()
+
+
+def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
+    """Weight gradient of a Conv2d (groups 1): x [B, Cin, H, W], dy [B, Cout, Ho, Wo] (channels_last bf16) -> dW [Cout, Cin, KH, KW]
+    (channels_last memory), f32 or bf16."""
+    lib = load()
+    x, dy = _nhwc_bf16(x, "x"), _nhwc_bf16(dy, "dy")
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+    ho, wo = (h + 2 * padding - kh) // stride + 1, (w + 2 * padding - kw) // stride + 1
+    if tuple(dy.shape) != (b, cout, ho, wo):
+        raise ValueError("dy shape %s does not match the convolution geometry %s" % (tuple(dy.shape), (b, cout, ho, wo)))
+    dw = torch.empty((cout, cin, kh, kw), dtype=dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_gemm_tn_workspace_bytes(b * ho * wo, cout, cin, kh * kw), x.device)
+    with _on(x.device):
+        _check(lib.epi_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32, b, h, w, cin, cout,
+                                         kh, kw, stride, padding, _ptr(ws), ws.numel(), _stream()), "epi_conv2d_bwd_weight")
+    return dw
 
 
 def column_sum_bf16(x):

@@ -208,6 +208,13 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, epi_stream_t stream);
 
+/* Weight gradient of a Conv2d (groups 1, dilation 1) on NHWC bf16 tensors -- the backbone convolutions' backward-weight
+ * (autograd of nn.Conv2d in lib/models/pose3d_resnet.py:21-88), which the reference leaves to cuDNN:
+ *   x [B][H][W][Cin], dy [B][Ho][Wo][Cout] -> dw [Cout][KH][KW][Cin] (channels_last weight order), dw_dtype EPI_F32 | EPI_BF16;
+ *   KH*KW <= 16, Cin % 8 == 0, Cout % 8 == 0.  workspace: epi_gemm_tn_workspace_bytes(B*Ho*Wo, Cout, Cin, KH*KW). */
+int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (ntap = 1 for epi_gemm_tn_bf16, 16 for the deconvolution).
  *   epi_gemm_tn_bf16:            C[I][J] = A[R][I]^T * B[R][J]  (final conv: A = dlogits, B = activations -> dW[Cout][Cin])

@@ -196,3 +196,20 @@ def test_fused_bn_call_patterns(dev):
     close(m.running_mean, ref.running_mean, rel=2e-3)
     close(m.running_var, ref.running_var, rel=2e-3)
     assert int(m.num_batches_tracked) == int(ref.num_batches_tracked) == 9
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,k,stride,pad", [(4, 16, 16, 64, 128, 1, 1, 0), (2, 12, 10, 64, 72, 3, 1, 1), (3, 9, 11, 128, 64, 3, 2, 1),
+                                                         (32, 16, 16, 256, 256, 3, 1, 1), (8, 32, 32, 256, 512, 1, 1, 0)])
+def test_conv2d_bwd_weight_vs_torch(dev, b, h, w, cin, cout, k, stride, pad):
+    from epipolarpose_amd import hip
+    x = rnd((b, cin, h, w), dev, 21).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = rnd((b, cout, ho, wo), dev, 22).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wt = torch.zeros((cout, cin, k, k), device=dev, requires_grad=True)
+    F.conv2d(x.float(), wt, None, stride=stride, padding=pad).backward(dy.float())
+    got = hip.conv2d_bwd_weight(x, dy, k, stride, pad)
+    assert got.shape == wt.shape and got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+    close(got, wt.grad, rel=1e-4)
+    got16 = hip.conv2d_bwd_weight(x, dy, k, stride, pad, dtype=torch.bfloat16)
+    assert got16.dtype == torch.bfloat16
+    close(got16, wt.grad, rel=1e-2)

@@ -183,6 +183,7 @@ def bench_bn():
 def bench_wrw1x1():
     """Weight gradient of the backbone's 1x1 convolutions: our TN GEMM (fp32 out, split over rows) vs MIOpen/CK through
     aten.convolution_backward (weight only)."""
+    torch.backends.cudnn.benchmark = True
     shapes = [(131072, 64, 64, 1), (131072, 256, 64, 3), (131072, 64, 256, 2), (131072, 128, 256, 1), (32768, 512, 128, 4),
               (32768, 128, 512, 3), (32768, 256, 512, 1), (8192, 1024, 256, 6), (8192, 256, 1024, 5), (8192, 512, 1024, 1),
               (2048, 2048, 512, 3), (2048, 512, 2048, 2)]
@@ -201,6 +202,28 @@ def bench_wrw1x1():
         print("wrw1x1 R=%6d %4d<-%4d x%d  ours %.4f ms %6.1f TF   stock %.4f ms %6.1f TF" % (r, cout, cin, count, to, fl / to / 1e9, ts, fl / ts / 1e9),
               flush=True)
     print("wrw1x1 total per step: ours %.3f ms, stock %.3f ms (stock includes its fill / cast launches)" % (tot_o, tot_s))
+
+
+def bench_wrw3x3():
+    """Weight gradient of the backbone's 3x3 convolutions: epi_conv2d_bwd_weight (TN GEMM with a 9-tap gather) vs MIOpen."""
+    torch.backends.cudnn.benchmark = True
+    shapes = [(64, 64, 64, 1, 3), (128, 128, 64, 2, 1), (128, 128, 32, 1, 3), (256, 256, 32, 2, 1), (256, 256, 16, 1, 5),
+              (512, 512, 16, 2, 1), (512, 512, 8, 1, 2)]
+    tot_o = tot_s = 0.0
+    for cin, cout, hw, stride, count in shapes:
+        x = torch.randn(32, cin, hw, hw, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ho = (hw + 2 - 3) // stride + 1
+        dy = torch.randn(32, cout, ho, ho, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(cout, cin, 3, 3, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        to = timeit(lambda: hip.conv2d_bwd_weight(x, dy, 3, stride, 1, dtype=torch.bfloat16))
+        ts = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1,
+                                                                [False, True, False]))
+        fl = 2.0 * 32 * ho * ho * cout * cin * 9
+        tot_o += to * count
+        tot_s += ts * count
+        print("wrw3x3 %4d->%4d @%3d s%d x%d  ours %.4f ms %6.1f TF   stock %.4f ms %6.1f TF" % (cin, cout, hw, stride, count, to, fl / to / 1e9,
+                                                                                              ts, fl / ts / 1e9), flush=True)
+    print("wrw3x3 total per step: ours %.3f ms, stock %.3f ms (stock includes its fill / cast launches)" % (tot_o, tot_s))
 
 
 if __name__ == "__main__":
