@@ -399,6 +399,106 @@ EPI_HD void correct_match(const double (&F)[3][3], double (&p1)[2], double (&p2)
     p2[0] = (y2[0] + p2[0] * y2[2]) / y2[2]; p2[1] = (y2[1] + p2[1] * y2[2]) / y2[2];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fundamental matrix from 2-D matches -- cv2.findFundamentalMat(u1, u2, FM_8POINT) (triangulation.py:216; cameras.py:136-143
+// asks for FM_LMEDS, whose random sampling is not reproducible: on outlier-free matches it converges to the same F).
+// Normalised 8-point algorithm as OpenCV's run8Point runs it: isotropic normalisation (centroid, mean distance sqrt 2),
+// eigenvector of the 9x9 A^T A with the smallest eigenvalue (cyclic Jacobi, float64), rank 2 through the 3x3 SVD,
+// de-normalisation, F[2][2] = 1.  x2^T F x1 = 0.  Returns 0 for degenerate input (fewer than 8 matches, coincident points).
+// ---------------------------------------------------------------------------------------------------------------------
+EPI_HD inline int fundamental_8point_one(const double* u1, const double* u2, int n, double (&F)[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) F[i][j] = 0.0;
+    if (n < 8) return 0;
+    double c1[2] = {0, 0}, c2[2] = {0, 0};
+    for (int i = 0; i < n; ++i) { c1[0] += u1[2 * i]; c1[1] += u1[2 * i + 1]; c2[0] += u2[2 * i]; c2[1] += u2[2 * i + 1]; }
+    const double rn = 1.0 / (double)n;
+    c1[0] *= rn; c1[1] *= rn; c2[0] *= rn; c2[1] *= rn;
+    double d1 = 0, d2 = 0;
+    for (int i = 0; i < n; ++i) {
+        const double ax = u1[2 * i] - c1[0], ay = u1[2 * i + 1] - c1[1], bx = u2[2 * i] - c2[0], by = u2[2 * i + 1] - c2[1];
+        d1 += sqrt(ax * ax + ay * ay);
+        d2 += sqrt(bx * bx + by * by);
+    }
+    d1 *= rn; d2 *= rn;
+    if (!(d1 >= 2.220446049250313e-16) || !(d2 >= 2.220446049250313e-16)) return 0;
+    const double s1 = 1.4142135623730951 / d1, s2 = 1.4142135623730951 / d2;
+    double A[9][9], V[9][9];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) { A[i][j] = 0.0; V[i][j] = (i == j) ? 1.0 : 0.0; }
+    for (int i = 0; i < n; ++i) {
+        const double x1 = (u1[2 * i] - c1[0]) * s1, y1 = (u1[2 * i + 1] - c1[1]) * s1;
+        const double x2 = (u2[2 * i] - c2[0]) * s2, y2 = (u2[2 * i + 1] - c2[1]) * s2;
+        const double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+        for (int a = 0; a < 9; ++a)
+            for (int b = a; b < 9; ++b) A[a][b] += r[a] * r[b];
+    }
+    for (int a = 0; a < 9; ++a)
+        for (int b = 0; b < a; ++b) A[a][b] = A[b][a];
+    // cyclic Jacobi on the symmetric 9x9: A <- J^T A J, V <- V J
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0, diag = 0;
+        for (int a = 0; a < 9; ++a) {
+            diag += A[a][a] * A[a][a];
+            for (int b = a + 1; b < 9; ++b) off += A[a][b] * A[a][b];
+        }
+        if (off <= 1e-30 * diag) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = A[p][q];
+                if (fabs(apq) <= 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 9; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int best = 0;
+    for (int a = 1; a < 9; ++a)
+        if (A[a][a] < A[best][best]) best = a;
+    double F0[3][3], U[3][3], sv[3], W[3][3];
+    for (int i = 0; i < 9; ++i) F0[i / 3][i % 3] = V[i][best];
+    svd3(F0, U, sv, W);
+    // rank 2: drop the smallest singular value.  F0 = U diag(s0, s1, 0) W^T
+    double G[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[i][j] = U[i][0] * sv[0] * W[j][0] + U[i][1] * sv[1] * W[j][1];
+    // F = T2^T G T1,  T = [[s, 0, -s cx], [0, s, -s cy], [0, 0, 1]]
+    double GT[3][3];
+    for (int i = 0; i < 3; ++i) {
+        GT[i][0] = G[i][0] * s1;
+        GT[i][1] = G[i][1] * s1;
+        GT[i][2] = -G[i][0] * s1 * c1[0] - G[i][1] * s1 * c1[1] + G[i][2];
+    }
+    for (int j = 0; j < 3; ++j) {
+        F[0][j] = s2 * GT[0][j];
+        F[1][j] = s2 * GT[1][j];
+        F[2][j] = -s2 * c2[0] * GT[0][j] - s2 * c2[1] * GT[1][j] + GT[2][j];
+    }
+    if (fabs(F[2][2]) > 1.1920928955078125e-07) {
+        const double inv = 1.0 / F[2][2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) F[i][j] *= inv;
+    }
+    return 1;
+}
+
 enum { TRI_ITER = 0, TRI_LS = 1, TRI_DLT = 2, TRI_POLY = 3 };
 
 template <typename T, int NV, int METHOD>
@@ -469,6 +569,18 @@ __global__ __launch_bounds__(256) void correct_matches_kernel(const double* __re
     correct_match(F, a, b);
     o1[2 * t] = a[0]; o1[2 * t + 1] = a[1];
     o2[2 * t] = b[0]; o2[2 * t + 1] = b[1];
+}
+
+// One fundamental matrix per group from its J matches (float64, one thread per group; the 9x9 Jacobi lives in scratch:
+// a few thousand groups at most, launch-latency bound).
+__global__ __launch_bounds__(64) void fundamental_8point_kernel(const double* __restrict__ u1, const double* __restrict__ u2, int G, int J,
+                                                                 double* __restrict__ Fm, int* __restrict__ status) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double F[3][3];
+    const int ok = fundamental_8point_one(u1 + (long long)g * J * 2, u2 + (long long)g * J * 2, J, F);
+    for (int i = 0; i < 9; ++i) Fm[(long long)g * 9 + i] = F[i / 3][i % 3];
+    if (status) status[g] = ok;
 }
 
 struct MetaDev {
@@ -670,6 +782,14 @@ extern "C" int epi_correct_matches(const double* F, const double* u1, const doub
     if (total > 0x7fffffffLL * 128) return EPI_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(correct_matches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, u1, u2,
                        G, J, out1, out2);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_fundamental_8point(const double* u1, const double* u2, int G, int J, double* F, int32_t* status, epi_stream_t stream) {
+    if (!u1 || !u2 || !F || G <= 0 || J <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(fundamental_8point_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, (hipStream_t)stream, u1, u2, G, J, F,
+                       (int*)status);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

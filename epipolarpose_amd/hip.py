@@ -38,6 +38,7 @@ _SIGNATURES = {
     "epi_triangulate_ls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_poly": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_fundamental_8point": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "epi_correct_matches": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
     "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
@@ -329,6 +330,20 @@ def triangulate(kps, proj, n_view, method="iterative", tolerance=3.0e-5, max_ite
             raise ValueError(method)
     _check(st, "epi_triangulate_" + method)
     return x, status
+
+
+def fundamental_8point(u1, u2):
+    """cv2.findFundamentalMat(..., FM_8POINT), batched.  u1, u2 [G, J, 2] float64 -> (F [G, 3, 3], status int32 [G])."""
+    lib = load()
+    u1, u2 = _dev(u1, torch.float64, "u1").contiguous(), _dev(u2, torch.float64, "u2").contiguous()
+    g, j, _ = u1.shape
+    if u2.shape != u1.shape or u1.shape[2] != 2:
+        raise ValueError("u1, u2 must both be [G, J, 2]")
+    f = torch.empty((g, 3, 3), dtype=torch.float64, device=u1.device)
+    status = torch.empty((g,), dtype=torch.int32, device=u1.device)
+    with _on(u1.device):
+        _check(lib.epi_fundamental_8point(_ptr(u1), _ptr(u2), g, j, _ptr(f), _ptr(status), _stream()), "epi_fundamental_8point")
+    return f, status
 
 
 def correct_matches(f, u1, u2):

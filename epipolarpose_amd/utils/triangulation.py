@@ -49,9 +49,33 @@ def linear_eigen_triangulation(u1, P1, u2, P2, max_coordinate_value=1.e16):
 
 
 def polynomial_triangulation(u1, P1, u2, P2):
-    """triangulation.py:184-220: optimal (Hartley & Sturm) correction of the matches, then the linear-eigen solve."""
+    """triangulation.py:184-220: optimal (Hartley & Sturm) correction of the matches, then the linear-eigen solve.  When the
+    correction with the projection-derived F yields NaN for every point (:213), F is re-estimated from the matches themselves
+    (8-point, :216) as the reference does."""
     x, st = triangulate_views(np.stack([u1, u2]), np.stack([P1[0:3, 0:4], P2[0:3, 0:4]]), "poly")
+    if np.isnan(x).all():
+        f, ok = find_fundamental_mat_8point(u1, u2)
+        if ok:
+            c1, c2 = correct_matches(f, np.asarray(u1, np.float64)[None], np.asarray(u2, np.float64)[None])
+            return linear_eigen_triangulation(c1[0], P1, c2[0], P2)
     return x, st.astype(bool)
+
+
+def find_fundamental_mat_8point(u1, u2, device=None):
+    """cv2.findFundamentalMat(u1, u2, cv2.FM_8POINT)[0] (triangulation.py:216): u1, u2 [N, 2] -> (F [3, 3] float64, ok)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    a = torch.as_tensor(np.asarray(u1, np.float64).reshape(1, -1, 2), device=device)
+    b = torch.as_tensor(np.asarray(u2, np.float64).reshape(1, -1, 2), device=device)
+    f, st = hip.fundamental_8point(a, b)
+    return f[0].cpu().numpy(), bool(st[0].item())
+
+
+def essential_matrix(F, K1, K2=None):
+    """cameras.py:133-134 (Camera.get_essential_matrix): E = K^T F K; K2 generalises to two different cameras (E = K2^T F K1).
+    Dataset-time 3x3 host arithmetic."""
+    k1 = np.asarray(K1, np.float64)
+    k2 = k1 if K2 is None else np.asarray(K2, np.float64)
+    return k2.T.dot(np.asarray(F, np.float64)).dot(k1)
 
 
 def correct_matches(F, points1, points2, device=None):

@@ -132,6 +132,11 @@ int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtyp
 int epi_triangulate_poly(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                          void* X, int32_t* status, epi_stream_t stream);
 
+/* cv2.findFundamentalMat(points1, points2, FM_8POINT) (triangulation.py:216; cameras.py:136-143 uses FM_LMEDS, whose random
+ * sampling is not reproducible), batched: u1/u2 [G][J][2] f64 -> F [G][3][3] f64 with x2^T F x1 = 0, rank 2, F[2][2] = 1;
+ * status [G] int32 or NULL: 1, or 0 for degenerate input (J < 8, coincident points: F = 0). */
+int epi_fundamental_8point(const double* u1, const double* u2, int G, int J, double* F, int32_t* status, epi_stream_t stream);
+
 /* cv2.correctMatches(F, points1, points2) (called at triangulation.py:210,216), batched: F [G][3][3],
  * u1/u2/out1/out2 [G][J][2], all f64 device pointers.  out may alias in. */
 int epi_correct_matches(const double* F, const double* u1, const double* u2, int G, int J,

@@ -202,3 +202,47 @@ def polynomial_triangulation(us, ps):
     f = fundamental_from_projections(ps[0], ps[1])
     c1, c2 = correct_matches(f, us[0], us[1])
     return dlt_triangulation(np.stack([c1, c2]), ps)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Fundamental matrix from 2-D matches: the reference calls cv2.findFundamentalMat(u1, u2, cv2.FM_8POINT)
+# (triangulation.py:216, the fall-back of polynomial_triangulation) and cv2.FM_LMEDS (cameras.py:136-143).  OpenCV is not
+# vendored; this restates the published normalised 8-point algorithm as OpenCV's run8Point implements it (calib3d
+# fundam.cpp): isotropic normalisation (centroid, mean distance sqrt 2), the eigenvector of A^T A with the smallest
+# eigenvalue, rank-2 enforcement by SVD, de-normalisation, scaling to F[2,2] = 1.  Convention: x2^T F x1 = 0.
+# LMedS (randomised sampling with OpenCV's internal RNG) is not reproducible and is not restated; on outlier-free matches
+# it converges to the same F.  Parity unpinned at the OpenCV layer (see oracle/__init__.py).
+# --------------------------------------------------------------------------------------------------------------------
+def fundamental_8point(u1, u2):
+    """u1, u2 [N, 2] (N >= 8) -> (F [3, 3], ok).  ok False: degenerate input (all points coincide)."""
+    u1, u2 = np.asarray(u1, np.float64), np.asarray(u2, np.float64)
+    n = u1.shape[0]
+    if n < 8:
+        return np.zeros((3, 3)), False
+    c1, c2 = u1.mean(0), u2.mean(0)
+    d1 = np.hypot(*(u1 - c1).T).sum() / n
+    d2 = np.hypot(*(u2 - c2).T).sum() / n
+    if d1 < np.finfo(np.float64).eps or d2 < np.finfo(np.float64).eps:
+        return np.zeros((3, 3)), False
+    s1, s2 = np.sqrt(2.0) / d1, np.sqrt(2.0) / d2
+    a, b = (u1 - c1) * s1, (u2 - c2) * s2
+    rows = np.stack([b[:, 0] * a[:, 0], b[:, 0] * a[:, 1], b[:, 0], b[:, 1] * a[:, 0], b[:, 1] * a[:, 1], b[:, 1], a[:, 0], a[:, 1],
+                     np.ones(n)], axis=1)
+    w, v = np.linalg.eigh(rows.T @ rows)
+    f0 = v[:, 0].reshape(3, 3)                                  # smallest eigenvalue
+    uu, sv, vt = np.linalg.svd(f0)
+    sv[2] = 0.0
+    f0 = uu @ np.diag(sv) @ vt
+    t1 = np.array([[s1, 0, -s1 * c1[0]], [0, s1, -s1 * c1[1]], [0, 0, 1.0]])
+    t2 = np.array([[s2, 0, -s2 * c2[0]], [0, s2, -s2 * c2[1]], [0, 0, 1.0]])
+    f = t2.T @ f0 @ t1
+    if abs(f[2, 2]) > np.finfo(np.float32).eps:
+        f = f / f[2, 2]
+    return f, True
+
+
+def essential_from_fundamental(f, k1, k2=None):
+    """cameras.py:133-134: E = K^T F K (the reference uses one camera matrix for both views; k2 generalises it: E = K2^T F K1)."""
+    k1 = np.asarray(k1, np.float64)
+    k2 = k1 if k2 is None else np.asarray(k2, np.float64)
+    return k2.T @ np.asarray(f, np.float64) @ k1

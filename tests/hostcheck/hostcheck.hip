@@ -48,3 +48,10 @@ extern "C" void hostcheck_svd3(const double* A, double* U, double* s, double* V)
     for (int i = 0; i < 9; ++i) { U[i] = u[i / 3][i % 3]; V[i] = v[i / 3][i % 3]; }
     for (int i = 0; i < 3; ++i) s[i] = sv[i];
 }
+
+extern "C" int hostcheck_fundamental_8point(const double* u1, const double* u2, int n, double* F) {
+    double Fm[3][3];
+    const int ok = epi::fundamental_8point_one(u1, u2, n, Fm);
+    for (int i = 0; i < 9; ++i) F[i] = Fm[i / 3][i % 3];
+    return ok;
+}

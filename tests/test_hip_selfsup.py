@@ -280,3 +280,33 @@ def test_polynomial_bulk_properties(dev):
         return ((ra - n1) ** 2).sum(-1) + ((rb - n2) ** 2).sum(-1)
     d, _ = hip.triangulate(noisy, pm, 2, "dlt")
     assert (reproj(a) <= reproj(d) + 1e-6).all()
+
+
+def test_fundamental_8point_vs_oracle(dev):
+    """cv2.findFundamentalMat(FM_8POINT) mirror: batched kernel == oracle; exact on noise-free matches; degenerate status."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.synthetic import make_cameras, project
+    from epipolarpose_amd.utils import triangulation as tri
+    cams = make_cameras(4)
+    rng = np.random.default_rng(5)
+    g_n, j = 64, 17
+    world = rng.normal(0, 300, size=(g_n, j, 3)) + [0, 0, 900]
+    u1 = np.stack([project(world[g], cams[g % 4])[0] for g in range(g_n)]) + rng.normal(0, 1.0, (g_n, j, 2))
+    u2 = np.stack([project(world[g], cams[(g + 1) % 4])[0] for g in range(g_n)]) + rng.normal(0, 1.0, (g_n, j, 2))
+    u1[5] = u1[5, :1]                                    # coincident points in view 1 -> degenerate
+    f, st = hip.fundamental_8point(torch.from_numpy(u1).to(dev), torch.from_numpy(u2).to(dev))
+    f, st = f.cpu().numpy(), st.cpu().numpy()
+    for g in range(g_n):
+        ref, ok = o_tri.fundamental_8point(u1[g], u2[g])
+        assert bool(st[g]) == ok
+        np.testing.assert_allclose(f[g], ref, rtol=0, atol=1e-10 * max(np.abs(ref).max(), 1e-300))
+    assert st[5] == 0 and st.sum() == g_n - 1
+    # reference-style wrappers
+    x = rng.normal(0, 300, size=(12, 3)) + [0, 0, 900]
+    a, b = project(x, cams[0])[0], project(x, cams[2])[0]
+    fm, ok = tri.find_fundamental_mat_8point(a, b)
+    ft = o_tri.fundamental_from_projections(cams[0]["projection_matrix"], cams[2]["projection_matrix"])
+    assert ok
+    np.testing.assert_allclose(fm, ft / ft[2, 2], atol=1e-8 * np.abs(ft / ft[2, 2]).max())
+    k = np.array([[1100.0, 0, 500.0], [0, 1100.0, 510.0], [0, 0, 1.0]])
+    np.testing.assert_allclose(tri.essential_matrix(fm, k), k.T @ fm @ k)

@@ -155,3 +155,38 @@ def test_hostcheck_polynomial_triangulation_matches_oracle(hostlib, pair, noise)
     hostlib.hostcheck_poly_triangulate(_dp(u1), _dp(u2), _dp(p1), _dp(p2), len(u1), _dp(xd), _dp(sd))
     np.testing.assert_allclose(xd, xo, atol=1e-4 if noise == 0.0 else 1e-6)
     np.testing.assert_array_equal(sd.astype(bool), so)
+
+
+# ------------------------------------------------------------------ fundamental matrix from matches (8-point)
+@pytest.mark.parametrize("pair", [(0, 1), (0, 3), (1, 2)])
+def test_oracle_8point_properties(pair):
+    _, u1, u2, p1, p2 = _scene(11, n=17, noise=0.0, pair=pair)
+    f, ok = o_tri.fundamental_8point(u1, u2)
+    ft = o_tri.fundamental_from_projections(p1, p2)
+    assert ok and abs(f[2, 2] - 1.0) < 1e-12
+    np.testing.assert_allclose(f, ft / ft[2, 2], rtol=0, atol=1e-9 * np.abs(ft / ft[2, 2]).max())     # exact on noise-free matches
+    assert np.linalg.svd(f, compute_uv=False)[2] < 1e-12 * np.linalg.svd(f, compute_uv=False)[0]       # rank 2
+    _, n1, n2, _, _ = _scene(12, n=17, noise=1.0, pair=pair)
+    fa, _ = o_tri.fundamental_8point(n1, n2)
+    fb, _ = o_tri.fundamental_8point(n2, n1)                                                              # swapped views: F^T
+    np.testing.assert_allclose(fb / np.linalg.norm(fb), fa.T / np.linalg.norm(fa), atol=1e-9)
+    fs, _ = o_tri.fundamental_8point(n1 + [100.0, -50.0], n2)                                             # translation of view 1
+    t = np.array([[1, 0, -100.0], [0, 1, 50.0], [0, 0, 1.0]])
+    np.testing.assert_allclose(fs / np.linalg.norm(fs), (fa @ t) / np.linalg.norm(fa @ t), atol=1e-8)
+    assert not o_tri.fundamental_8point(n1[:7], n2[:7])[1]
+    assert not o_tri.fundamental_8point(np.zeros((9, 2)), n2[:9])[1]
+    k = np.array([[1100.0, 0, 500.0], [0, 1100.0, 510.0], [0, 0, 1.0]])
+    e = o_tri.essential_from_fundamental(ft, k)
+    sv = np.linalg.svd(e, compute_uv=False)
+    assert sv[2] < 1e-9 * sv[0]                                                                           # an essential matrix is rank 2
+
+
+@pytest.mark.parametrize("n,noise", [(8, 0.0), (17, 0.0), (17, 1.0), (32, 3.0), (9, 0.5)])
+def test_hostcheck_8point_matches_oracle(hostlib, n, noise):
+    _, u1, u2, _, _ = _scene(13, n=n, noise=noise, pair=(1, 3))
+    f, ok = o_tri.fundamental_8point(u1, u2)
+    fd = np.zeros(9)
+    okd = hostlib.hostcheck_fundamental_8point(_dp(u1), _dp(u2), n, _dp(fd))
+    assert ok and okd == 1
+    np.testing.assert_allclose(fd.reshape(3, 3), f, rtol=0, atol=1e-11 * np.abs(f).max())
+    assert hostlib.hostcheck_fundamental_8point(_dp(u1), _dp(u2), 7, _dp(fd)) == 0 and not fd.any()
