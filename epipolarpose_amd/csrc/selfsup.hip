@@ -423,7 +423,7 @@ EPI_HD inline int fundamental_8point_one(const double* u1, const double* u2, int
         d2 += sqrt(bx * bx + by * by);
     }
     d1 *= rn; d2 *= rn;
-    if (!(d1 >= 2.220446049250313e-16) || !(d2 >= 2.220446049250313e-16)) return 0;
+    if (!(d1 >= 1.1920928955078125e-07) || !(d2 >= 1.1920928955078125e-07)) return 0;      // FLT_EPSILON on the mean distance
     const double s1 = 1.4142135623730951 / d1, s2 = 1.4142135623730951 / d2;
     double A[9][9], V[9][9];
     for (int i = 0; i < 9; ++i)

@@ -222,7 +222,7 @@ def fundamental_8point(u1, u2):
     c1, c2 = u1.mean(0), u2.mean(0)
     d1 = np.hypot(*(u1 - c1).T).sum() / n
     d2 = np.hypot(*(u2 - c2).T).sum() / n
-    if d1 < np.finfo(np.float64).eps or d2 < np.finfo(np.float64).eps:
+    if d1 < np.finfo(np.float32).eps or d2 < np.finfo(np.float32).eps:          # FLT_EPSILON on the mean distance
         return np.zeros((3, 3)), False
     s1, s2 = np.sqrt(2.0) / d1, np.sqrt(2.0) / d2
     a, b = (u1 - c1) * s1, (u2 - c2) * s2
