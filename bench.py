@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + --same-device lets "
                     "the N>1 code path be exercised on a single-GPU box")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (functional testing only)")
+    ap.add_argument("--force-grad-sync", action="store_true", help="diagnostic: run the N>1 gradient-bucket path at N=1 (copies "
+                    "into the flat buckets, no collective) to price its overhead on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
@@ -163,7 +165,7 @@ def main():
     use_graph = bool(args.graph)
     cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank, capturable=use_graph)
     grad_sync = None
-    if world > 1:
+    if world > 1 or args.force_grad_sync:
         epd.broadcast_module(model)
         grad_sync = epd.BucketedGradSync(model, optimizer=optimizer)
     n_view = args.views if args.workload == "ss" else None

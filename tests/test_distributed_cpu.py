@@ -18,10 +18,19 @@ def _free_port():
     return p
 
 
+class _Net(nn.Sequential):
+    """The last module ("unused") takes no part in forward: its parameters receive no gradient (must come out as zeros)."""
+
+    def forward(self, x):
+        for m in list(self)[:-1]:
+            x = m(x)
+        return x
+
+
 def _make_model():
     torch.manual_seed(0)
-    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.Flatten(),
-                         nn.Linear(8 * 6 * 6, 5))
+    return _Net(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.Flatten(), nn.Linear(8 * 6 * 6, 5),
+                nn.Linear(4, 4))
 
 
 def _loss(model, x, y):
@@ -46,8 +55,12 @@ def _worker(rank, world, port, tmp):
     xs, ys = x[2 * start:2 * (start + n)], y[2 * start:2 * (start + n)]
     for _ in range(2):                                        # twice: state resets between steps
         sync.zero_grad()
+        assert all(p.grad is None for p in model.parameters())          # autograd hands gradients over, no accumulate kernels
         _loss(model, xs, ys).backward()
         sync.finish()
+    for flat, plist, _ in sync.buckets:                      # every .grad now lives inside its flat all-reduce bucket
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        assert all(lo <= p.grad.data_ptr() < hi for p in plist)
     torch.save([p.grad.clone() for p in model.parameters()], os.path.join(tmp, "g%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -63,4 +76,5 @@ def test_bucketed_allreduce_matches_global_batch(tmp_path):
     _loss(model, x, y).backward()
     for a, b, p in zip(g0, g1, model.parameters()):
         assert torch.equal(a, b)
-        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
+        want = p.grad if p.grad is not None else torch.zeros_like(p)      # the unused layer
+        torch.testing.assert_close(a, want, rtol=1e-5, atol=1e-6)
