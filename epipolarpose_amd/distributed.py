@@ -65,8 +65,9 @@ class BucketedGradSync:
         self.buckets = []          # (flat tensor, [params], [views])
         self._pending = {}
         self._handles = []
-        # RCCL averages in the collective; gloo (CPU tests) only sums
-        self._avg = self.world > 1 and dist.get_backend() == "nccl"
+        # sum in the collective, scale afterwards (one small kernel per bucket): ReduceOp.AVG would save those kernels on
+        # RCCL but is not available on every backend / dtype combination
+        self._avg = False
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * (grad_dtype or p.dtype).itemsize
@@ -77,7 +78,13 @@ class BucketedGradSync:
             cur_bytes += nbytes
         if cur:
             self._make_bucket(cur, grad_dtype)
+        # Step 1 hooks every parameter and learns, per bucket, which gradient arrives last; from step 2 on only those
+        # parameters keep a hook (a Python hook costs the autograd thread ~8 us: 161 of them made backward host-bound).
+        # A launch that finds a gradient missing (the graph changed) is deferred to finish(), which is always correct.
         self._hooks = []
+        self._launched = set()
+        self._last = {}
+        self._learning = True
         for bi, (_, plist, _) in enumerate(self.buckets):
             for p in plist:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
@@ -88,10 +95,9 @@ class BucketedGradSync:
         flat = torch.zeros(total, dtype=grad_dtype or plist[0].dtype, device=plist[0].device)
         off, views = 0, []
         for p in plist:
-            view = flat[off:off + p.numel()].view_as(p)
-            if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
-                # keep the gradient's logical strides equal to the parameter's (channels-last weights)
-                view = flat[off:off + p.numel()].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+            # a dense view with exactly the parameter's strides (channels-last weights included): the optimizer reads the
+            # gradient in place, and the multi-tensor copy stays on its fast path
+            view = torch.as_strided(flat, p.shape, p.stride(), storage_offset=off)
             views.append(view)
             off += p.numel()
         self.buckets.append((flat, plist, views))
@@ -109,15 +115,20 @@ class BucketedGradSync:
             torch._foreach_copy_(dst, src)
         for p, v in zip(plist, views):
             p.grad = v
+        self._launched.add(bi)
         if self.world > 1:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._handles.append(dist.all_reduce(flat, op=op, async_op=True))
 
     def _make_hook(self, bi):
-        def hook(_param):
-            self._pending[bi] -= 1
-            if self._pending[bi] == 0:
-                self._launch(bi)
+        def hook(param):
+            if self._learning:
+                self._pending[bi] -= 1
+                if self._pending[bi] == 0:
+                    self._last[bi] = param
+                    self._launch(bi)
+            elif all(p.grad is not None for p in self.buckets[bi][1]):
+                self._launch(bi)             # the learned last arrival, and indeed every gradient is here
         return hook
 
     def zero_grad(self):
@@ -127,13 +138,13 @@ class BucketedGradSync:
                 p.grad = None
         self._pending = {bi: len(plist) for bi, (_, plist, _) in enumerate(self.buckets)}
         self._handles = []
+        self._launched = set()
 
     def finish(self):
         """Wait for the in-flight all-reduces; gradients become the mean over ranks.  Call between backward() and
         optimizer.step()."""
-        for bi, left in self._pending.items():        # buckets with parameters that received no gradient this step
-            if left > 0:
-                self._pending[bi] = 0
+        for bi in range(len(self.buckets)):           # buckets whose hook did not fire / found a gradient missing
+            if bi not in self._launched:
                 self._launch(bi)
         for h in self._handles:
             h.wait()
@@ -142,6 +153,11 @@ class BucketedGradSync:
             inv = 1.0 / self.world
             for flat, _, _ in self.buckets:
                 flat.mul_(inv)
+        if self._learning and len(self._last) == len(self.buckets):
+            self._learning = False
+            for h in self._hooks:
+                h.remove()
+            self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(bi)) for bi, p in self._last.items()]
 
     def total_bytes(self):
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets)

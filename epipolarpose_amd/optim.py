@@ -25,6 +25,12 @@ def _lp_conv_forward(self, x):
     return F.conv2d(x, self.weight_lp, None, self.stride, self.padding, self.dilation, self.groups)
 
 
+def _same_layout(a, b):
+    """Same memory order: strides agree on every dimension of extent > 1 (a 1x1 convolution weight is the same memory in its
+    contiguous and its channels_last form)."""
+    return all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
@@ -111,7 +117,7 @@ class FusedAdam(torch.optim.Optimizer):
             g = self._lp_of[i].grad if i in self._lp_of else p.grad
             if g is None:
                 raise RuntimeError("FusedAdam: parameter %d received no gradient (partial updates are not supported)" % i)
-            if g.shape != p.shape or g.stride() != p.stride():          # e.g. NCHW-strided grad for an NHWC weight
+            if g.shape != p.shape or not _same_layout(g, p):            # e.g. NCHW-strided grad for an NHWC weight
                 g2 = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device)
                 g2.copy_(g)
                 keep.append(g2)

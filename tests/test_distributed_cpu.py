@@ -53,7 +53,7 @@ def _worker(rank, world, port, tmp):
     x, y = torch.randn(8, 3, 6, 6), torch.randn(8, 5)
     start, n = epd.shard_groups(4, rank, world)               # 4 groups of 2 "views"
     xs, ys = x[2 * start:2 * (start + n)], y[2 * start:2 * (start + n)]
-    for _ in range(2):                                        # twice: state resets between steps
+    for _ in range(3):                                        # three times: all hooks, then the learned per-bucket hooks
         sync.zero_grad()
         assert all(p.grad is None for p in model.parameters())          # autograd hands gradients over, no accumulate kernels
         _loss(model, xs, ys).backward()
