@@ -15,7 +15,7 @@ struct Aff { double a00, a01, a02, a10, a11, a12; };
 // img_utils.py:72-105 (gen_trans_from_patch_cv) with its float32 roundings (:82-83,87-99), then the exact
 // affine through the three point pairs (cv2.getAffineTransform) in closed form: the patch-side triple is
 // axis aligned, so  org = s0 + (px-dcx)/dhw * (s2-s0) + (py-dcy)/dhh * (s1-s0).
-__device__ __forceinline__ void patch_affines(double cx, double cy, double bw, double bh, double scale, double rot,
+EPI_HD __forceinline__ void patch_affines(double cx, double cy, double bw, double bh, double scale, double rot,
                                               double pw, double ph, Aff* inv, Aff* fwd) {
     const double rot_rad = 3.141592653589793 * rot / 180.0;
     const double sn = sin(rot_rad), cs = cos(rot_rad);
@@ -46,7 +46,7 @@ __device__ __forceinline__ void patch_affines(double cx, double cy, double bw, d
 // Least squares of an (R x 3) system by Householder QR, in place (stand-in for cv2.solve(DECOMP_SVD),
 // triangulation.py:95,155 -- identical for full column rank).  Rows beyond the used views are zero.
 template <typename T, int R>
-__device__ __forceinline__ void qr_solve3(T (&A)[R][3], T (&b)[R], T (&x)[3]) {
+EPI_HD __forceinline__ void qr_solve3(T (&A)[R][3], T (&b)[R], T (&x)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         T tail2 = 0;                                     // sub-diagonal part kept separate: no cancellation
@@ -86,7 +86,7 @@ __device__ __forceinline__ void qr_solve3(T (&A)[R][3], T (&b)[R], T (&x)[3]) {
 
 // rows of the inhomogeneous system (triangulation.py:138-148): A = C P[:, :3], b = -(C P[:, 3])
 template <typename T, int NV>
-__device__ __forceinline__ void build_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&A)[2 * NV][3], T (&b)[2 * NV]) {
+EPI_HD __forceinline__ void build_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&A)[2 * NV][3], T (&b)[2 * NV]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const bool on = v < nv;
@@ -100,7 +100,7 @@ __device__ __forceinline__ void build_ls(const T (&u)[NV][2], const T (&P)[NV][1
 }
 
 template <typename T, int NV>
-__device__ __forceinline__ int tri_linear_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&x)[3]) {
+EPI_HD __forceinline__ int tri_linear_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T (&x)[3]) {
     T A[2 * NV][3], b[2 * NV];
     build_ls<T, NV>(u, P, nv, A, b);
     qr_solve3<T, 2 * NV>(A, b, x);
@@ -109,7 +109,7 @@ __device__ __forceinline__ int tri_linear_ls(const T (&u)[NV][2], const T (&P)[N
 
 // triangulation.py:104-181
 template <typename T, int NV>
-__device__ __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
+EPI_HD __forceinline__ int tri_iterative_ls(const T (&u)[NV][2], const T (&P)[NV][12], int nv, T tol, int max_iter, T (&x)[3]) {
     T A[2 * NV][3], b[2 * NV], d[NV], dn[NV];
     build_ls<T, NV>(u, P, nv, A, b);
 #pragma unroll
@@ -602,7 +602,7 @@ __global__ void decode_kernel(const float* __restrict__ xyz, int B, int J, MetaD
 }
 
 // prep_h36m.py:177-204 + img_utils.py:232-238 + integral_loss.py:170-177 for one (sample, joint)
-__device__ __forceinline__ void reproject_one(const double (&X)[3], const double (&Xroot)[3], const double* R, const double* T,
+EPI_HD __forceinline__ void reproject_one(const double (&X)[3], const double (&Xroot)[3], const double* R, const double* T,
                                               const double* f, const double* c, const Aff& fwd, double scale, double pw,
                                               double ph, double rect3d, float* lab) {
     const double dx = X[0] - T[0], dy = X[1] - T[1], dz = X[2] - T[2];

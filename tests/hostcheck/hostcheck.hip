@@ -55,3 +55,40 @@ extern "C" int hostcheck_fundamental_8point(const double* u1, const double* u2, 
     for (int i = 0; i < 9; ++i) F[i] = Fm[i / 3][i % 3];
     return ok;
 }
+
+// ---- two-view triangulators (the reference's V = 2 case): method 0 iterative LS, 1 linear LS, 2 DLT; float64 ----
+extern "C" void hostcheck_triangulate2(int method, const double* u1, const double* u2, const double* P1, const double* P2, int n,
+                                       double tol, int max_iter, double* X, int* status) {
+    double P[2][12];
+    for (int i = 0; i < 12; ++i) { P[0][i] = P1[i]; P[1][i] = P2[i]; }
+    for (int i = 0; i < n; ++i) {
+        double u[2][2] = {{u1[2 * i], u1[2 * i + 1]}, {u2[2 * i], u2[2 * i + 1]}}, x[3];
+        int st;
+        if (method == 0) st = epi::tri_iterative_ls<double, 2>(u, P, 2, tol, max_iter, x);
+        else if (method == 1) st = epi::tri_linear_ls<double, 2>(u, P, 2, x);
+        else st = epi::tri_dlt<2>(u, P, 2, x);
+        X[3 * i] = x[0]; X[3 * i + 1] = x[1]; X[3 * i + 2] = x[2];
+        status[i] = st;
+    }
+}
+
+// ---- patch <-> image affines, decode (patch -> image) and re-projection (world -> label) for one sample ----
+extern "C" void hostcheck_patch_affines(double cx, double cy, double bw, double bh, double scale, double rot, double pw, double ph,
+                                        double* inv6, double* fwd6) {
+    epi::Aff inv, fwd;
+    epi::patch_affines(cx, cy, bw, bh, scale, rot, pw, ph, &inv, &fwd);
+    const double a[6] = {inv.a00, inv.a01, inv.a02, inv.a10, inv.a11, inv.a12}, b[6] = {fwd.a00, fwd.a01, fwd.a02, fwd.a10, fwd.a11, fwd.a12};
+    for (int i = 0; i < 6; ++i) { inv6[i] = a[i]; fwd6[i] = b[i]; }
+}
+
+extern "C" void hostcheck_reproject(const double* X, int J, int root, const double* R, const double* T, const double* f, const double* c,
+                                    double cx, double cy, double bw, double bh, double scale, double rot, double pw, double ph,
+                                    double rect3d, float* label) {
+    epi::Aff fwd;
+    epi::patch_affines(cx, cy, bw, bh, scale, rot, pw, ph, nullptr, &fwd);
+    const double Xr[3] = {X[3 * root], X[3 * root + 1], X[3 * root + 2]};
+    for (int j = 0; j < J; ++j) {
+        const double Xj[3] = {X[3 * j], X[3 * j + 1], X[3 * j + 2]};
+        epi::reproject_one(Xj, Xr, R, T, f, c, fwd, scale, pw, ph, rect3d, label + 3 * j);
+    }
+}

@@ -85,3 +85,31 @@ def test_torch_glue_builds_loads_and_links_the_c_abi():
     m = FusedBatchNormAct(8)
     with pytest.raises(RuntimeError, match="GPU"):
         m(torch.zeros(2, 8, 4, 4, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last))
+
+
+def declared_prototypes():
+    """{name: number of parameters} for every function declared in include/epipolar_hip.h."""
+    text = open(os.path.join(ROOT, "include", "epipolar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(epi_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_ctypes_signatures_match_the_header_arity():
+    """A wrong argument count in the ctypes table corrupts the call silently (e.g. a stream pointer read as garbage):
+    the number of parameters of every prototype in the header must equal the length of its ctypes argtypes."""
+    from epipolarpose_amd import hip
+    protos = declared_prototypes()
+    assert set(protos) == set(hip._SIGNATURES)
+    for name, (res, args) in hip._SIGNATURES.items():
+        assert protos[name] == len(args), "%s: header declares %d parameters, ctypes table has %d" % (name, protos[name], len(args))
+
+
+def test_glue_calls_use_the_header_prototypes():
+    """csrc/torch_glue.cpp includes the public header (the compiler checks its calls); this guards against a private re-declaration."""
+    src = open(os.path.join(ROOT, "epipolarpose_amd", "csrc", "torch_glue.cpp")).read()
+    assert '#include "../../include/epipolar_hip.h"' in src
+    assert not re.search(r'extern\s+"C"\s+int\s+epi_', src)
