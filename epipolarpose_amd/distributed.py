@@ -106,11 +106,22 @@ class BucketedGradSync:
         flat, plist, views = self.buckets[bi]
         dst, src = [], []
         for p, v in zip(plist, views):
-            if p.grad is None:
+            g = p.grad
+            if g is None:
                 v.zero_()                    # parameter without a gradient this step
-            elif p.grad.data_ptr() != v.data_ptr():
+            elif g.data_ptr() != v.data_ptr():
+                if g.stride() != v.stride():
+                    if g.shape == v.shape and all(a == b for n, a, b in zip(g.shape, g.stride(), v.stride()) if n > 1):
+                        # same memory order, only the strides of extent-1 dimensions differ (a 1x1 convolution weight's
+                        # gradient comes back "contiguous", the parameter is "channels_last"): re-stride the alias, so
+                        # that the multi-tensor copy keeps its fast path (one mismatch sends the WHOLE list down the
+                        # one-kernel-per-tensor route)
+                        g = g.as_strided(g.shape, v.stride(), g.storage_offset())
+                    else:
+                        v.copy_(g)           # genuinely different layout: its own strided copy
+                        continue
                 dst.append(v)
-                src.append(p.grad)
+                src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
         for p, v in zip(plist, views):

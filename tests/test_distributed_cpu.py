@@ -29,8 +29,9 @@ class _Net(nn.Sequential):
 
 def _make_model():
     torch.manual_seed(0)
-    return _Net(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.Flatten(), nn.Linear(8 * 6 * 6, 5),
-                nn.Linear(4, 4))
+    # channels_last weights incl. a 1x1 convolution: its gradient may come back with the strides of the contiguous form
+    return _Net(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.Flatten(),
+                nn.Linear(8 * 6 * 6, 5), nn.Linear(4, 4)).to(memory_format=torch.channels_last)
 
 
 def _loss(model, x, y):
