@@ -63,6 +63,17 @@ def _worker(rank, world, port, tmp):
         lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
         assert all(lo <= p.grad.data_ptr() < hi for p in plist)
     torch.save([p.grad.clone() for p in model.parameters()], os.path.join(tmp, "g%d.pt" % rank))
+    assert sync._learning                                     # the unused layer's bucket never completes: every hook stays
+    # second model, every parameter used: after the first step only one hook per bucket remains
+    model2 = nn.Sequential(*list(_make_model())[:-1])
+    sync2 = epd.BucketedGradSync(model2, bucket_bytes=2048)
+    n_hooks_first = len(sync2._hooks)
+    for _ in range(3):
+        sync2.zero_grad()
+        _loss(model2, xs, ys).backward()
+        sync2.finish()
+    assert n_hooks_first == len(list(model2.parameters())) and not sync2._learning and len(sync2._hooks) == len(sync2.buckets)
+    torch.save([p.grad.clone() for p in model2.parameters()], os.path.join(tmp, "h%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -79,3 +90,8 @@ def test_bucketed_allreduce_matches_global_batch(tmp_path):
         assert torch.equal(a, b)
         want = p.grad if p.grad is not None else torch.zeros_like(p)      # the unused layer
         torch.testing.assert_close(a, want, rtol=1e-5, atol=1e-6)
+    h0 = torch.load(tmp_path / "h0.pt")
+    h1 = torch.load(tmp_path / "h1.pt")
+    for a, b, p in zip(h0, h1, list(model.parameters())[:-2]):             # learned-hook mode: same gradients
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
