@@ -11,6 +11,21 @@ import os
 import torch
 import torch.distributed as dist
 
+# How a completed bucket's gradients are packed into its flat buffer: "foreach" (default: torch._foreach_copy_ into the
+# parameter-strided views) or "cat" (torch.cat of memory-order flat aliases, written straight into the flat buffer: one
+# batched-copy kernel per <=128 tensors).  Same bytes either way (tests/test_distributed_cpu.py); the choice is a speed
+# experiment for the N>1 path.
+BUCKET_PACK = os.environ.get("EPI_BUCKET_PACK", "foreach")
+
+
+def _memory_order_flat(t):
+    """A 1-D alias of a dense tensor in the order its elements lie in memory, or None if it is not dense."""
+    if t.is_contiguous():
+        return t.reshape(-1)
+    order = sorted(range(t.dim()), key=lambda d: (-t.stride(d), -t.shape[d]))
+    q = t.permute(order)
+    return q.reshape(-1) if q.is_contiguous() else None
+
 
 def init_from_env(backend=None, set_device=True):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local)."""
@@ -104,6 +119,9 @@ class BucketedGradSync:
 
     def _launch(self, bi):
         flat, plist, views = self.buckets[bi]
+        if BUCKET_PACK == "cat" and self._pack_cat(flat, plist, views):
+            self._finish_launch(bi, flat, plist, views)
+            return
         dst, src = [], []
         for p, v in zip(plist, views):
             g = p.grad
@@ -124,6 +142,26 @@ class BucketedGradSync:
                 src.append(g)
         if dst:
             torch._foreach_copy_(dst, src)
+        self._finish_launch(bi, flat, plist, views)
+
+    def _pack_cat(self, flat, plist, views):
+        """torch.cat of the gradients' memory-order aliases into the flat buffer.  False (nothing written) when a gradient is
+        missing, already lives in the bucket, or does not have its parameter's memory order."""
+        parts = []
+        for p, v in zip(plist, views):
+            g = p.grad
+            if g is None or g.data_ptr() == v.data_ptr() or g.dtype != flat.dtype or g.shape != v.shape:
+                return False
+            if not all(a == b for n, a, b in zip(g.shape, g.stride(), v.stride()) if n > 1):
+                return False
+            f = _memory_order_flat(g)
+            if f is None:
+                return False
+            parts.append(f)
+        torch.cat(parts, out=flat)
+        return True
+
+    def _finish_launch(self, bi, flat, plist, views):
         for p, v in zip(plist, views):
             p.grad = v
         self._launched.add(bi)

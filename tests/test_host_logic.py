@@ -122,3 +122,35 @@ def test_synthetic_item_contract():
     assert set(sc.meta) == {"center_x", "center_y", "width", "height", "scale", "rot", "R", "T", "f", "c", "projection_matrix"}
     assert sc.meta["projection_matrix"].shape == (12, 3, 4) and sc.meta["T"].shape == (12, 3, 1)
     assert np.abs(sc.label).max() < 1.5
+
+
+def test_bucket_pack_variants_write_the_same_bytes():
+    """BucketedGradSync packs a completed bucket either with torch._foreach_copy_ (default) or with one torch.cat into the flat
+    buffer (EPI_BUCKET_PACK=cat): identical bucket contents and parameter-strided .grad views, channels_last weights included."""
+    import torch
+    import torch.nn as nn
+    from epipolarpose_amd import distributed as epd
+
+    def run(mode):
+        old = epd.BUCKET_PACK
+        epd.BUCKET_PACK = mode
+        try:
+            torch.manual_seed(0)
+            m = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 1), nn.ReLU(), nn.Conv2d(8, 16, 3, padding=1),
+                              nn.Flatten(), nn.Linear(16 * 36, 5)).to(memory_format=torch.channels_last)
+            s = epd.BucketedGradSync(m, bucket_bytes=4096)
+            x = torch.randn(4, 3, 6, 6)
+            for _ in range(3):
+                s.zero_grad()
+                m(x).square().sum().backward()
+                s.finish()
+            return [f.clone() for f, _, _ in s.buckets], [p.grad.clone() for p in m.parameters()], [p.grad.stride() for p in m.parameters()]
+        finally:
+            epd.BUCKET_PACK = old
+    a, b = run("foreach"), run("cat")
+    assert len(a[0]) > 1
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert a[2] == b[2]
+    t = torch.arange(24.0).reshape(2, 3, 2, 2).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(epd._memory_order_flat(t), t.permute(0, 2, 3, 1).reshape(-1))
+    assert epd._memory_order_flat(t[:, :2]) is None
