@@ -25,3 +25,6 @@ for d in sorted(diff, reverse=True)[:25]:
     print("%+9.1f us/step  %+6.1f launches/step  %s" % d)
 PY
 python tools/phase_times.py 2>&1 | tail -2
+for mode in foreach cat; do
+  echo "EPI_BUCKET_PACK=$mode"; EPI_BUCKET_PACK=$mode python bench.py --no-cpu-baseline --force-grad-sync 2>/dev/null | tail -1 | cut -c1-250
+done
