@@ -166,7 +166,7 @@ def main():
     cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank, capturable=use_graph)
     grad_sync = None
     if world > 1 or args.force_grad_sync:
-        epd.broadcast_module(model)
+        epd.broadcast_module(model, optimizer=optimizer)
         grad_sync = epd.BucketedGradSync(model, optimizer=optimizer)
     n_view = args.views if args.workload == "ss" else None
     # 4-view SS uses the V-view generalisation of the reference's iterative LS solver (V=2 is the reference itself)

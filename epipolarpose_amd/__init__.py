@@ -23,6 +23,10 @@ _LIB_ALIASES = {
     "lib.utils.img_utils": "epipolarpose_amd.utils.img_utils",
     "lib.utils.triangulation": "epipolarpose_amd.utils.triangulation",
     "lib.utils.utils": "epipolarpose_amd.utils.utils",
+    "lib.utils.prep_h36m": "epipolarpose_amd.utils.prep_h36m",
+    "lib.utils.cameras": "epipolarpose_amd.utils.cameras",
+    "lib.dataset": "epipolarpose_amd.dataset",
+    "lib.dataset.h36m": "epipolarpose_amd.dataset.synthetic",
 }
 
 

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import hip
+from ..dataset.collate import tri_batch_to_view_major
 from ..utils.img_utils import self_supervision_device
 from ..utils.utils import AverageMeter
 from .integral_loss import joint_location_result_device
@@ -91,13 +92,15 @@ def train_integral(config, train_loader, model, criterion, optimizer, epoch, gra
     end = time.time()
     for i, data in enumerate(train_loader):
         data_time.update(time.time() - end)
+        if isinstance(data, dict):            # stock default_collate of TRI items: {'cam_1': bundle, 'cam_2': bundle} -> view-major
+            data = tri_batch_to_view_major(data)
         batch_data, batch_label, batch_label_weight, meta = data
         batch_data = batch_data.cuda(non_blocking=True)
         batch_label = batch_label.cuda(non_blocking=True)
         batch_label_weight = batch_label_weight.cuda(non_blocking=True)
         batch_size = batch_data.size(0)
         loss = train_step(model, criterion, optimizer, batch_data, batch_label, batch_label_weight,
-                          meta=meta if use_ss else None, n_view=n_view, grad_sync=grad_sync)
+                          meta=hip.DeviceMeta(meta, batch_data.device) if use_ss else None, n_view=n_view, grad_sync=grad_sync)
         pending = loss * batch_size if pending is None else pending + loss * batch_size
         pending_n += batch_size
         if i % config.PRINT_FREQ == 0:

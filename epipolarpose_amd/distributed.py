@@ -4,7 +4,8 @@ The reference uses single-process ``torch.nn.DataParallel`` (scripts/train.py:93
 step, the 17.8 MB/image logits gathered to GPU 0, gradients reduce-added to GPU 0.  Here every rank owns whole
 multi-view groups, computes its loss locally, and the ONLY exchange is a bucketed gradient all-reduce that starts
 while backward is still running.  xGMI is point-to-point (7 links x ~153 GB/s), so buckets are large
-(default 64 MiB: R50's 137 MB of fp32 gradients leave in 3 collectives) to stay bandwidth- not latency-bound.
+(default 32 MiB per bucket, one chain of buckets per gradient dtype: ResNet-50 with bf16 convolution-weight gradients leaves in
+4 collectives) to stay bandwidth- not latency-bound.
 """
 import os
 
@@ -50,12 +51,17 @@ def shard_groups(n_group_global, rank, world):
     return start, base + (1 if rank < rem else 0)
 
 
-def broadcast_module(module, src=0):
-    """One-time broadcast of parameters and buffers from rank ``src`` (replaces DataParallel's per-step replicate)."""
+def broadcast_module(module, src=0, optimizer=None):
+    """One-time broadcast of parameters and buffers from rank ``src`` (replaces DataParallel's per-step replicate).  The
+    tensors are written in place under ``no_grad`` (which bumps their version counters, so bf16 training copies notice); pass the
+    optimizer when it already exists and its copies are refreshed right away."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)
+    if optimizer is not None and hasattr(optimizer, "refresh_training_copies"):
+        optimizer.refresh_training_copies()
 
 
 class BucketedGradSync:
@@ -70,7 +76,7 @@ class BucketedGradSync:
     ResNet-50) plus the bucket memsets.  One backward per step (no gradient accumulation across backward calls).
     """
 
-    def __init__(self, module, bucket_bytes=64 << 20, grad_dtype=None, optimizer=None):
+    def __init__(self, module, bucket_bytes=32 << 20, grad_dtype=None, optimizer=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         copies = optimizer.training_copies() if hasattr(optimizer, "training_copies") else {}
@@ -83,16 +89,26 @@ class BucketedGradSync:
         # sum in the collective, scale afterwards (one small kernel per bucket): ReduceOp.AVG would save those kernels on
         # RCCL but is not available on every backend / dtype combination
         self._avg = False
-        cur, cur_bytes = [], 0
+        # One OPEN bucket per gradient dtype, filled in reverse registration order (~ the order backward produces the
+        # gradients) and closed when it reaches ``bucket_bytes``.  A dtype change does NOT close a bucket: with FusedAdam's bf16
+        # training copies the network alternates conv (bf16) / BatchNorm (fp32) parameters layer by layer, and cutting at
+        # every change produced 106 latency-bound collectives on ResNet-50 instead of a handful of bandwidth-bound ones.
+        open_buckets = {}          # dtype -> ([params], bytes)
+        order = []                 # closed buckets, in closing order
         for p in reversed(self.params):
-            nbytes = p.numel() * (grad_dtype or p.dtype).itemsize
-            if cur and (cur_bytes + nbytes > bucket_bytes or (grad_dtype is None and p.dtype != cur[0].dtype)):
-                self._make_bucket(cur, grad_dtype)
+            dt = grad_dtype or p.dtype
+            nbytes = p.numel() * dt.itemsize
+            cur, cur_bytes = open_buckets.get(dt, ([], 0))
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                order.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._make_bucket(cur, grad_dtype)
+            open_buckets[dt] = (cur, cur_bytes + nbytes)
+        for dt, (cur, _) in open_buckets.items():
+            if cur:
+                order.append(cur)
+        for plist in order:
+            self._make_bucket(plist, grad_dtype)
         # Step 1 hooks every parameter and learns, per bucket, which gradient arrives last; from step 2 on only those
         # parameters keep a hook (a Python hook costs the autograd thread ~8 us: 161 of them made backward host-bound).
         # A launch that finds a gradient missing (the graph changed) is deferred to finish(), which is always correct.

@@ -269,23 +269,46 @@ def argmax_rows(x):
 
 
 class DeviceMeta:
-    """float64 device copies of the per-sample camera / crop arrays + the C struct that points at them."""
+    """float64 device copies of the per-sample camera / crop arrays + the C struct that points at them.
+
+    Host inputs (what ``default_collate`` makes of the reference's ``meta`` dict, h36m.py:73-86: float64 tensors, or plain arrays)
+    are packed into ONE staging buffer and cross PCIe in ONE copy -- the training loop builds a ``DeviceMeta`` per step, and eleven
+    separate small H2D copies cost more host time than the whole self-supervision kernel."""
 
     KEYS = ("center_x", "center_y", "width", "height", "scale", "rot", "R", "T", "f", "c", "projection_matrix")
+    FIELDS = (("center_x", "center_x"), ("center_y", "center_y"), ("width", "width"), ("height", "height"), ("scale", "scale"),
+              ("rot", "rot"), ("R", "R"), ("T", "T"), ("f", "f"), ("c", "c"), ("P", "projection_matrix"))
 
     def __init__(self, meta, device):
         self.tensors = {}
+        host = []
         for k in self.KEYS:
             if k not in meta:
                 continue
             v = meta[k]
             t = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
-            self.tensors[k] = t.to(device=device, dtype=torch.float64, non_blocking=True).contiguous()
+            if t.is_cuda:
+                self.tensors[k] = t.to(device=device, dtype=torch.float64).contiguous()
+            else:
+                host.append((k, t))
+        if host:
+            total = sum(t.numel() for _, t in host)
+            stage = torch.empty(total, dtype=torch.float64)
+            if torch.cuda.is_available():
+                stage = stage.pin_memory()
+            off = 0
+            for _, t in host:
+                stage[off:off + t.numel()].copy_(t.reshape(-1))          # converts dtype on the way
+                off += t.numel()
+            dev = stage.to(device=device, non_blocking=True)
+            self._stage = stage                                           # keep the pinned buffer alive until the copy ran
+            off = 0
+            for k, t in host:
+                self.tensors[k] = dev[off:off + t.numel()].view(t.shape)
+                off += t.numel()
         self.batch = int(self.tensors["center_x"].shape[0])
         s = EpiViewMeta()
-        for field, key in (("center_x", "center_x"), ("center_y", "center_y"), ("width", "width"), ("height", "height"),
-                           ("scale", "scale"), ("rot", "rot"), ("R", "R"), ("T", "T"), ("f", "f"), ("c", "c"),
-                           ("P", "projection_matrix")):
+        for field, key in self.FIELDS:
             setattr(s, field, self.tensors[key].data_ptr() if key in self.tensors else None)
         self.struct = s
 

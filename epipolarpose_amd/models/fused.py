@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..optim import sync_training_copy
 
 
 def _nhwc_bf16(x):
@@ -76,9 +77,7 @@ class PointwiseConv(nn.Module):
         self.register_parameter("bias", None)
 
     def forward(self, x):
-        w = getattr(self, "weight_lp", None)
-        if w is None:
-            w = self.weight
+        w = self.weight if getattr(self, "weight_lp", None) is None else sync_training_copy(self)
         if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
             x = _nhwc_bf16(x)
         if w.dtype != torch.bfloat16:
@@ -170,5 +169,5 @@ class Conv1x1(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x):
-        w = getattr(self, "weight_lp", None)
-        return _Conv1x1Function.apply(_nhwc_bf16(x), self.weight if w is None else w, self.bias)
+        w = self.weight if getattr(self, "weight_lp", None) is None else sync_training_copy(self)
+        return _Conv1x1Function.apply(_nhwc_bf16(x), w, self.bias)

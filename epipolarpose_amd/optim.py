@@ -19,10 +19,22 @@ from . import hip
 _ROW = 7        # int64 slots per table row: p, g, m, v, shadow, n, flags (low 32 bits: gradient is bf16)
 
 
+def sync_training_copy(module):
+    """Bring a module's bf16 training copy back in line with its fp32 master when the master was written by anyone but the
+    Adam kernel (``load_state_dict``, a broadcast, an initialiser: all bump ``weight._version``; the kernel writes through raw
+    pointers and refreshes the copy itself).  One integer compare per forward."""
+    w = module.weight
+    if w._version != module._lp_version:
+        with torch.no_grad():
+            module.weight_lp.copy_(w)
+        module._lp_version = w._version
+    return module.weight_lp
+
+
 def _lp_conv_forward(self, x):
     if x.dtype != torch.bfloat16:
         x = x.to(torch.bfloat16)
-    return F.conv2d(x, self.weight_lp, None, self.stride, self.padding, self.dilation, self.groups)
+    return F.conv2d(x, sync_training_copy(self), None, self.stride, self.padding, self.dilation, self.groups)
 
 
 def _same_layout(a, b):
@@ -61,6 +73,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if lp_modules else None
         self._lp_of = {}
+        self._lp_modules = lp_modules
+        self._offs = offs
         for m in lp_modules:
             w = m.weight
             idx = next(i for i, p in enumerate(params) if p is w)
@@ -69,6 +83,7 @@ class FusedAdam(torch.optim.Optimizer):
             lp.copy_(w.detach())
             lp.requires_grad_(True)
             object.__setattr__(m, "weight_lp", lp)
+            object.__setattr__(m, "_lp_version", w._version)
             if type(m) is nn.Conv2d:
                 m.forward = types.MethodType(_lp_conv_forward, m)
             self._lp_of[idx] = lp
@@ -93,6 +108,18 @@ class FusedAdam(torch.optim.Optimizer):
         self._chunks_all = chunks
         self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
         self._grad_ptrs = None
+
+    def refresh_training_copies(self):
+        """Re-copy every fp32 master into its bf16 training copy (after the masters were loaded / broadcast)."""
+        with torch.no_grad():
+            for m in self._lp_modules:
+                m.weight_lp.copy_(m.weight)
+                m._lp_version = m.weight._version
+
+    def _state_view(self, flat, i):
+        """Slice of a flat moment buffer with parameter i's shape and strides."""
+        p = self._params[i]
+        return torch.as_strided(flat, p.shape, p.stride(), storage_offset=self._offs[i])
 
     def training_copies(self):
         """{parameter index: bf16 leaf tensor} of the convolution weights trained through a bf16 copy."""
@@ -147,16 +174,39 @@ class FusedAdam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
+        """``torch.optim.Adam``'s format (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move freely
+        between this optimizer and the reference's ``torch.optim.Adam`` (scripts/train.py:118,177)."""
         sd = super().state_dict()
-        sd["fused"] = {"step": self._step, "exp_avg": self._exp_avg, "exp_avg_sq": self._exp_avg_sq}
+        if self._step > 0:
+            step = torch.tensor(float(self._step))
+            sd["state"] = {i: {"step": step.clone(), "exp_avg": self._state_view(self._exp_avg, i).clone(),
+                               "exp_avg_sq": self._state_view(self._exp_avg_sq, i).clone()} for i in range(len(self._params))}
         return sd
 
     def load_state_dict(self, state_dict):
-        fused = state_dict.get("fused")
-        super().load_state_dict({k: v for k, v in state_dict.items() if k != "fused"})
+        state = state_dict.get("state", {})
+        fused = state_dict.get("fused")                      # round-1 checkpoints: flat buffers
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if fused is not None:
             self._step = int(fused["step"])
             self._exp_avg.copy_(fused["exp_avg"])
             self._exp_avg_sq.copy_(fused["exp_avg_sq"])
-        for i, lp in self._lp_of.items():           # masters may have been reloaded: refresh the training copies
-            lp.data.copy_(self._params[i].detach())
+        elif state:
+            if set(int(k) for k in state) != set(range(len(self._params))):
+                raise ValueError("FusedAdam.load_state_dict: optimizer state covers %d of %d parameters" % (len(state), len(self._params)))
+            steps = set()
+            for k, st in state.items():
+                i = int(k)
+                if "max_exp_avg_sq" in st:
+                    raise ValueError("FusedAdam.load_state_dict: amsgrad state is not supported")
+                self._state_view(self._exp_avg, i).copy_(st["exp_avg"])
+                self._state_view(self._exp_avg_sq, i).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            if len(steps) != 1:
+                raise ValueError("FusedAdam.load_state_dict: per-parameter step counts differ: %s" % sorted(steps))
+            self._step = steps.pop()
+        else:
+            self._step = 0
+            self._exp_avg.zero_()
+            self._exp_avg_sq.zero_()
+        self.refresh_training_copies()               # masters may have been reloaded too

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import ref_shims                                   # noqa: E402
 from det_weights import fill_state_dict, seeded_array   # noqa: E402
-from make_golden_cases import DLOGITS_STRIDE, INTEGRAL_CASES, NETWORK_CASES   # noqa: E402
+from make_golden_cases import DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES   # noqa: E402
 from epipolarpose_amd.synthetic import SyntheticScenes  # noqa: E402
 
 REF = ref_shims.load_reference()
@@ -262,6 +262,46 @@ def gen_network():
             out[name + "/grad/" + k] = g if g.size <= 70000 else g.reshape(-1)[:: max(1, g.size // 50000)]
         out[name + "/gradnorm"] = np.array([float(g.norm()) for g in grads.values()])
     save("network.npz", **out)
+
+
+def gen_network_big():
+    """The reference network at BASELINE.json's full configurations (1, 2, 5), fp32 on the CPU.  Outputs are sub-sampled
+    (make_golden_cases.LOGIT_STRIDE) so that the fixture stays small; the decode (soft-argmax) and the loss are stored in full."""
+    out = {}
+    for name, layers, image, j, d, b in NETWORK_BIG_CASES:
+        model = REF.pose3d_resnet.get_pose_net(ref_cfg(layers, image, j, d), is_train=True)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        out[name + "/keys"] = np.array(list(shapes.keys()))
+        out[name + "/shapes"] = np.array([str(s) for s in shapes.values()])
+        model.load_state_dict(fill_state_dict(shapes, seed=1))
+        x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image)))
+        gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2))
+        wt = torch.ones(b, 3 * j)
+        hm = image // 4
+        model.eval()
+        with torch.no_grad():
+            le = model(x)
+            out[name + "/logits_eval"] = le.reshape(-1)[::LOGIT_STRIDE].numpy().copy()
+            out[name + "/logits_eval_absmax"] = np.float32(le.abs().max().item())
+            out[name + "/xyz_eval"] = REF.integral_loss.softmax_integral_tensor(le, j, True, hm, hm, d).numpy()
+        model.train()
+        logits = model(x)
+        out[name + "/logits_train"] = logits.detach().reshape(-1)[::LOGIT_STRIDE].numpy().copy()
+        out[name + "/logits_train_absmax"] = np.float32(logits.detach().abs().max().item())
+        out[name + "/xyz_train"] = REF.integral_loss.softmax_integral_tensor(logits.detach(), j, True, hm, hm, d).numpy()
+        loss = REF.integral_loss.SmoothL1JointLocationLoss(num_joints=j)(logits, gt, wt)
+        loss.backward()
+        out[name + "/loss"] = np.float32(loss.item())
+        sd = model.state_dict()
+        out[name + "/bn1.running_mean"] = sd["bn1.running_mean"].numpy()
+        out[name + "/deconv_layers.7.running_var"] = sd["deconv_layers.7.running_var"].numpy()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+        for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.0.weight", "layer3.0.conv2.weight",
+                  "layer1.0.conv1.weight", "conv1.weight"):
+            g = grads[k].numpy()
+            out[name + "/grad/" + k] = g.reshape(-1)[:: max(1, g.size // 50000)].copy()
+        print(name, "loss", loss.item(), flush=True)
+    save("network_big.npz", **out)
 
 
 # --------------------------------------------------------------------------------------------------

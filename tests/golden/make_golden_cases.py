@@ -10,3 +10,11 @@ NETWORK_CASES = [  # name, layers, image, J, D, batch
     ("r18", 18, 64, 3, 8, 2),
     ("r50", 50, 128, 2, 16, 4),
 ]
+# Full-size configurations (BASELINE.json configs 1, 2 and 5): logits are stored as every LOGIT_STRIDE-th element of the flattened
+# NCHW tensor, weight gradients as every max(1, size // 50000)-th element; stored in network_big.npz.
+LOGIT_STRIDE = 997
+NETWORK_BIG_CASES = [  # name, layers, image, J, D, batch
+    ("cfg1_r18_128", 18, 128, 17, 64, 2),     # configs[0]: ResNet-18, 2-view 128x128, batch 2 (heat-map 32^2, D = 64 != W)
+    ("cfg2_r50_256", 50, 256, 17, 64, 4),     # configs[1] shape (the bench configuration) at batch 4
+    ("cfg5_r152_384", 152, 384, 17, 64, 2),   # configs[4]: ResNet-152, 384x384 (heat-map 96^2, D = 64 != W)
+]

@@ -95,3 +95,90 @@ def test_bucketed_allreduce_matches_global_batch(tmp_path):
     for a, b, p in zip(h0, h1, list(model.parameters())[:-2]):             # learned-hook mode: same gradients
         assert torch.equal(a, b)
         torch.testing.assert_close(a, p.grad, rtol=1e-5, atol=1e-6)
+
+
+class _MixedNet(nn.Module):
+    """fp32 / bf16 parameters alternating layer by layer, as FusedAdam's bf16 training copies make them in the real network."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.a = nn.Linear(6, 16)
+        self.b = nn.Linear(16, 16).to(torch.bfloat16)
+        self.c = nn.Linear(16, 16)
+        self.d = nn.Linear(16, 16).to(torch.bfloat16)
+        self.e = nn.Linear(16, 4)
+
+    def forward(self, x):
+        x = torch.relu(self.a(x))
+        x = torch.relu(self.b(x.to(torch.bfloat16))).float()
+        x = torch.relu(self.c(x))
+        x = torch.relu(self.d(x.to(torch.bfloat16))).float()
+        return self.e(x)
+
+
+def _mixed_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from epipolarpose_amd import distributed as epd
+    epd.init_from_env(backend="gloo")
+    model = _MixedNet()
+    sync = epd.BucketedGradSync(model, bucket_bytes=1 << 20)
+    # one chain of buckets per dtype, NOT one bucket per dtype change (10 parameters alternate dtype 4 times)
+    assert len(sync.buckets) == 2 and {f.dtype for f, _, _ in sync.buckets} == {torch.float32, torch.bfloat16}
+    torch.manual_seed(7)
+    x, y = torch.randn(8, 6), torch.randn(8, 4)
+    xs, ys = x[4 * rank:4 * rank + 4], y[4 * rank:4 * rank + 4]
+    for _ in range(3):
+        sync.zero_grad()
+        (((model(xs) - ys) ** 2).sum() / 4).backward()
+        sync.finish()
+    torch.save([p.grad.clone() for p in model.parameters()], os.path.join(tmp, "m%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_mixed_dtype_buckets_allreduce(tmp_path):
+    """world 2, gloo: bf16 and fp32 gradients travel in their own bucket chains and both come out as the rank mean."""
+    port = _free_port()
+    mp.spawn(_mixed_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
+    model = _MixedNet()
+    torch.manual_seed(7)
+    x, y = torch.randn(8, 6), torch.randn(8, 4)
+    per_rank = []
+    for r in range(2):
+        model.zero_grad()
+        (((model(x[4 * r:4 * r + 4]) - y[4 * r:4 * r + 4]) ** 2).sum() / 4).backward()
+        per_rank.append([p.grad.clone() for p in model.parameters()])
+    for a, b, w0, w1 in zip(g0, g1, *per_rank):
+        assert torch.equal(a, b)
+        want = (w0.float() + w1.float()) / 2
+        tol = dict(rtol=2e-2, atol=2e-3) if a.dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a.float(), want, **tol)
+
+
+def test_resnet50_bucket_count_with_bf16_training_copies():
+    """The real ResNet-50 with bf16 training copies of the convolution weights (FusedAdam's default): conv (bf16) and BatchNorm
+    (fp32) parameters alternate through the whole network; the gradient path must still be a handful of large buckets
+    (round-1 defect: 106 buckets, median 18.8 KB)."""
+    from epipolarpose_amd import distributed as epd
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    model = get_pose_net(cfg, True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    index = {id(p): i for i, p in enumerate(params)}
+
+    class _Copies:
+        def training_copies(self):
+            out = {}
+            for mod in model.modules():
+                if (type(mod) is nn.Conv2d or getattr(mod, "supports_training_copy", False)) and mod.bias is None:
+                    out[index[id(mod.weight)]] = mod.weight.detach().to(torch.bfloat16).requires_grad_(True)
+            return out
+    sync = epd.BucketedGradSync(model, optimizer=_Copies())
+    sizes = [f.numel() * f.element_size() for f, _, _ in sync.buckets]
+    assert len(sync.buckets) <= 6, sizes
+    assert {f.dtype for f, _, _ in sync.buckets} == {torch.float32, torch.bfloat16}
+    assert sum(len(pl) for _, pl, _ in sync.buckets) == len(params)
+    assert len(epd.BucketedGradSync(model).buckets) <= 6          # pure fp32 gradients

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from det_weights import fill_state_dict, seeded_array
-from make_golden_cases import NETWORK_CASES
+from make_golden_cases import LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -27,42 +27,54 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("case", NETWORK_CASES, ids=[c[0] for c in NETWORK_CASES])
-def test_network_vs_reference_golden(golden, case):
-    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+# (case, parameter) pairs whose fp32 gradient bf16 arithmetic cannot reproduce on the golden input: STOCK PyTorch-ROCm kernels
+# under bf16 autocast reach a cosine < 0.9 against the reference there, so our bf16 network is only required to be finite for
+# them.  Explicit list (round-1 review: a silent `continue` made the check vacuous): a pair that is limited but not listed, or
+# listed but not limited, fails the test.
+KNOWN_BF16_LIMITED = {
+}
+
+
+def _check_network(g, name, layers, image, j, d, b, stride, limited_log):
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss, softmax_integral_tensor
     from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from oracle import network as o_net
     assert torch.cuda.is_available()
     dev = torch.device("cuda:0")
-    g = golden("network")
-    name, layers, image, j, d, b = case
+    sub = (lambda a: a.reshape(-1)[::stride]) if stride else (lambda a: a)
     model = get_pose_net(make_cfg(layers, image, j, d), is_train=True).to(dev)
     shapes = {k: ast.literal_eval(s) for k, s in zip(g[name + "/keys"].tolist(), g[name + "/shapes"].tolist())}
     assert list(model.state_dict().keys()) == list(shapes.keys())
     model.load_state_dict(fill_state_dict(shapes, seed=1))
     x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image))).to(dev)
+    hm = image // 4
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = model(x)
+    assert tuple(out.shape) == (b, j * d, hm, hm)
     ref = g[name + "/logits_eval"]
-    assert out.shape == ref.shape
-    assert np.abs(out.float().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max()
+    ref_max = float(g[name + "/logits_eval_absmax"]) if stride else np.abs(ref).max()
+    assert np.abs(sub(out.float().cpu().numpy()) - ref).max() <= 3e-2 * ref_max
+    if stride:      # decode with the explicit joint count (heat-map width != DEPTH_RES for configs 1 and 5)
+        xyz = softmax_integral_tensor(out, j, True, hm, hm, d).cpu().numpy()
+        np.testing.assert_allclose(xyz, g[name + "/xyz_eval"], atol=1.5e-2)
     model.train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         logits = model(x)
     ref = g[name + "/logits_train"]
-    # Training-mode BatchNorm over a batch of 2 at 2x2 spatial amplifies bf16 rounding through the whole depth, so the
-    # yardstick is the oracle network run through STOCK PyTorch-ROCm kernels under the same bf16 autocast: our error
+    ref_max = float(g[name + "/logits_train_absmax"]) if stride else np.abs(ref).max()
+    # Training-mode BatchNorm over a small batch at 2x2 .. 12x12 spatial amplifies bf16 rounding through the whole depth, so
+    # the yardstick is the oracle network run through STOCK PyTorch-ROCm kernels under the same bf16 autocast: our error
     # against the fp32 reference must not exceed 1.5x the stock-bf16 error (or 8 % of max|logit|, whichever is larger).
-    from oracle import network as o_net
     sd = {k: v.to(dev) for k, v in fill_state_dict(shapes, seed=1).items()}
     params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
     sd.update(params)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         ologits = o_net.forward(sd, x, layers, training=True, new_stats={})
-    err_ours = np.abs(logits.float().detach().cpu().numpy() - ref).max()
-    err_stock = np.abs(ologits.float().detach().cpu().numpy() - ref).max()
-    assert err_ours <= max(8e-2 * np.abs(ref).max(), 1.5 * err_stock), (err_ours, err_stock, np.abs(ref).max())
-    c_ours, c_stock = cosine(logits.float().detach().cpu(), torch.from_numpy(ref)), cosine(ologits.float().detach().cpu(), torch.from_numpy(ref))
+    ours, stock = sub(logits.float().detach().cpu().numpy()), sub(ologits.float().detach().cpu().numpy())
+    err_ours, err_stock = np.abs(ours - ref).max(), np.abs(stock - ref).max()
+    assert err_ours <= max(8e-2 * ref_max, 1.5 * err_stock), (err_ours, err_stock, ref_max)
+    c_ours, c_stock = cosine(torch.from_numpy(ours), torch.from_numpy(ref)), cosine(torch.from_numpy(stock), torch.from_numpy(ref))
     assert c_ours >= min(0.99, c_stock - 0.01), (c_ours, c_stock)
     gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
     loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
@@ -74,18 +86,53 @@ def test_network_vs_reference_golden(golden, case):
     grads = {k: p.grad for k, p in model.named_parameters()}
     # gradients: same yardstick (deep-layer gradients of ANY bf16 run sit at cosine ~0.96-0.99 against fp32 here)
     o_net.joint_location_loss(ologits.float(), gt, torch.ones(b, 3 * j, device=dev), j, "smoothl1").backward()
-    for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.0.weight", "conv1.weight"):
+    stale = []
+    for k in sorted(kk[len(name) + 6:] for kk in g if kk.startswith(name + "/grad/")):
+        if k not in grads or k == "deconv_layers.7.weight":
+            continue
         got = grads[k].float().contiguous().cpu()
         stock = params[k].grad.float().contiguous().cpu()
         refg = torch.from_numpy(g[name + "/grad/" + k])
+        assert torch.isfinite(got).all(), k
         if refg.dim() == 1 and got.dim() > 1:
             step = max(1, got.numel() // 50000)
             got, stock = got.reshape(-1)[::step], stock.reshape(-1)[::step]
         c_ours, c_stock = cosine(got, refg), cosine(stock, refg)
-        if c_stock < 0.9:
-            continue        # bf16 itself cannot reproduce the fp32 gradient of this layer on this input: check is vacuous
+        limited = c_stock < 0.9
+        if limited:
+            limited_log.append((name, k, round(c_stock, 3), round(c_ours, 3)))
+        if limited != ((name, k) in KNOWN_BF16_LIMITED):
+            stale.append((name, k, round(c_stock, 3), round(c_ours, 3)))
+        if limited:
+            continue
         assert c_ours >= min(0.99, c_stock - 0.01), (k, c_ours, c_stock)
         assert abs(float(got.norm() / refg.norm()) - 1.0) <= 0.15, k
+    assert not stale, ("KNOWN_BF16_LIMITED is out of date (case, parameter, stock cosine, our cosine)", stale)
+
+
+@pytest.fixture(scope="module")
+def limited_log():
+    log = []
+    yield log
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "bf16_limited_pairs.json"), "w") as f:
+        json.dump(log, f)
+
+
+@pytest.mark.parametrize("case", NETWORK_CASES, ids=[c[0] for c in NETWORK_CASES])
+def test_network_vs_reference_golden(golden, case, limited_log):
+    name, layers, image, j, d, b = case
+    _check_network(golden("network"), name, layers, image, j, d, b, 0, limited_log)
+
+
+@pytest.mark.parametrize("case", NETWORK_BIG_CASES, ids=[c[0] for c in NETWORK_BIG_CASES])
+def test_network_full_configs_vs_reference_golden(golden, case, limited_log):
+    """BASELINE.json configs 1 (ResNet-18, 128x128), 2 (ResNet-50, 256x256: the bench shape) and 5 (ResNet-152, 384x384) against
+    the reference network executed in fp32 (tests/golden/make_golden.py network_big); sub-sampled logits, full decode + loss."""
+    name, layers, image, j, d, b = case
+    _check_network(golden("network_big"), name, layers, image, j, d, b, LOGIT_STRIDE, limited_log)
 
 
 def test_training_reduces_loss_and_ss_step_runs():
