@@ -50,6 +50,15 @@ struct GemmScatter {       // maps GEMM row m to an output row
     int Ho, Wo;            // output tensor [n][Ho][Wo][ldc]
     int so, oy, ox;        // output pixel = (i*so + oy, j*so + ox)
 };
+// Output-parity phases of a stride-2 transposed convolution (ConvTranspose2d forward, or the backward-data of a stride-2
+// Conv2d): blockIdx.z = phase 2*py + px owns the output pixels (2i + py, 2j + px); only the taps whose stride lands on that
+// parity contribute, so every phase is its own gather GEMM with its own tap list, K extent and weight block.
+struct GemmPhases {
+    int enabled;
+    int ntap[4];           // taps of phase p (0 .. 4); K of the phase = ntap * ga.Cs
+    int dy[4][4], dx[4][4];   // source pixel of tap t = (i + dy, j + dx)
+    long long bt_off[4];   // element offset of the phase's weight block [N][ntap * Cs] inside Bt
+};
 struct GemmArgs {
     const unsigned short* A;
     const unsigned short* Bt;
@@ -58,7 +67,7 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc;
     GemmGather ga;
     GemmScatter sc;
-    int deconv_phases;     // 1: blockIdx.z = output-parity phase 2*ph+pw of ConvTranspose2d(k4,s2,p1); taps/weights/scatter derive from it
+    GemmPhases ph;         // enabled: K = the LARGEST phase's extent (split-K planning); ldb is per phase ntap * Cs
     int k_per_split;       // split-K: blockIdx.y handles K range [y*k_per_split, ...) and writes an fp32 slab (plain rows)
     float* slabs;          // [nsplit][nphase][M][N] when gridDim.y > 1
 };
@@ -84,7 +93,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
-enum { A_PLAIN = 0, A_GATHER = 1, A_DECONV = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
+enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
 
 template <bool OUT_F32, typename Cfg, int MODE>
 __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_kernel(GemmArgs p) {
@@ -102,10 +111,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
     const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
     const int ph = phase >> 1, pw = phase & 1;
-    const unsigned short* Bt = p.Bt + (MODE == A_DECONV ? (long long)phase * p.N * p.ldb : 0);
-    const int sc_oy = MODE == A_DECONV ? ph : p.sc.oy, sc_ox = MODE == A_DECONV ? pw : p.sc.ox;
+    const unsigned short* Bt = p.Bt + (MODE == A_PHASED ? p.ph.bt_off[phase] : 0);
+    const int ldb = MODE == A_PHASED ? p.ph.ntap[phase] * p.ga.Cs : p.ldb;
+    const int sc_oy = MODE == A_PHASED ? ph : p.sc.oy, sc_ox = MODE == A_PHASED ? pw : p.sc.ox;
+    const int k_total = MODE == A_PHASED ? p.ph.ntap[phase] * p.ga.Cs : p.K;
     const int k_begin = split_id * p.k_per_split;
-    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int k_end = min(k_total, k_begin + p.k_per_split);
 
     // ---- staging roles (direct-to-LDS): wave w, piece ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear) of the
     //      A tile and of the B tile; lane l lands at row 32*w + 8*ps + (l >> 3), PHYSICAL chunk l & 7, so it fetches the
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         }
         const int n = n0 + trow;
         b_ok[ps] = n < p.N;
-        b_row[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * p.ldb + s_chunk[ps] * 8;
+        b_row[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * ldb + s_chunk[ps] * 8;
     }
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
     // one piece = 1 KiB of the A tile + 1 KiB of the B tile for K tile k0 (two DMA instructions per wave)
@@ -147,9 +158,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         long long off;
         if (MODE != A_PLAIN) {
             const int tap = k0 / p.ga.Cs, c0 = k0 - tap * p.ga.Cs;
-            // ConvTranspose phases: oh = 2*ih - 1 + kh, so tap (ty, tx) of phase (ph, pw) reads (i + ph - ty, j + pw - tx)
-            const int tdy = MODE == A_DECONV ? ph - (tap >> 1) : p.ga.dy[tap];
-            const int tdx = MODE == A_DECONV ? pw - (tap & 1) : p.ga.dx[tap];
+            const int tdy = MODE == A_PHASED ? p.ph.dy[phase][tap] : p.ga.dy[tap];
+            const int tdx = MODE == A_PHASED ? p.ph.dx[phase][tap] : p.ga.dx[tap];
             const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
             ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
             off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + s_chunk[ps] * 8;
@@ -170,9 +180,11 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (k_end - k_begin + GBK - 1) / GBK;
+    const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;     // 0: a phase without taps / an empty split (zeros)
+    if (nk > 0) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) issue_piece(ps, k_begin, 0);
+        for (int ps = 0; ps < 4; ++ps) issue_piece(ps, k_begin, 0);
+    }
     __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
     const int frow = lane & 31, fhalf = lane >> 5;
     const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         __syncthreads();
     };
     for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type());
-    k_tile(nk - 1, std::false_type());
+    if (nk > 0) k_tile(nk - 1, std::false_type());
 
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*TM*32 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
@@ -487,7 +499,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
         const int hw = p.sc.Hg * p.sc.Wg;
         const int b = m / hw, rem = m - b * hw;
         const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
-        const int oy = p.deconv_phases ? (phase >> 1) : p.sc.oy, ox = p.deconv_phases ? (phase & 1) : p.sc.ox;
+        const int oy = p.ph.enabled ? (phase >> 1) : p.sc.oy, ox = p.ph.enabled ? (phase & 1) : p.sc.ox;
         orow = ((long long)b * p.sc.Ho + i * p.sc.so + oy) * p.sc.Wo + j * p.sc.so + ox;
     }
     if (OUT_F32) {
@@ -587,7 +599,7 @@ static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, h
 }
 template <bool OUT_F32, typename Cfg>
 static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
-    if (a.deconv_phases) return launch_gemm_mode<OUT_F32, Cfg, A_DECONV>(a, pl, nphase, st);
+    if (a.ph.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_PHASED>(a, pl, nphase, st);
     if (a.ga.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_GATHER>(a, pl, nphase, st);
     return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN>(a, pl, nphase, st);
 }
@@ -659,7 +671,13 @@ extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, 
     a.M = B * H * W; a.N = Cout; a.K = 4 * Cin; a.lda = 0; a.ldb = 4 * Cin; a.ldc = Cout;
     a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = H; a.ga.Ws = W; a.ga.Cs = Cin; a.ga.stride = 1;
     a.sc.enabled = 1; a.sc.Hg = H; a.sc.Wg = W; a.sc.Ho = 2 * H; a.sc.Wo = 2 * W; a.sc.so = 2;
-    a.deconv_phases = 1;
+    a.ph.enabled = 1;
+    // oh = 2*ih - 1 + kh: tap (ty, tx) of phase (py, px) reads the input pixel (i + py - ty, j + px - tx)
+    for (int phase = 0; phase < 4; ++phase) {
+        a.ph.ntap[phase] = 4;
+        a.ph.bt_off[phase] = (long long)phase * Cout * 4 * Cin;
+        for (int t = 0; t < 4; ++t) { a.ph.dy[phase][t] = (phase >> 1) - (t >> 1); a.ph.dx[phase][t] = (phase & 1) - (t & 1); }
+    }
     return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1007,4 +1025,178 @@ extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, in
             for (int kw = 0; kw < KW; ++kw) { a.gb.dy[kh * KW + kw] = kh - pad; a.gb.dx[kh * KW + kw] = kw - pad; }
     }
     return launch_tn(a, KH * KW, dw, (float*)workspace, workspace_bytes, (hipStream_t)stream, 1, dw_dtype == EPI_BF16);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backbone convolutions (lib/models/pose3d_resnet.py:21-88: BasicBlock / Bottleneck conv1..conv3 and the downsample
+// projections) on the same implicit-GEMM kernel: NHWC bf16 activations, channels_last weights.
+//   forward        y[n][oh][ow][co] = sum_{kh,kw,ci} x[n][oh*s + kh - pad][ow*s + kw - pad][ci] * w[co][kh][kw][ci]
+//                  = gather GEMM, M = B*Ho*Wo, N = Cout, K = KH*KW*Cin, Bt = the weight as it lies in memory
+//   backward-data  stride 1: gather GEMM over dy with taps (pad - kh, pad - kw) and the transposed weight [Cin][KH][KW][Cout];
+//                  stride 2: four output-parity phases (GemmPhases), each with the taps whose stride lands on that parity
+//   backward-weight epi_conv2d_bwd_weight above (TN kernel).
+// The transposed / phase-ordered weight is produced by epi_conv2d_pack_weight_bwd once per optimizer step.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ConvBwdLayout {      // where tap (kh, kw) of the ORIGINAL weight goes in the packed backward-data weight
+    int nphase;             // 1 (stride 1) or 4 (stride 2)
+    int ntap[4];
+    int dy[4][4], dx[4][4];
+    long long bt_off[4];    // element offset of phase block [Cin][ntap * Cout]
+    int tap_phase[16], tap_slot[16];   // per original tap: phase and position inside the phase (-1: tap unused)
+};
+
+// returns false when the geometry is not covered (more than 16 taps, more than 4 taps in a stride-2 phase, stride > 2)
+bool conv_bwd_layout(int KH, int KW, int stride, int pad, int Cin, int Cout, ConvBwdLayout* L) {
+    if (KH * KW > 16 || stride < 1 || stride > 2) return false;
+    *L = ConvBwdLayout();
+    if (stride == 1) {
+        L->nphase = 1;
+        for (int t = 0; t < KH * KW; ++t) { L->tap_phase[t] = 0; L->tap_slot[t] = t; }
+        L->ntap[0] = KH * KW;
+        return true;
+    }
+    L->nphase = 4;
+    long long off = 0;
+    for (int phase = 0; phase < 4; ++phase) {
+        const int py = phase >> 1, px = phase & 1;
+        int n = 0;
+        for (int kh = 0; kh < KH; ++kh) {
+            if ((py + pad - kh) & 1) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                if ((px + pad - kw) & 1) continue;
+                if (n == 4) return false;
+                L->dy[phase][n] = (py + pad - kh) / 2;          // exact: the numerator is even
+                L->dx[phase][n] = (px + pad - kw) / 2;
+                L->tap_phase[kh * KW + kw] = phase;
+                L->tap_slot[kh * KW + kw] = n;
+                ++n;
+            }
+        }
+        L->ntap[phase] = n;
+        L->bt_off[phase] = off;
+        off += (long long)Cin * n * Cout;
+    }
+    return true;
+}
+
+struct PackArgs {
+    const unsigned short* w;     // [Cout][ntap][Cin]
+    unsigned short* out;
+    int Cout, Cin, ntap;
+    long long dst_base[16];      // per original tap: element offset of (ci = 0, co = 0) in the packed buffer
+    int dst_ci_stride[16];       // per original tap: elements between consecutive ci
+};
+
+}  // namespace
+
+namespace epi {
+// 32 x 32 (co x ci) tile transpose through LDS: coalesced reads along ci, coalesced writes along co
+__global__ __launch_bounds__(256) void conv_pack_weight_bwd_kernel(PackArgs p) {
+    __shared__ unsigned short tile[32][33];
+    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + ty + 8 * r, ci = ci0 + tx;
+        tile[ty + 8 * r][tx] = (co < p.Cout && ci < p.Cin) ? p.w[((long long)co * p.ntap + tap) * p.Cin + ci] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ci = ci0 + ty + 8 * r, co = co0 + tx;
+        if (ci < p.Cin && co < p.Cout) p.out[p.dst_base[tap] + (long long)ci * p.dst_ci_stride[tap] + co] = tile[tx][ty + 8 * r];
+    }
+}
+}  // namespace epi
+
+extern "C" int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
+                                          epi_stream_t stream) {
+    if (!w || !w_bwd || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    ConvBwdLayout L;
+    if (!conv_bwd_layout(KH, KW, stride, pad, Cin, Cout, &L)) return EPI_ERR_UNSUPPORTED;
+    PackArgs a = {};
+    a.w = (const unsigned short*)w; a.out = (unsigned short*)w_bwd; a.Cout = Cout; a.Cin = Cin; a.ntap = KH * KW;
+    for (int t = 0; t < KH * KW; ++t) {
+        const int ph = L.tap_phase[t];
+        a.dst_base[t] = L.bt_off[ph] + (long long)L.tap_slot[t] * Cout;
+        a.dst_ci_stride[t] = L.ntap[ph] * Cout;
+    }
+    hipLaunchKernelGGL(epi::conv_pack_weight_bwd_kernel, dim3((unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32), (unsigned)(KH * KW)),
+                       dim3(256), 0, (hipStream_t)stream, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+static inline int conv_out_dim(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
+
+extern "C" size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+    const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
+    if (Ho <= 0 || Wo <= 0) return 0;
+    size_t need = epi_gemm_workspace_bytes(B * Ho * Wo, Cout, KH * KW * Cin, 1);                       // forward
+    if (stride == 1) need = std::max(need, epi_gemm_workspace_bytes(B * H * W, Cin, KH * KW * Cout, 1));   // backward-data
+    else need = std::max(need, epi_gemm_workspace_bytes(B * ((H + 1) / 2) * ((W + 1) / 2), Cin, 4 * Cout, 4));
+    return need;
+}
+
+extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                              int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return EPI_ERR_INVALID_ARGUMENT;
+    const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
+    if (Ho <= 0 || Wo <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (KH * KW > 16 || Cout % 4) return EPI_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)x; a.Bt = (const unsigned short*)w; a.C = y;
+    a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.ldb = KH * KW * Cin; a.ldc = Cout;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) {
+        a.lda = Cin;                                     // plain GEMM on the [B*H*W][Cin] view
+    } else {
+        if (Cin % GBK) return EPI_ERR_UNSUPPORTED;
+        a.ga.enabled = 1; a.ga.Hg = Ho; a.ga.Wg = Wo; a.ga.Hs = H; a.ga.Ws = W; a.ga.Cs = Cin; a.ga.stride = stride;
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = kh - pad; a.ga.dx[kh * KW + kw] = kw - pad; }
+    }
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+        return EPI_ERR_INVALID_ARGUMENT;
+    const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
+    if (Ho <= 0 || Wo <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    ConvBwdLayout L;
+    if (!conv_bwd_layout(KH, KW, stride, pad, Cin, Cout, &L) || Cin % 4) return EPI_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)dy; a.Bt = (const unsigned short*)w_bwd; a.C = dx; a.N = Cin; a.ldc = Cin;
+    if (stride == 1) {
+        a.M = B * H * W; a.K = KH * KW * Cout; a.ldb = KH * KW * Cout;
+        if (KH == 1 && KW == 1 && pad == 0) {
+            a.lda = Cout;
+        } else {
+            if (Cout % GBK) return EPI_ERR_UNSUPPORTED;
+            a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = Ho; a.ga.Ws = Wo; a.ga.Cs = Cout; a.ga.stride = 1;
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = pad - kh; a.ga.dx[kh * KW + kw] = pad - kw; }
+        }
+        return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    }
+    // stride 2: dx pixel (2i + py, 2j + px) gathers dy pixels (i + dy_t, j + dx_t) over the taps of its parity phase
+    if ((H & 1) || (W & 1) || Cout % GBK) return EPI_ERR_UNSUPPORTED;
+    const int Hh = H / 2, Wh = W / 2;
+    int kmax = 0;
+    for (int p = 0; p < 4; ++p) kmax = std::max(kmax, L.ntap[p] * Cout);
+    a.M = B * Hh * Wh; a.K = kmax; a.ldb = kmax;
+    a.ga.enabled = 1; a.ga.Hg = Hh; a.ga.Wg = Wh; a.ga.Hs = Ho; a.ga.Ws = Wo; a.ga.Cs = Cout; a.ga.stride = 1;
+    a.sc.enabled = 1; a.sc.Hg = Hh; a.sc.Wg = Wh; a.sc.Ho = H; a.sc.Wo = W; a.sc.so = 2;
+    a.ph.enabled = 1;
+    for (int p = 0; p < 4; ++p) {
+        a.ph.ntap[p] = L.ntap[p];
+        a.ph.bt_off[p] = L.bt_off[p];
+        for (int t = 0; t < 4; ++t) { a.ph.dy[p][t] = L.dy[p][t]; a.ph.dx[p][t] = L.dx[p][t]; }
+    }
+    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -47,6 +47,10 @@ _SIGNATURES = {
     "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_workspace_bytes": (_sz, [_i] * 9),
+    "epi_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_pack_weight_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -582,6 +586,60 @@ def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
         _check(lib.epi_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32, b, h, w, cin, cout,
                                          kh, kw, stride, padding, _ptr(ws), ws.numel(), _stream()), "epi_conv2d_bwd_weight")
     return dw
+
+
+def _cl_weight_bf16(weight):
+    """[Cout, Cin, KH, KW] weight -> bf16 tensor whose MEMORY is [Cout][KH][KW][Cin] (channels_last)."""
+    _dev(weight, name="weight")
+    w = weight.detach()
+    if w.dtype != torch.bfloat16:
+        w = w.to(torch.bfloat16)
+    return w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
+
+
+def conv2d_fwd(x, weight, stride=1, padding=0):
+    """x [B, Cin, H, W] channels_last bf16, weight [Cout, Cin, KH, KW] (channels_last memory) -> y [B, Cout, Ho, Wo]
+    channels_last bf16.  Reference: the nn.Conv2d calls of pose3d_resnet.py:21-88."""
+    lib = load()
+    x = _nhwc_bf16(x, "x")
+    w = _cl_weight_bf16(weight)
+    b, cin, h, wd = x.shape
+    cout, _, kh, kw = w.shape
+    ho, wo = (h + 2 * padding - kh) // stride + 1, (wd + 2 * padding - kw) // stride + 1
+    y = torch.empty((b, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_conv2d_workspace_bytes(b, h, wd, cin, cout, kh, kw, stride, padding), x.device)
+    ev = timer.start("epi_conv2d_fwd")
+    _check(lib.epi_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(ws), ws.numel(), _stream()),
+           "epi_conv2d_fwd")
+    timer.stop(ev)
+    return y
+
+
+def conv2d_pack_weight_bwd(weight, stride=1, padding=0, out=None):
+    """weight [Cout, Cin, KH, KW] -> the backward-data operand (flat bf16, Cin*KH*KW*Cout elements; see epipolar_hip.h)."""
+    lib = load()
+    w = _cl_weight_bf16(weight)
+    cout, cin, kh, kw = w.shape
+    if out is None:
+        out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
+    _check(lib.epi_conv2d_pack_weight_bwd(_ptr(w), cout, cin, kh, kw, stride, padding, _ptr(out), _stream()), "epi_conv2d_pack_weight_bwd")
+    return out
+
+
+def conv2d_bwd_data(dy, w_bwd, in_shape, kernel, stride=1, padding=0):
+    """dy [B, Cout, Ho, Wo] channels_last bf16, w_bwd from ``conv2d_pack_weight_bwd`` -> dx of shape ``in_shape`` = (B, Cin, H, W)."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    b, cin, h, wd = in_shape
+    cout = dy.shape[1]
+    kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+    dx = torch.empty((b, cin, h, wd), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_conv2d_workspace_bytes(b, h, wd, cin, cout, kh, kw, stride, padding), dy.device)
+    ev = timer.start("epi_conv2d_bwd_data")
+    _check(lib.epi_conv2d_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(ws), ws.numel(),
+                                   _stream()), "epi_conv2d_bwd_data")
+    timer.stop(ev)
+    return dx
 
 
 def column_sum_bf16(x):

@@ -213,6 +213,28 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, epi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backbone convolutions on the matrix cores -- replace the cuDNN/MIOpen calls behind every bias-free nn.Conv2d of
+ * lib/models/pose3d_resnet.py:21-88,130-136 (BasicBlock / Bottleneck conv1..conv3, downsample.0; groups 1, dilation 1).
+ * NHWC bf16 activations, fp32 accumulation; the same implicit-GEMM kernel as the deconvolution head.
+ *   x [B][H][W][Cin],  y / dy [B][Ho][Wo][Cout],  Ho = (H + 2*pad - KH)/stride + 1
+ *   w      [Cout][KH][KW][Cin]  bf16 -- the memory order of a channels_last weight tensor (no repacking for the forward)
+ *   w_bwd  Cin*KH*KW*Cout bf16, written by epi_conv2d_pack_weight_bwd: [Cin][KH][KW][Cout] for stride 1; for stride 2
+ *          the four output-parity phase blocks [Cin][taps of the phase][Cout] one after the other
+ * Coverage: KH*KW <= 16, Cout % 4 == 0, Cin % 4 == 0, and Cin % 64 == 0 (forward) / Cout % 64 == 0 (backward-data) unless
+ * the convolution is 1x1 / stride 1 / pad 0 (a plain GEMM: % 8); stride 1 or 2; stride-2 backward-data needs even H, W and
+ * at most 4 taps per parity phase (3x3 pad 1 and 1x1 pad 0 qualify).  Anything else: EPI_ERR_UNSUPPORTED (the caller keeps
+ * the library convolution for it, e.g. the 7x7 stem on 3 input channels).
+ * workspace: epi_conv2d_workspace_bytes(...) covers forward and backward-data of one layer.
+ * ------------------------------------------------------------------------------------------------ */
+size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                   int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
+                               epi_stream_t stream);
+int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                        int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+
 /* Weight gradient of a Conv2d (groups 1, dilation 1) on NHWC bf16 tensors -- the backbone convolutions' backward-weight
  * (autograd of nn.Conv2d in lib/models/pose3d_resnet.py:21-88), which the reference leaves to cuDNN:
  *   x [B][H][W][Cin], dy [B][Ho][Wo][Cout] -> dw [Cout][KH][KW][Cin] (channels_last weight order), dw_dtype EPI_F32 | EPI_BF16;

@@ -32,6 +32,10 @@ def cosine(a, b):
 # them.  Explicit list (round-1 review: a silent `continue` made the check vacuous): a pair that is limited but not listed, or
 # listed but not limited, fails the test.
 KNOWN_BF16_LIMITED = {
+    ("r18", "conv1.weight"),               # stock bf16 cosine 0.85 (ours 0.89) on MI355X, round 2
+    ("r50", "conv1.weight"),               # 0.10 (0.13): 128x128 input, batch 4 -- 2x2 maps in layer4 under training BatchNorm
+    ("r50", "deconv_layers.0.weight"),     # 0.45 (0.45)
+    ("r50", "deconv_layers.6.weight"),     # 0.85 (0.86)
 }
 
 
@@ -55,9 +59,20 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log):
     ref = g[name + "/logits_eval"]
     ref_max = float(g[name + "/logits_eval_absmax"]) if stride else np.abs(ref).max()
     assert np.abs(sub(out.float().cpu().numpy()) - ref).max() <= 3e-2 * ref_max
-    if stride:      # decode with the explicit joint count (heat-map width != DEPTH_RES for configs 1 and 5)
+    if stride:
+        # decode with the explicit joint count (heat-map width != DEPTH_RES for configs 1 and 5).  With the He-scaled golden
+        # weights the logits reach several hundred, so the soft-argmax is practically a hard arg-max and a bf16 rounding that
+        # swaps two near-equal top voxels moves a coordinate by whole voxels: the yardstick is again the oracle network under
+        # STOCK bf16 autocast -- the fraction of coordinates off by more than 1.5e-2 must not exceed stock's by more than 5 %.
         xyz = softmax_integral_tensor(out, j, True, hm, hm, d).cpu().numpy()
-        np.testing.assert_allclose(xyz, g[name + "/xyz_eval"], atol=1.5e-2)
+        sd_e = {k: v.to(dev) for k, v in fill_state_dict(shapes, seed=1).items()}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            stock_eval = o_net.forward(sd_e, x, layers, training=False)
+        xyz_stock = softmax_integral_tensor(stock_eval.to(torch.bfloat16), j, True, hm, hm, d).cpu().numpy()
+        ref_xyz = g[name + "/xyz_eval"]
+        bad_ours, bad_stock = float((np.abs(xyz - ref_xyz) > 1.5e-2).mean()), float((np.abs(xyz_stock - ref_xyz) > 1.5e-2).mean())
+        assert bad_ours <= bad_stock + 0.05, (bad_ours, bad_stock)
+        assert bad_ours <= 0.25, bad_ours
     model.train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         logits = model(x)
