@@ -214,9 +214,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ sums,
                                                                   unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
-                                                                  float* __restrict__ fwd_sums_clear) {
-    if (fwd_sums_clear && blockIdx.x == 0)         // the forward statistics accumulator of this layer's NEXT forward pass
-        for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
+                                                                  float* __restrict__ fwd_sums_clear, float* __restrict__ param_grads) {
+    if (blockIdx.x == 0) {
+        if (fwd_sums_clear)                        // the forward statistics accumulator of this layer's NEXT forward pass
+            for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
+        if (param_grads)                           // (dbeta | dgamma) handed to the caller in memory the accumulator protocol never touches
+            for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) param_grads[c] = sums[c];
+    }
     const int cg = C >> 3;
     const float inv_r = 1.f / (float)R;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
@@ -302,7 +306,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
 
 extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
                               const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
-                              float* fwd_sums_clear, epi_stream_t stream) {
+                              float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
@@ -322,7 +326,7 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear)
+#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, param_grads)
     if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
     else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }
     else { if (dres) EPI_BN_APP(BN_MASK_FROM_Y, true); else EPI_BN_APP(BN_MASK_FROM_Y, false); }

@@ -1085,6 +1085,9 @@ struct PackArgs {
     const unsigned short* w;     // [Cout][ntap][Cin]
     unsigned short* out;
     int Cout, Cin, ntap;
+    int tiles_ci, tiles_co;      // 32 x 32 tiles along Cin / Cout   (multi-layer table only)
+    int reserved;
+    long long tile_begin;        // first global tile of this row      (multi-layer table only)
     long long dst_base[16];      // per original tap: element offset of (ci = 0, co = 0) in the packed buffer
     int dst_ci_stride[16];       // per original tap: elements between consecutive ci
 };
@@ -1093,9 +1096,30 @@ struct PackArgs {
 
 namespace epi {
 // 32 x 32 (co x ci) tile transpose through LDS: coalesced reads along ci, coalesced writes along co
+__device__ __forceinline__ void conv_pack_tile(const PackArgs& p, int tap, int ci0, int co0);
+
 __global__ __launch_bounds__(256) void conv_pack_weight_bwd_kernel(PackArgs p) {
+    conv_pack_tile(p, blockIdx.z, blockIdx.x * 32, blockIdx.y * 32);
+}
+
+// every layer of a table in one launch: blockIdx.x = global tile; the owning row is found by bisection on tile_begin
+__global__ __launch_bounds__(256) void conv_pack_weight_bwd_multi_kernel(const PackArgs* __restrict__ rows, int nrows) {
+    const long long t = blockIdx.x;
+    int lo = 0, hi = nrows - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rows[mid].tile_begin <= t) lo = mid; else hi = mid - 1;
+    }
+    const PackArgs& p = rows[lo];
+    int local = (int)(t - p.tile_begin);
+    const int tci = local % p.tiles_ci;
+    local /= p.tiles_ci;
+    const int tco = local % p.tiles_co, tap = local / p.tiles_co;
+    conv_pack_tile(p, tap, tci * 32, tco * 32);
+}
+
+__device__ __forceinline__ void conv_pack_tile(const PackArgs& p, int tap, int ci0, int co0) {
     __shared__ unsigned short tile[32][33];
-    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1111,18 +1135,48 @@ __global__ __launch_bounds__(256) void conv_pack_weight_bwd_kernel(PackArgs p) {
 }
 }  // namespace epi
 
-extern "C" int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
-                                          epi_stream_t stream) {
+static int conv_pack_args(PackArgs* a, const void* w, void* w_bwd, int Cout, int Cin, int KH, int KW, int stride, int pad) {
     if (!w || !w_bwd || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return EPI_ERR_INVALID_ARGUMENT;
     ConvBwdLayout L;
     if (!conv_bwd_layout(KH, KW, stride, pad, Cin, Cout, &L)) return EPI_ERR_UNSUPPORTED;
-    PackArgs a = {};
-    a.w = (const unsigned short*)w; a.out = (unsigned short*)w_bwd; a.Cout = Cout; a.Cin = Cin; a.ntap = KH * KW;
+    *a = PackArgs();
+    a->w = (const unsigned short*)w; a->out = (unsigned short*)w_bwd; a->Cout = Cout; a->Cin = Cin; a->ntap = KH * KW;
+    a->tiles_ci = (Cin + 31) / 32; a->tiles_co = (Cout + 31) / 32;
     for (int t = 0; t < KH * KW; ++t) {
         const int ph = L.tap_phase[t];
-        a.dst_base[t] = L.bt_off[ph] + (long long)L.tap_slot[t] * Cout;
-        a.dst_ci_stride[t] = L.ntap[ph] * Cout;
+        a->dst_base[t] = L.bt_off[ph] + (long long)L.tap_slot[t] * Cout;
+        a->dst_ci_stride[t] = L.ntap[ph] * Cout;
     }
+    return EPI_OK;
+}
+
+extern "C" size_t epi_conv2d_pack_row_bytes(void) { return sizeof(PackArgs); }
+
+extern "C" int epi_conv2d_pack_fill_row(void* row_host, const void* w, void* w_bwd, int Cout, int Cin, int KH, int KW, int stride,
+                                        int pad, long long tile_begin, long long* ntiles) {
+    if (!row_host || !ntiles) return EPI_ERR_INVALID_ARGUMENT;
+    PackArgs a;
+    const int rc = conv_pack_args(&a, w, w_bwd, Cout, Cin, KH, KW, stride, pad);
+    if (rc != EPI_OK) return rc;
+    a.tile_begin = tile_begin;
+    *reinterpret_cast<PackArgs*>(row_host) = a;
+    *ntiles = (long long)a.tiles_ci * a.tiles_co * a.ntap;
+    return EPI_OK;
+}
+
+extern "C" int epi_conv2d_pack_weight_bwd_multi(const void* rows, int nrows, long long total_tiles, epi_stream_t stream) {
+    if (!rows || nrows <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return EPI_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(epi::conv_pack_weight_bwd_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const PackArgs*)rows, nrows);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
+                                          epi_stream_t stream) {
+    PackArgs a;
+    const int rc = conv_pack_args(&a, w, w_bwd, Cout, Cin, KH, KW, stride, pad);
+    if (rc != EPI_OK) return rc;
     hipLaunchKernelGGL(epi::conv_pack_weight_bwd_kernel, dim3((unsigned)((Cin + 31) / 32), (unsigned)((Cout + 31) / 32), (unsigned)(KH * KW)),
                        dim3(256), 0, (hipStream_t)stream, a);
     EPI_CHECK_LAUNCH();

@@ -2,11 +2,19 @@
 //
 // Not a kernel and not a second implementation: every function here only allocates outputs, forwards raw device
 // pointers to an `epi_*` entry point on the current HIP stream, and tells autograd what to save.  It exists because the
-// network calls the fused BatchNorm 53 times per step in each direction, and a Python autograd.Function + ctypes call costs
+// network calls a fused op ~60 times per step in each direction, and a Python autograd.Function + ctypes call costs
 // ~35 us of host time per call -- at batch 32 the step had become host-bound (tools/host_profile.py).  The Python classes
 // in models/fused.py keep the module interface (parameters, buffers, state_dict) and call into this extension.
+//
+//   bn_act        BatchNorm (+ residual) (+ ReLU)                                   one autograd node
+//   conv_bn_act   Conv2d -> BatchNorm (+ residual) (+ ReLU)  (a whole conv-bn-relu    one autograd node, 2-3 launches forward,
+//                 stage of BasicBlock / Bottleneck, pose3d_resnet.py:31-47,68-88)   4 backward
+//   adam_prepare  the per-step pointer table of FusedAdam (170 parameters) without a Python loop
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "../../include/epipolar_hip.h"
 
@@ -28,8 +36,77 @@ inline bool nhwc_bf16(const Tensor& t) {
     return t.scalar_type() == at::kBFloat16 && t.dim() == 4 && t.is_contiguous(at::MemoryFormat::ChannelsLast);
 }
 
+// split-K / slab scratch shared by every GEMM-type launch of this process (one process per GPU; launches on one stream are
+// ordered, so consecutive kernels may reuse it); grown on demand, never shrunk
+Tensor& workspace(size_t bytes, const Tensor& like) {
+    static std::vector<Tensor> per_device(64);
+    Tensor& ws = per_device[like.device().index()];
+    if (!ws.defined() || (size_t)ws.numel() < bytes)
+        ws = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 16)}, like.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+    return ws;
+}
+
+// ---- BatchNorm halves shared by bn_act and conv_bn_act ------------------------------------------------------------
 // flags (CPU int32[2], owned by the module): [0] sums_ws still holds a forward's sums, [1] bwd_sums still holds a
 // backward's sums -- the accumulator hand-over protocol of epi_bn_act_fwd / epi_bn_act_bwd (see include/epipolar_hip.h)
+struct BnBuffers {
+    Tensor weight, bias, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags;
+};
+
+// x: raw input [B,C,H,W] NHWC bf16.  Returns y; `stats` receives (mean | rstd | scale | shift).
+Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, bool training, double momentum, double eps, bool relu,
+                  Tensor* stats) {
+    const bool has_res = residual.defined();
+    if (has_res) TORCH_CHECK(nhwc_bf16(residual) && residual.sizes() == x.sizes(), "FusedBatchNormAct: residual layout");
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    TORCH_CHECK(b.weight.numel() == C, "FusedBatchNormAct: channel count mismatch");
+    int* fl = b.flags.data_ptr<int>();
+    Tensor sums_ws = b.sums_ws;
+    if (training) {
+        if (fl[0]) sums_ws.zero_();
+        fl[0] = 1;
+        fl[1] = 0;
+    }
+    Tensor y = at::empty_like(x);
+    *stats = at::empty({4 * C}, b.weight.options().dtype(at::kFloat));
+    float* sp = stats->data_ptr<float>();
+    check(epi_bn_act_fwd(x.data_ptr(), has_res ? residual.data_ptr() : nullptr, B * H * W, (int)C, b.weight.data_ptr<float>(),
+                         b.bias.data_ptr<float>(), (float)eps, (float)momentum, training ? 1 : 0, relu ? 1 : 0,
+                         b.running_mean.data_ptr<float>(), b.running_var.data_ptr<float>(),
+                         reinterpret_cast<long long*>(b.num_batches.data_ptr<int64_t>()), sp, sp + C, sp + 2 * C, sums_ws.data_ptr<float>(),
+                         training ? b.bwd_sums.data_ptr<float>() : nullptr, y.data_ptr(), current_stream(x)),
+          "epi_bn_act_fwd");
+    return y;
+}
+
+struct BnGrads { Tensor dx, dres, dgamma, dbeta; };
+
+// dy: gradient of the fused output; x: the raw BatchNorm input saved by the forward; y: saved output (relu && residual) or undefined
+BnGrads bn_backward(Tensor dy, const Tensor& x, const Tensor& y, const Tensor& stats, const Tensor& weight, Tensor sums_ws, Tensor bwd_sums,
+                    Tensor flags, bool relu, bool has_res) {
+    if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+    const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+    int* fl = flags.data_ptr<int>();
+    // bwd_sums was cleared by this layer's forward pass; a second backward without a forward in between gets a fresh accumulator
+    Tensor sums = fl[1] ? at::zeros({2 * C}, stats.options()) : bwd_sums;
+    BnGrads g;
+    g.dx = at::empty_like(x);
+    if (has_res) g.dres = at::empty_like(x);
+    // the parameter gradients leave in their OWN memory: the accumulator is cleared by the next forward, which must not wipe
+    // a gradient that is still waiting for the optimizer (gradient accumulation, a forward between backward and step)
+    Tensor pg = at::empty({2 * C}, stats.options());
+    const float* sp = stats.data_ptr<float>();
+    check(epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, B * H * W, (int)C, weight.data_ptr<float>(), sp,
+                         sp + C, sp + 2 * C, relu ? 1 : 0, sums.data_ptr<float>(), g.dx.data_ptr(), has_res ? g.dres.data_ptr() : nullptr,
+                         sums_ws.data_ptr<float>(), pg.data_ptr<float>(), current_stream(x)),
+          "epi_bn_act_bwd");
+    fl[0] = 0;
+    fl[1] = 1;
+    g.dbeta = pg.slice(0, 0, C);
+    g.dgamma = pg.slice(0, C, 2 * C);
+    return g;
+}
+
 struct BnAct : public torch::autograd::Function<BnAct> {
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor weight, Tensor bias, c10::optional<Tensor> residual_opt, Tensor running_mean,
                           Tensor running_var, Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training,
@@ -38,23 +115,9 @@ struct BnAct : public torch::autograd::Function<BnAct> {
         TORCH_CHECK(nhwc_bf16(x), "FusedBatchNormAct: x must be channels_last bf16");
         const bool has_res = residual_opt.has_value() && residual_opt->defined();
         const Tensor residual = has_res ? *residual_opt : Tensor();
-        if (has_res) TORCH_CHECK(nhwc_bf16(residual) && residual.sizes() == x.sizes(), "FusedBatchNormAct: residual layout");
-        const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
-        int* fl = flags.data_ptr<int>();
-        if (training) {
-            if (fl[0]) sums_ws.zero_();
-            fl[0] = 1;
-            fl[1] = 0;
-        }
-        Tensor y = at::empty_like(x);
-        Tensor stats = at::empty({4 * C}, weight.options().dtype(at::kFloat));
-        float* sp = stats.data_ptr<float>();
-        check(epi_bn_act_fwd(x.data_ptr(), has_res ? residual.data_ptr() : nullptr, B * H * W, (int)C, weight.data_ptr<float>(),
-                             bias.data_ptr<float>(), (float)eps, (float)momentum, training ? 1 : 0, relu ? 1 : 0,
-                             running_mean.data_ptr<float>(), running_var.data_ptr<float>(), reinterpret_cast<long long*>(num_batches.data_ptr<int64_t>()), sp, sp + C,
-                             sp + 2 * C, sums_ws.data_ptr<float>(), training ? bwd_sums.data_ptr<float>() : nullptr, y.data_ptr(),
-                             current_stream(x)),
-              "epi_bn_act_fwd");
+        BnBuffers b{weight, bias, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
+        Tensor stats;
+        Tensor y = bn_forward(x, residual, b, training, momentum, eps, relu, &stats);
         ctx->saved_data["training"] = training;
         if (training) {
             ctx->saved_data["relu"] = relu;
@@ -71,27 +134,10 @@ struct BnAct : public torch::autograd::Function<BnAct> {
         TORCH_CHECK(ctx->saved_data["training"].toBool(),
                     "FusedBatchNormAct: backward through inference-mode statistics is not supported");
         const auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &y = saved[1], &stats = saved[2], &weight = saved[3];
         const bool relu = ctx->saved_data["relu"].toBool(), has_res = ctx->saved_data["has_res"].toBool();
-        Tensor sums_ws = ctx->saved_data["sums_ws"].toTensor(), bwd_sums = ctx->saved_data["bwd_sums"].toTensor();
-        Tensor flags = ctx->saved_data["flags"].toTensor();
-        Tensor dy = grads[0];
-        if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
-        const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
-        int* fl = flags.data_ptr<int>();
-        // bwd_sums was cleared by this layer's forward pass; a second backward without a forward in between must not
-        // touch it again -- the first one's parameter gradients may alias it
-        Tensor sums = fl[1] ? at::zeros({2 * C}, stats.options()) : bwd_sums;
-        Tensor dx = at::empty_like(x);
-        Tensor dres = has_res ? at::empty_like(x) : Tensor();
-        const float* sp = stats.data_ptr<float>();
-        check(epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, B * H * W, (int)C, weight.data_ptr<float>(),
-                             sp, sp + C, sp + 2 * C, relu ? 1 : 0, sums.data_ptr<float>(), dx.data_ptr(),
-                             has_res ? dres.data_ptr() : nullptr, sums_ws.data_ptr<float>(), current_stream(x)),
-              "epi_bn_act_bwd");
-        fl[0] = 0;
-        fl[1] = 1;
-        return {dx, sums.slice(0, C, 2 * C), sums.slice(0, 0, C), dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+        BnGrads g = bn_backward(grads[0], saved[0], saved[1], saved[2], saved[3], ctx->saved_data["sums_ws"].toTensor(),
+                                ctx->saved_data["bwd_sums"].toTensor(), ctx->saved_data["flags"].toTensor(), relu, has_res);
+        return {g.dx, g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
@@ -102,10 +148,157 @@ Tensor bn_act(Tensor x, Tensor weight, Tensor bias, c10::optional<Tensor> residu
                         bwd_sums, flags, training, momentum, eps, relu);
 }
 
+// ---- Conv2d -> BatchNorm (+ residual) (+ ReLU) as ONE autograd node ------------------------------------------------
+// w: [Cout, Cin, k, k], bf16 training copy (gradient returned in bf16, channels_last order) or the fp32 master (converted per
+// call, gradient returned in fp32); w_bwd: the packed backward-data operand kept up to date by the optimizer
+// (epi_conv2d_pack_weight_bwd_multi after every step), or None -> packed here.
+inline Tensor channels_last_bf16_weight(const Tensor& w) {
+    Tensor w16 = w.scalar_type() == at::kBFloat16 ? w : w.to(at::kBFloat16);
+    if (w16.is_contiguous(at::MemoryFormat::ChannelsLast)) return w16;
+    if (w16.size(2) == 1 && w16.size(3) == 1 && w16.is_contiguous()) return w16;          // 1x1: the same memory either way
+    return w16.contiguous(at::MemoryFormat::ChannelsLast);
+}
+
+struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, c10::optional<Tensor> w_bwd_opt, int64_t stride, int64_t pad, Tensor gamma,
+                          Tensor beta, c10::optional<Tensor> residual_opt, Tensor running_mean, Tensor running_var, Tensor num_batches,
+                          Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
+        TORCH_CHECK(x.is_cuda() && w.is_cuda(), "conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
+        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        TORCH_CHECK(w.dim() == 4 && w.size(1) == x.size(1) && w.size(2) == w.size(3), "conv_bn_act: weight shape");
+        const bool has_res = residual_opt.has_value() && residual_opt->defined();
+        const Tensor residual = has_res ? *residual_opt : Tensor();
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
+        const int Cout = (int)w.size(0), K = (int)w.size(2), S = (int)stride, P = (int)pad;
+        const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+        const Tensor w16 = channels_last_bf16_weight(w.detach());
+        Tensor raw = at::empty({B, Cout, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+        Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
+        check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P, ws.data_ptr(), (size_t)ws.numel(),
+                             current_stream(x)),
+              "epi_conv2d_fwd");
+        BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
+        Tensor stats;
+        Tensor y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats);
+        ctx->saved_data["training"] = training;
+        if (training) {
+            Tensor wb;
+            if (x.requires_grad()) {                       // backward-data operand: the optimizer's packed copy, or packed now
+                if (w_bwd_opt.has_value() && w_bwd_opt->defined()) {
+                    wb = *w_bwd_opt;
+                    TORCH_CHECK(wb.numel() == w.numel() && wb.scalar_type() == at::kBFloat16, "conv_bn_act: packed weight mismatch");
+                } else {
+                    wb = at::empty({w.numel()}, w16.options().memory_format(at::MemoryFormat::Contiguous));
+                    check(epi_conv2d_pack_weight_bwd(w16.data_ptr(), Cout, Cin, K, K, S, P, wb.data_ptr(), current_stream(x)),
+                          "epi_conv2d_pack_weight_bwd");
+                }
+            }
+            ctx->saved_data["relu"] = relu;
+            ctx->saved_data["has_res"] = has_res;
+            ctx->saved_data["sums_ws"] = sums_ws;
+            ctx->saved_data["bwd_sums"] = bwd_sums;
+            ctx->saved_data["flags"] = flags;
+            ctx->saved_data["geom"] = std::vector<int64_t>{K, S, P};
+            ctx->saved_data["w_f32"] = w.scalar_type() != at::kBFloat16;
+            ctx->saved_data["w_sizes"] = w.sizes().vec();
+            ctx->saved_data["w_strides"] = (w.is_contiguous(at::MemoryFormat::ChannelsLast) || (K == 1 && w.is_contiguous())) ? w.strides().vec()
+                                                                                                                             : w16.strides().vec();
+            // wb is not a differentiable input and is rewritten in place by the optimizer: keep it out of the version-checked list
+            if (wb.defined()) ctx->saved_data["w_bwd"] = wb;
+            ctx->save_for_backward({x, raw, (relu && has_res) ? y : Tensor(), stats, gamma});
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        TORCH_CHECK(ctx->saved_data["training"].toBool(), "conv_bn_act: backward through inference-mode statistics is not supported");
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &x = saved[0], &raw = saved[1], &y = saved[2], &stats = saved[3], &gamma = saved[4];
+        const bool relu = ctx->saved_data["relu"].toBool(), has_res = ctx->saved_data["has_res"].toBool();
+        BnGrads g = bn_backward(grads[0], raw, y, stats, gamma, ctx->saved_data["sums_ws"].toTensor(), ctx->saved_data["bwd_sums"].toTensor(),
+                                ctx->saved_data["flags"].toTensor(), relu, has_res);
+        const auto geom = ctx->saved_data["geom"].toIntVector();
+        const int K = (int)geom[0], S = (int)geom[1], P = (int)geom[2];
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)raw.size(1);
+        const int Ho = (int)raw.size(2), Wo = (int)raw.size(3);
+        Tensor dx, dw;
+        if (ctx->needs_input_grad(0)) {
+            TORCH_CHECK(ctx->saved_data.count("w_bwd"), "conv_bn_act: input gradient requested but no backward-data weight was prepared");
+            const Tensor wb = ctx->saved_data["w_bwd"].toTensor();
+            dx = at::empty_like(x);
+            Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
+            check(epi_conv2d_bwd_data(g.dx.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P, ws.data_ptr(),
+                                      (size_t)ws.numel(), current_stream(x)),
+                  "epi_conv2d_bwd_data");
+        }
+        if (ctx->needs_input_grad(1)) {
+            const bool f32 = ctx->saved_data["w_f32"].toBool();
+            dw = at::empty_strided(ctx->saved_data["w_sizes"].toIntVector(), ctx->saved_data["w_strides"].toIntVector(),
+                                   x.options().dtype(f32 ? at::kFloat : at::kBFloat16));
+            Tensor& ws = workspace(epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K), x);
+            check(epi_conv2d_bwd_weight(x.data_ptr(), g.dx.data_ptr(), dw.data_ptr(), f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, K, K, S, P,
+                                        ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
+                  "epi_conv2d_bwd_weight");
+        }
+        return {dx, dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor conv_bn_act(Tensor x, Tensor w, c10::optional<Tensor> w_bwd, int64_t stride, int64_t pad, Tensor gamma, Tensor beta,
+                   c10::optional<Tensor> residual, Tensor running_mean, Tensor running_var, Tensor num_batches, Tensor sums_ws, Tensor bwd_sums,
+                   Tensor flags, bool training, double momentum, double eps, bool relu) {
+    return ConvBnAct::apply(x, w, w_bwd, stride, pad, gamma, beta, residual, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags,
+                            training, momentum, eps, relu);
+}
+
+// ---- FusedAdam's per-step pointer table ----------------------------------------------------------------------------
+// Row layout (int64 slots): p, g, m, v, shadow, n, flags (bit 0: gradient is bf16).  For every parameter: take the gradient of its
+// bf16 training copy (when it has one) or its own, check dtype and memory order against the parameter (same strides on every
+// dimension of extent > 1; otherwise the gradient is re-laid-out into a temporary returned to the caller, who keeps it alive until
+// the Adam kernel has been enqueued), and write parameter / shadow / gradient addresses into the pinned host table.  Returns
+// (changed, temporaries): `changed` tells the caller to upload the table again.
+std::tuple<bool, std::vector<Tensor>> adam_prepare(const std::vector<Tensor>& params, const std::vector<c10::optional<Tensor>>& copies,
+                                                  Tensor table_host, int64_t row) {
+    TORCH_CHECK(params.size() == copies.size() && table_host.scalar_type() == at::kLong && table_host.numel() >= (int64_t)params.size() * row,
+                "adam_prepare: table size");
+    int64_t* t = table_host.data_ptr<int64_t>();
+    bool changed = false;
+    std::vector<Tensor> keep;
+    for (size_t i = 0; i < params.size(); ++i) {
+        const Tensor& p = params[i];
+        const bool has_copy = copies[i].has_value() && copies[i]->defined();
+        Tensor g = has_copy ? copies[i]->grad() : p.grad();
+        TORCH_CHECK(g.defined(), "FusedAdam: parameter ", i, " received no gradient (partial updates are not supported)");
+        TORCH_CHECK(g.scalar_type() == at::kFloat || g.scalar_type() == at::kBFloat16, "FusedAdam: gradient dtype not supported");
+        bool same = g.sizes() == p.sizes();
+        if (same)
+            for (int64_t d = 0; d < p.dim(); ++d)
+                if (p.size(d) > 1 && g.stride(d) != p.stride(d)) { same = false; break; }
+        if (!same) {                                   // e.g. an NCHW-strided gradient for a channels_last weight
+            Tensor g2 = at::empty_strided(p.sizes(), p.strides(), g.options());
+            g2.copy_(g);
+            keep.push_back(g2);
+            g = g2;
+        }
+        const int64_t gp = reinterpret_cast<int64_t>(g.data_ptr()), pp = reinterpret_cast<int64_t>(p.data_ptr());
+        const int64_t sh = has_copy ? reinterpret_cast<int64_t>(copies[i]->data_ptr()) : 0;
+        const int64_t fl = g.scalar_type() == at::kBFloat16 ? 1 : 0;
+        int64_t* r = t + (int64_t)i * row;
+        if (r[0] != pp || r[1] != gp || r[4] != sh || r[6] != fl) {
+            r[0] = pp; r[1] = gp; r[4] = sh; r[6] = fl;
+            changed = true;
+        }
+    }
+    return std::make_tuple(changed, keep);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "torch-autograd glue over the libepipolar_hip C ABI (no compute of its own)";
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
+    m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
+    m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");
     m.def("abi_version", []() { return epi_version(); });
 }

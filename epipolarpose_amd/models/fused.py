@@ -61,6 +61,45 @@ class FusedBatchNormAct(nn.Module):
         return "{num_features}, eps={eps}, momentum={momentum}, relu={relu}".format(**self.__dict__)
 
 
+def conv_is_fusable(conv):
+    """Can this convolution run on the hand-written implicit-GEMM kernels (epi_conv2d_*)?  Bias-free nn.Conv2d, groups 1,
+    dilation 1, square kernel 1 or 3 with the matching padding, stride 1 or 2, channel counts the kernels tile (multiples of 64;
+    see include/epipolar_hip.h).  The 7x7 stem on 3 input channels is not: it stays with the library."""
+    if type(conv) is not nn.Conv2d or conv.bias is not None or conv.groups != 1 or conv.dilation != (1, 1):
+        return False
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    if k[0] != k[1] or k[0] not in (1, 3) or s[0] != s[1] or s[0] not in (1, 2) or p != (k[0] // 2, k[0] // 2):
+        return False
+    return conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+
+
+class FusedConvBn:
+    """conv -> BatchNorm (+ residual) (+ ReLU) of one residual-unit stage as ONE autograd node (``conv_bn_act`` of the C++
+    glue): forward = implicit-GEMM convolution + BatchNorm statistics + apply, backward = BatchNorm reduce + apply +
+    convolution backward-data + backward-weight, all enqueued from C++.  Holds no parameters: it reads them from the
+    ``nn.Conv2d`` / ``FusedBatchNormAct`` modules it was built from (which keep the reference's ``state_dict`` names).
+
+    Weight operands: the forward reads the bf16 training copy an optimizer installed (``conv.weight_lp``, optim.FusedAdam) or
+    converts the fp32 master per call; the backward-data operand (transposed / phase-ordered weight) is ``conv.weight_bwd``
+    when the optimizer maintains it (one multi-layer pack launch per step), else it is packed per call inside the node."""
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn = conv, bn
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        conv.epi_geometry = (conv.kernel_size[0], self.stride, self.pad)      # optimizers look for this to maintain weight_bwd
+
+    def __call__(self, x, residual=None):
+        conv, bn = self.conv, self.bn
+        if getattr(conv, "weight_lp", None) is not None:
+            w = sync_training_copy(conv)
+            wb = getattr(conv, "weight_bwd", None)
+        else:
+            w, wb = conv.weight, None
+        g, b, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
+        return hip.glue().conv_bn_act(x, w, wb, self.stride, self.pad, g, b, residual, rm, rv, nbt, sums_ws, bwd_sums, bn._flags,
+                                      bn.training, bn.momentum, bn.eps, bn.relu)
+
+
 class PointwiseConv(nn.Module):
     """Bias-free 1x1 stride-1 convolution of an NHWC tensor as a plain library GEMM (hipBLASLt through ``F.linear`` on the
     zero-copy [B*H*W, Cin] view); weight [Cout, Cin, 1, 1] keeps the ``nn.Conv2d`` name and shape (bottleneck conv1 / conv3,

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, PointwiseConv
+from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, FusedConvBn, PointwiseConv, conv_is_fusable
 
 BN_MOMENTUM = 0.1
 # Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1).  Measured round 1 at B=32 (ms/step, whole training step):
@@ -26,6 +26,10 @@ BN_MOMENTUM = 0.1
 #   "blaslt" (plain hipBLASLt GEMM on the NHWC view, F.linear)    13.4
 #   "mfma"   (the hand-written head GEMM + TN weight gradient)    14.4   (per-call host cost + weight transposes)
 POINTWISE_BACKEND = os.environ.get("EPI_1X1", "miopen")
+# Backend of the residual units' convolutions (EPI_CONV): "hip" (default) = the hand-written implicit-GEMM kernels, every
+# conv -> BatchNorm (+ residual) (+ ReLU) stage one C++ autograd node (models/fused.py:FusedConvBn); "miopen" = nn.Conv2d through
+# MIOpen followed by the fused BatchNorm module (the round-1 path, kept for A/B measurements).
+CONV_BACKEND = os.environ.get("EPI_CONV", "hip")
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -63,7 +67,25 @@ class ResidualUnit(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, cin, kernel_size=1, stride=stride, bias=False),
                                             FusedBatchNormAct(cin, momentum=BN_MOMENTUM, relu=False))
 
+        self._fused = self._build_fused()
+
+    def _build_fused(self):
+        """One FusedConvBn per conv/bn pair when every convolution of the unit qualifies (else the module-by-module path)."""
+        pairs = [(getattr(self, "conv%d" % i), getattr(self, "bn%d" % i)) for i in range(1, self.n_conv + 1)]
+        if self.downsample is not None:
+            pairs.append((self.downsample[0], self.downsample[1]))
+        if CONV_BACKEND != "hip" or not all(conv_is_fusable(c) for c, _ in pairs):
+            return ()
+        return tuple(FusedConvBn(c, b) for c, b in pairs)
+
     def forward(self, x):
+        fused = self._fused
+        if fused and x.is_cuda:
+            out = x
+            for i in range(self.n_conv - 1):
+                out = fused[i](out)                                                      # conv -> BN -> ReLU: one node
+            shortcut = x if self.downsample is None else fused[self.n_conv](x)
+            return fused[self.n_conv - 1](out, shortcut)                                 # conv -> BN -> (+ shortcut) -> ReLU
         out = x
         for i in range(1, self.n_conv):
             out = getattr(self, "bn%d" % i)(getattr(self, "conv%d" % i)(out))          # conv -> BN -> ReLU, fused

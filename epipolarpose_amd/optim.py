@@ -27,6 +27,10 @@ def sync_training_copy(module):
     if w._version != module._lp_version:
         with torch.no_grad():
             module.weight_lp.copy_(w)
+            wb = getattr(module, "weight_bwd", None)
+            if wb is not None:                 # the packed backward-data operand follows the copy
+                _, stride, pad = module.epi_geometry
+                hip.conv2d_pack_weight_bwd(module.weight_lp, stride, pad, out=wb)
         module._lp_version = w._version
     return module.weight_lp
 
@@ -87,11 +91,10 @@ class FusedAdam(torch.optim.Optimizer):
             if type(m) is nn.Conv2d:
                 m.forward = types.MethodType(_lp_conv_forward, m)
             self._lp_of[idx] = lp
-        # two pinned staging copies of the table: the host may run a step ahead of the asynchronous upload
-        self._table_hosts = [torch.zeros(len(params) * _ROW, dtype=torch.int64).pin_memory() for _ in range(2)]
-        self._table_events = [None, None]
-        self._table_turn = 0
-        self._table_host = self._table_hosts[0]
+        self._init_packed_weights(lp_modules, dev)
+        # pinned staging copy of the device table (uploaded asynchronously whenever an address changed)
+        self._table_host = torch.zeros(len(params) * _ROW, dtype=torch.int64).pin_memory()
+        self._table_event = None
         self._table_dev = torch.zeros(len(params) * _ROW, dtype=torch.int64, device=dev)
         chunk = hip.load().epi_adam_chunk_elems()
         chunks = []
@@ -104,10 +107,44 @@ class FusedAdam(torch.optim.Optimizer):
             t[_ROW * i + 4] = (self._shadow.data_ptr() + 2 * offs[i]) if i in self._lp_of else 0
             t[_ROW * i + 5] = n
             chunks += [(i, c) for c in range((n + chunk - 1) // chunk)]
-        self._table_hosts[1].copy_(self._table_hosts[0])
         self._chunks_all = chunks
         self._chunks_dev = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
-        self._grad_ptrs = None
+        self._copies = [self._lp_of.get(i) for i in range(len(params))]
+
+    def _init_packed_weights(self, lp_modules, dev):
+        """Backward-data operands (``weight_bwd``: transposed / parity-phase-ordered bf16 weights, include/epipolar_hip.h) of every
+        convolution that runs on the implicit-GEMM kernels (modules carrying ``epi_geometry``, models/fused.py:FusedConvBn): one flat
+        buffer, refreshed by ONE multi-layer pack launch after each Adam step."""
+        lib = hip.load()
+        mods = [m for m in lp_modules if getattr(m, "epi_geometry", None) is not None]
+        self._pack_rows, self._pack_tiles, self._pack_table = 0, 0, None
+        if not mods:
+            return
+        import ctypes
+        total = sum(m.weight.numel() for m in mods)
+        self._packed = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        row_bytes = lib.epi_conv2d_pack_row_bytes()
+        host = torch.zeros(len(mods) * row_bytes, dtype=torch.uint8)
+        off, tiles = 0, 0
+        for r, m in enumerate(mods):
+            n = m.weight.numel()
+            wb = self._packed[off:off + n]
+            off += n
+            object.__setattr__(m, "weight_bwd", wb)
+            k, stride, pad = m.epi_geometry
+            cout, cin = m.weight.shape[0], m.weight.shape[1]
+            nt = ctypes.c_longlong(0)
+            hip._check(lib.epi_conv2d_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), wb.data_ptr(), cout, cin, k, k,
+                                                    stride, pad, tiles, ctypes.byref(nt)), "epi_conv2d_pack_fill_row")
+            tiles += nt.value
+        self._pack_table = host.to(dev)
+        self._pack_rows, self._pack_tiles = len(mods), tiles
+        self._pack_weights()
+
+    def _pack_weights(self):
+        if self._pack_rows:
+            hip._check(hip.load().epi_conv2d_pack_weight_bwd_multi(self._pack_table.data_ptr(), self._pack_rows, self._pack_tiles,
+                                                                   hip._stream()), "epi_conv2d_pack_weight_bwd_multi")
 
     def refresh_training_copies(self):
         """Re-copy every fp32 master into its bf16 training copy (after the masters were loaded / broadcast)."""
@@ -115,6 +152,7 @@ class FusedAdam(torch.optim.Optimizer):
             for m in self._lp_modules:
                 m.weight_lp.copy_(m.weight)
                 m._lp_version = m.weight._version
+        self._pack_weights()
 
     def _state_view(self, flat, i):
         """Slice of a flat moment buffer with parameter i's shape and strides."""
@@ -139,38 +177,22 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        keep, ptrs = [], []
-        for i, p in enumerate(self._params):
-            g = self._lp_of[i].grad if i in self._lp_of else p.grad
-            if g is None:
-                raise RuntimeError("FusedAdam: parameter %d received no gradient (partial updates are not supported)" % i)
-            if g.shape != p.shape or not _same_layout(g, p):            # e.g. NCHW-strided grad for an NHWC weight
-                g2 = torch.empty_strided(p.shape, p.stride(), dtype=g.dtype, device=g.device)
-                g2.copy_(g)
-                keep.append(g2)
-                g = g2
-            if g.dtype not in (torch.float32, torch.bfloat16):
-                raise TypeError("FusedAdam: gradient dtype %s not supported" % g.dtype)
-            ptrs.append((g.data_ptr(), 1 if g.dtype == torch.bfloat16 else 0))
-        if ptrs != self._grad_ptrs:                 # gradient addresses are stable once the allocator has warmed up
-            k = self._table_turn
-            self._table_turn ^= 1
-            if self._table_events[k] is not None:
-                self._table_events[k].synchronize()         # upload issued two refreshes ago: long finished
-            t = self._table_hosts[k].numpy()
-            for i, (ptr, flag) in enumerate(ptrs):
-                t[_ROW * i + 1] = ptr
-                t[_ROW * i + 6] = flag
-            self._table_dev.copy_(self._table_hosts[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._table_events[k] = ev
-            self._grad_ptrs = ptrs
+        # gradient / parameter / shadow addresses -> the pinned host table, in C++ (no Python loop over ~170 parameters); the
+        # addresses are stable once the allocator has warmed up, so the upload below is rare
+        if self._table_event is not None:
+            self._table_event.synchronize()              # the previous upload (a whole step ago) must have left the staging buffer
+            self._table_event = None
+        changed, keep = hip.glue().adam_prepare(self._params, self._copies, self._table_host, _ROW)
+        if changed:
+            self._table_dev.copy_(self._table_host, non_blocking=True)
+            self._table_event = torch.cuda.Event()
+            self._table_event.record()
         group = self.param_groups[0]
         self._step += 1
         hip.adam_step(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
                       group["eps"], self._step)
         del keep
+        self._pack_weights()                         # backward-data operands of the implicit-GEMM convolutions follow the update
         return loss
 
     def state_dict(self):

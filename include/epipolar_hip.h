@@ -204,6 +204,9 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
  *   = gradient of the residual input;  y = saved forward output, required when relu && dres;
  *   fwd_sums_clear [2C] f32 or NULL: zeroed (the forward accumulator above).
+ *   param_grads [2C] f32 or NULL: a COPY of (dbeta | dgamma) in caller-owned memory outside the accumulator protocol -- hand
+ *   THIS to the optimizer / autograd, never dbeta_dgamma itself: the layer's next forward clears that accumulator, which would
+ *   wipe a gradient that is still waiting (gradient accumulation, a forward between backward and optimizer.step).
  * ------------------------------------------------------------------------------------------------ */
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
@@ -211,7 +214,7 @@ int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, cons
                    float* bwd_sums, void* y, epi_stream_t stream);
 int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma,
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
-                   float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, epi_stream_t stream);
+                   float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, float* param_grads, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions on the matrix cores -- replace the cuDNN/MIOpen calls behind every bias-free nn.Conv2d of
@@ -232,6 +235,13 @@ int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, i
                    int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
                                epi_stream_t stream);
+/* The same for MANY layers in one launch (every backbone weight after an optimizer step).  The caller keeps a table of
+ * epi_conv2d_pack_row_bytes()-sized rows: fill each row ONCE on the host with epi_conv2d_pack_fill_row (tile_begin = the sum of
+ * the *ntiles of the rows before it), copy the table to the device, then launch with the total tile count. */
+size_t epi_conv2d_pack_row_bytes(void);
+int epi_conv2d_pack_fill_row(void* row_host, const void* w, void* w_bwd, int Cout, int Cin, int KH, int KW, int stride, int pad,
+                             long long tile_begin, long long* ntiles);
+int epi_conv2d_pack_weight_bwd_multi(const void* rows, int nrows, long long total_tiles, epi_stream_t stream);
 int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 

@@ -10,8 +10,11 @@ def _rng(key, seed):
     return np.random.default_rng([zlib.crc32(key.encode()), seed])
 
 
-def fill_state_dict(shapes, seed=0):
-    """shapes: ordered {key: shape}.  Returns {key: torch tensor} (fp32; int64 for num_batches_tracked)."""
+def fill_state_dict(shapes, seed=0, head_std=None):
+    """shapes: ordered {key: shape}.  Returns {key: torch tensor} (fp32; int64 for num_batches_tracked).
+    ``head_std``: standard deviation of the deconvolution / final-layer weights (the reference initialises them with
+    N(0, 0.001), pose3d_resnet.py:222-239); None = He scaling like the backbone (logits of several hundred: a practically
+    one-hot soft-argmax, whose gradient no reduced-precision run can reproduce)."""
     out = {}
     for key, shape in shapes.items():
         r = _rng(key, seed)
@@ -31,6 +34,8 @@ def fill_state_dict(shapes, seed=0):
             if "deconv" in key:                      # ConvTranspose weight is [Cin, Cout, k, k]
                 fan_in = shape[0] * shape[2] * shape[3] // 4
             std = (2.0 / max(fan_in, 1)) ** 0.5
+            if head_std is not None and ("deconv" in key or key.startswith("final_layer")):
+                std = head_std
             out[key] = torch.from_numpy((std * r.standard_normal(size=shape)).astype(np.float32))
     return out
 

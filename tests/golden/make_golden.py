@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import ref_shims                                   # noqa: E402
 from det_weights import fill_state_dict, seeded_array   # noqa: E402
-from make_golden_cases import DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES   # noqa: E402
+from make_golden_cases import BIG_HEAD_STD, DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES   # noqa: E402
 from epipolarpose_amd.synthetic import SyntheticScenes  # noqa: E402
 
 REF = ref_shims.load_reference()
@@ -273,7 +273,7 @@ def gen_network_big():
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         out[name + "/keys"] = np.array(list(shapes.keys()))
         out[name + "/shapes"] = np.array([str(s) for s in shapes.values()])
-        model.load_state_dict(fill_state_dict(shapes, seed=1))
+        model.load_state_dict(fill_state_dict(shapes, seed=1, head_std=BIG_HEAD_STD))
         x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image)))
         gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2))
         wt = torch.ones(b, 3 * j)

@@ -13,6 +13,7 @@ NETWORK_CASES = [  # name, layers, image, J, D, batch
 # Full-size configurations (BASELINE.json configs 1, 2 and 5): logits are stored as every LOGIT_STRIDE-th element of the flattened
 # NCHW tensor, weight gradients as every max(1, size // 50000)-th element; stored in network_big.npz.
 LOGIT_STRIDE = 997
+BIG_HEAD_STD = 0.001     # head weights of the full-size cases: the reference's own N(0, 0.001) initialisation (pose3d_resnet.py:222-239)
 NETWORK_BIG_CASES = [  # name, layers, image, J, D, batch
     ("cfg1_r18_128", 18, 128, 17, 64, 2),     # configs[0]: ResNet-18, 2-view 128x128, batch 2 (heat-map 32^2, D = 64 != W)
     ("cfg2_r50_256", 50, 256, 17, 64, 4),     # configs[1] shape (the bench configuration) at batch 4

@@ -82,3 +82,122 @@ def test_conv2d_unsupported_geometry_is_refused():
     w = torch.zeros(64, 3, 7, 7, dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
     with pytest.raises(RuntimeError, match="epi_conv2d_fwd"):
         hip.conv2d_fwd(x, w, 2, 3)                            # the 7x7 stem (49 taps, 3 channels) stays with the library
+
+
+def _ref_conv_bn(x, w, gamma, beta, residual, stride, pad, relu, eps=1e-5):
+    """fp32 reference of one conv -> BatchNorm(training) (+ residual) (+ ReLU) stage (pose3d_resnet.py:68-88)."""
+    raw = F.conv2d(x, w, stride=stride, padding=pad).to(torch.bfloat16).float()      # our kernel rounds the conv output to bf16
+    y = F.batch_norm(raw, None, None, gamma, beta, True, 0.1, eps)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("geo", [(64, 64, 3, 1, 16, False), (256, 64, 1, 1, 16, False), (128, 128, 3, 2, 16, False), (64, 256, 1, 1, 16, True),
+                                 (256, 512, 1, 2, 16, False), (512, 512, 3, 1, 4, True)],
+                         ids=lambda g: "%dto%d_k%ds%d_h%d_res%d" % g)
+def test_conv_bn_act_node_vs_torch_fp32(geo):
+    """The fused autograd node (glue conv_bn_act: conv + BatchNorm + residual + ReLU forward, and its whole backward) against
+    torch fp32 autograd of the same composition; fp32-master and bf16-copy weight inputs."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    cin, cout, k, stride, h, with_res = geo
+    pad, b = k // 2, 4
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin + 3 * cout + k)
+    x = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    w32 = (_rand((cout, cin, k, k), gen, scale=(2.0 / (cin * k * k)) ** 0.5).float()).to(dev).contiguous(memory_format=torch.channels_last)
+    ho = (h + 2 * pad - k) // stride + 1
+    res = _rand((b, cout, ho, ho), gen).to(dev).contiguous(memory_format=torch.channels_last) if with_res else None
+    dy = _rand((b, cout, ho, ho), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    bn = FusedBatchNormAct(cout, relu=True).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=gen) * 0.1)
+    # reference
+    xr, wr = x.float().requires_grad_(True), w32.clone().requires_grad_(True)
+    gr, br = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    rr = res.float().requires_grad_(True) if with_res else None
+    yr = _ref_conv_bn(xr, wr, gr, br, rr, stride, pad, True)
+    yr.backward(dy.float())
+    for wdtype in (torch.float32, torch.bfloat16):
+        bn.zero_grad()
+        xo = x.clone().requires_grad_(True)
+        wo = w32.to(wdtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ro = res.clone().requires_grad_(True) if with_res else None
+        bn.train()
+        y = hip.glue().conv_bn_act(xo, wo, None, stride, pad, *bn._tensors()[:2], ro, *bn._tensors()[2:], bn._flags, True, bn.momentum,
+                                   bn.eps, True)
+        assert y.dtype == torch.bfloat16 and y.shape == yr.shape
+        assert (y.float() - yr).abs().max().item() <= 2 ** -6 * max(1.0, yr.abs().max().item())
+        y.backward(dy)
+        assert wo.grad.dtype == wdtype and wo.grad.shape == wo.shape
+        scale = lambda t: t.abs().max().item() + 1e-6
+        assert (xo.grad.float() - xr.grad).abs().max().item() <= 3e-2 * scale(xr.grad)
+        assert (wo.grad.float() - wr.grad).abs().max().item() <= 3e-2 * scale(wr.grad)
+        assert (bn.weight.grad - gr.grad).abs().max().item() <= 3e-2 * scale(gr.grad)
+        assert (bn.bias.grad - br.grad).abs().max().item() <= 3e-2 * scale(br.grad)
+        if with_res:
+            assert (ro.grad.float() - rr.grad).abs().max().item() <= 2e-2 * scale(rr.grad)
+
+
+def test_bn_parameter_gradients_survive_a_forward_and_accumulate():
+    """BatchNorm parameter gradients must not alias the accumulator the next forward clears: with gradient
+    accumulation (two forward/backward rounds before the optimizer step) weight.grad must be g1 + g2."""
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(2)
+    bn = FusedBatchNormAct(64, relu=True).to(dev)
+    xs = [_rand((2, 64, 8, 8), gen).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    dys = [_rand((2, 64, 8, 8), gen).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    singles = []
+    for x, dy in zip(xs, dys):
+        bn.zero_grad()
+        bn(x).backward(dy)
+        singles.append((bn.weight.grad.clone(), bn.bias.grad.clone()))
+    bn.zero_grad()
+    bn(xs[0]).backward(dys[0])
+    g1 = bn.weight.grad.clone()
+    y2 = bn(xs[1])                                   # a forward between backward and step: clears the internal accumulator
+    torch.cuda.synchronize()
+    torch.testing.assert_close(bn.weight.grad, g1)   # ... but not the gradient
+    y2.backward(dys[1])
+    torch.testing.assert_close(bn.weight.grad, singles[0][0] + singles[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn.bias.grad, singles[0][1] + singles[1][1], rtol=1e-5, atol=1e-5)
+
+
+def test_fused_adam_maintains_packed_backward_weights():
+    """FusedAdam keeps every fused convolution's backward-data operand (weight_bwd) equal to a fresh pack of the updated bf16
+    copy, through steps and through an external load_state_dict."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from epipolarpose_amd.optim import FusedAdam
+    from tests_util_cfg import make_cfg
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = get_pose_net(make_cfg(18, 64, 3, 8), is_train=True).to(dev)
+    opt = FusedAdam(model, lr=1e-3)
+    convs = [m for m in model.modules() if getattr(m, "epi_geometry", None) is not None]
+    assert len(convs) == 19 and all(getattr(m, "weight_bwd", None) is not None for m in convs)        # 16 3x3 + 3 downsample 1x1
+
+    def check():
+        for m in convs:
+            k, s, p = m.epi_geometry
+            assert torch.equal(m.weight_lp.detach().float(), m.weight.detach().to(torch.bfloat16).float())
+            assert torch.equal(m.weight_bwd, hip.conv2d_pack_weight_bwd(m.weight_lp.detach(), s, p))
+    check()
+    crit = SmoothL1JointLocationLoss(num_joints=3)
+    x = torch.randn(4, 3, 64, 64, device=dev)
+    gt = torch.rand(4, 9, device=dev) - 0.5
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(x)
+        crit(out, gt, torch.ones_like(gt)).backward()
+        opt.step()
+    check()
+    model.load_state_dict({k: (torch.randn_like(v) * 0.05 if v.dtype.is_floating_point and v.dim() == 4 else v) for k, v in model.state_dict().items()})
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        model(x)                                     # the forward notices the new masters and re-syncs copy + packed operand
+    check()

@@ -151,7 +151,7 @@ def bench_bn():
 
         def bwd():
             rc = lib.epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr() if res else None, R, c, gamma.data_ptr(), sp, sp + 4 * c,
-                                    sp + 8 * c, 1, bsums.data_ptr(), dx.data_ptr(), dres.data_ptr() if res else None, sums.data_ptr(), st)
+                                    sp + 8 * c, 1, bsums.data_ptr(), dx.data_ptr(), dres.data_ptr() if res else None, sums.data_ptr(), None, st)
             assert rc == 0
         tf = tb = 0.0
         n = 20
