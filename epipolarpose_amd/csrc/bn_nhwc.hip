@@ -278,7 +278,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     if ((running_mean == nullptr) != (running_var == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (training) {
+    if (training && training != 2) {             // 2: the producer already accumulated the batch sums into sums_ws
         int rpw = 0;
         dim3 rgrid;
         reduce_blocking(R, C, &rpw, &rgrid);

@@ -24,18 +24,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBK = 64;                            // K (reduction) depth of one staged tile, every kernel
 
-// NT kernel tile configurations: 2 x WN waves, each wave TM x 2 MFMA tiles (32x32).
-//   small: 128 x 128, 4 waves, 64 KiB LDS (2 workgroups / CU)   -- short K, few rows, ragged N
-//   big:   256 x 256, 8 waves, 128 KiB LDS (1 workgroup / CU)   -- twice the MFMA work per staged byte and per DMA
-//          instruction, 1.5x less LDS read traffic per MFMA, coalesced (LDS-transposed) epilogue
-template <int TM_, int WN_> struct GemmCfg {
-    static constexpr int TM = TM_, WN = WN_, NW = 2 * WN_, THREADS = 64 * NW;
-    static constexpr int BM = 2 * TM_ * 32, BN = WN_ * 64;
+// NT kernel tile configurations: WM x WN waves, each wave TM x 2 MFMA tiles (32x32): tile (WM*TM*32) x (WN*64).
+//   small: 128 x 128, 4 waves (2 x 2), 64 KiB LDS (2 workgroups / CU)  -- short K, few rows, ragged N
+//   tall:  256 x  64, 4 waves (4 x 1), 80 KiB LDS (2 workgroups / CU)  -- N <= 64 (the 64-channel layers): no half-empty MFMA tiles
+//   big:   256 x 256, 8 waves (2 x 4), 128 KiB LDS (1 workgroup / CU)  -- twice the MFMA work per staged byte and per DMA
+//          instruction, 1.5x less LDS read traffic per MFMA
+template <int TM_, int WM_, int WN_, int MIN_WAVES_> struct GemmCfg {
+    static constexpr int TM = TM_, WM = WM_, WN = WN_, NW = WM_ * WN_, THREADS = 64 * NW, MIN_WAVES = MIN_WAVES_;
+    static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    static_assert(BM / NW == 32 && BN / NW == 32, "each wave stages 32 rows of either operand");
+    static constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;       // 1 KiB DMA pieces (8 rows x 128 B) per wave and K tile
+    static constexpr bool EARLY = NW == 4;                         // issue the next K tile's DMA at the top of the current one
+    static_assert(AP >= 1 && BP >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "whole pieces per wave");
 };
-typedef GemmCfg<2, 2> CfgSmall;
-typedef GemmCfg<4, 4> CfgBig;
+typedef GemmCfg<2, 2, 2, 2> CfgSmall;
+typedef GemmCfg<2, 4, 1, 2> CfgTall;
+typedef GemmCfg<4, 2, 4, 1> CfgBig;
 
 struct GemmGather {        // maps GEMM row m / K tile to an NHWC source pixel
     int enabled;           // 0: plain A[m*lda + k]
@@ -70,6 +74,8 @@ struct GemmArgs {
     GemmPhases ph;         // enabled: K = the LARGEST phase's extent (split-K planning); ldb is per phase ntap * Cs
     int k_per_split;       // split-K: blockIdx.y handles K range [y*k_per_split, ...) and writes an fp32 slab (plain rows)
     float* slabs;          // [nsplit][nphase][M][N] when gridDim.y > 1
+    float* stats;          // [2N] or null: += per-column (sum, sum of squares) of the bf16 result (unsplit bf16 launches only)
+    int coalesce;          // bf16 result with N % 8 == 0, ldc % 8 == 0: LDS-staged 128-byte row segments
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -96,8 +102,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
 enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
 
 template <bool OUT_F32, typename Cfg, int MODE>
-__global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_kernel(GemmArgs p) {
-    constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM;
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel(GemmArgs p) {
+    constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM, AP = Cfg::AP, BP = Cfg::BP;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
@@ -117,59 +123,93 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
     const int k_total = MODE == A_PHASED ? p.ph.ntap[phase] * p.ga.Cs : p.K;
     const int k_begin = split_id * p.k_per_split;
     const int k_end = min(k_total, k_begin + p.k_per_split);
+    const int* tap_dy = MODE == A_PHASED ? p.ph.dy[phase] : p.ga.dy;
+    const int* tap_dx = MODE == A_PHASED ? p.ph.dx[phase] : p.ga.dx;
 
-    // ---- staging roles (direct-to-LDS): wave w, piece ps fills LDS rows 32*w + 8*ps .. +7 (1 KiB, lane-linear) of the
-    //      A tile and of the B tile; lane l lands at row 32*w + 8*ps + (l >> 3), PHYSICAL chunk l & 7, so it fetches the
-    //      LOGICAL chunk (l & 7) ^ f(row) of that row from global memory (the XOR swizzle is applied on the source side) ----
-    const int srow = wid * 32 + (lane >> 3), schunk_phys = lane & 7;
-    long long a_base[4];
-    int a_iy[4], a_jx[4], s_chunk[4];
-    bool a_ok[4], b_ok[4];
-    const unsigned short* b_row[4];
+    // ---- staging roles (direct-to-LDS): wave w, piece ps fills LDS rows (w*AP + ps)*8 .. +7 of the A tile (1 KiB, lane-linear) and
+    //      rows (w*BP + ps)*8 .. +7 of the B tile; lane l lands at row base + (l >> 3), PHYSICAL chunk l & 7, so it fetches the
+    //      LOGICAL chunk (l & 7) ^ f(row) of that row from global memory (the XOR swizzle is applied on the source side).
+    //      Gather modes: everything about the lane's output pixel is folded ONCE into a pixel index and a bit mask of the filter
+    //      taps that fall inside the image; per K tile only a (scalar) tap offset is added -- no bounds compares, no 64-bit
+    //      multiplies in the loop. ----
+    const int schunk_phys = lane & 7;
+    int a_pix[AP], a_mask[AP], a_chunk[AP], b_chunk[BP];
+    const unsigned short* a_ptr[AP];
+    const unsigned short* b_ptr[BP];
+    bool b_ok[BP];
+    const int ntaps = MODE == A_PLAIN ? 0 : k_total / p.ga.Cs;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int trow = srow + ps * 8;
-        s_chunk[ps] = schunk_phys ^ ((trow >> 1) & 7);
+    for (int ps = 0; ps < AP; ++ps) {
+        const int trow = (wid * AP + ps) * 8 + (lane >> 3);
+        a_chunk[ps] = (schunk_phys ^ ((trow >> 1) & 7)) * 8;
         const int m = m0 + trow;
-        a_ok[ps] = m < p.M;
+        const bool ok = m < p.M;
         if (MODE != A_PLAIN) {
             const int hw = p.ga.Hg * p.ga.Wg;
             const int n = m / hw, rem = m - n * hw;
             const int i = rem / p.ga.Wg, j = rem - i * p.ga.Wg;
-            a_iy[ps] = i * p.ga.stride;
-            a_jx[ps] = j * p.ga.stride;
-            a_base[ps] = (long long)n * p.ga.Hs;
+            const int iy = i * p.ga.stride, jx = j * p.ga.stride;
+            a_pix[ps] = (n * p.ga.Hs + iy) * p.ga.Ws + jx;
+            int mask = 0;
+            for (int t = 0; t < ntaps; ++t) {
+                const int y = iy + tap_dy[t], x = jx + tap_dx[t];
+                if (ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws) mask |= 1 << t;
+            }
+            a_mask[ps] = mask;
+            a_ptr[ps] = p.A + a_chunk[ps];
         } else {
-            a_iy[ps] = a_jx[ps] = 0;
-            a_base[ps] = (long long)m * p.lda + s_chunk[ps] * 8;
+            a_pix[ps] = 0;
+            a_mask[ps] = ok ? 1 : 0;
+            a_ptr[ps] = p.A + (long long)(ok ? m : 0) * p.lda + a_chunk[ps];
         }
+    }
+#pragma unroll
+    for (int ps = 0; ps < BP; ++ps) {
+        const int trow = (wid * BP + ps) * 8 + (lane >> 3);
+        b_chunk[ps] = (schunk_phys ^ ((trow >> 1) & 7)) * 8;
         const int n = n0 + trow;
         b_ok[ps] = n < p.N;
-        b_row[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * ldb + s_chunk[ps] * 8;
+        b_ptr[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * ldb + b_chunk[ps];
     }
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
-    // one piece = 1 KiB of the A tile + 1 KiB of the B tile for K tile k0 (two DMA instructions per wave)
-    auto issue_piece = [&](int ps, int k0, int buf) {
-        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
-        char* b_s = a_s + Cfg::A_BYTES;
-        const int kc = k0 + s_chunk[ps] * 8;
-        const bool kok = kc < k_end;                 // K tail (K % 8 == 0): zero-filled chunks
-        bool ok = a_ok[ps] && kok;
-        long long off;
-        if (MODE != A_PLAIN) {
-            const int tap = k0 / p.ga.Cs, c0 = k0 - tap * p.ga.Cs;
-            const int tdy = MODE == A_PHASED ? p.ph.dy[phase][tap] : p.ga.dy[tap];
-            const int tdx = MODE == A_PHASED ? p.ph.dx[phase][tap] : p.ga.dx[tap];
-            const int y = a_iy[ps] + tdy, x = a_jx[ps] + tdx;
-            ok = ok && (unsigned)y < (unsigned)p.ga.Hs && (unsigned)x < (unsigned)p.ga.Ws;
-            off = ((a_base[ps] + y) * p.ga.Ws + x) * p.ga.Cs + c0 + s_chunk[ps] * 8;
+    // gather state of the NEXT K tile to be issued (wave-uniform): filter tap, channel offset inside the tap, pixel shift
+    int g_tap = MODE == A_PLAIN ? 0 : k_begin / p.ga.Cs;
+    int g_c0 = MODE == A_PLAIN ? 0 : k_begin - g_tap * p.ga.Cs;
+    int g_shift = (MODE == A_PLAIN || ntaps == 0) ? 0 : tap_dy[min(g_tap, ntaps - 1)] * p.ga.Ws + tap_dx[min(g_tap, ntaps - 1)];
+    auto issue_a = [&](int ps, int k0, int buf) {
+        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * (AP * 1024);
+        const void* src;
+        if (MODE != A_PLAIN) {       // K tiles never straddle a tap (Cs % 64 == 0) and K has no tail in the gather modes
+            const unsigned eoff = (unsigned)(a_pix[ps] + g_shift) * (unsigned)p.ga.Cs + (unsigned)g_c0;
+            src = ((a_mask[ps] >> g_tap) & 1) ? reinterpret_cast<const void*>(a_ptr[ps] + eoff) : reinterpret_cast<const void*>(zero_src);
         } else {
-            off = a_base[ps] + k0;
+            const bool ok = a_mask[ps] && (k0 + a_chunk[ps] < k_end);          // K tail (K % 8 == 0): zero-filled chunks
+            src = ok ? reinterpret_cast<const void*>(a_ptr[ps] + k0) : reinterpret_cast<const void*>(zero_src);
         }
-        const void* asrc = ok ? reinterpret_cast<const void*>(p.A + off) : reinterpret_cast<const void*>(zero_src);
-        glds16(asrc, a_s + ps * 1024);
-        const void* bsrc = (b_ok[ps] && kok) ? reinterpret_cast<const void*>(b_row[ps] + k0) : reinterpret_cast<const void*>(zero_src);
-        glds16(bsrc, b_s + ps * 1024);
+        glds16(src, a_s + ps * 1024);
+    };
+    auto issue_b = [&](int ps, int k0, int buf) {
+        char* b_s = smem + buf * Cfg::STAGE_BYTES + Cfg::A_BYTES + __builtin_amdgcn_readfirstlane(wid) * (BP * 1024);
+        const bool ok = b_ok[ps] && (MODE != A_PLAIN || k0 + b_chunk[ps] < k_end);
+        glds16(ok ? reinterpret_cast<const void*>(b_ptr[ps] + k0) : reinterpret_cast<const void*>(zero_src), b_s + ps * 1024);
+    };
+    auto advance_gather = [&]() {    // after all pieces of one K tile were issued
+        if (MODE != A_PLAIN) {
+            g_c0 += GBK;
+            if (g_c0 >= p.ga.Cs) {
+                g_c0 = 0;
+                g_tap += 1;
+                const int t = min(g_tap, ntaps - 1);
+                g_shift = tap_dy[t] * p.ga.Ws + tap_dx[t];
+            }
+        }
+    };
+    auto issue_tile = [&](int k0, int buf) {
+#pragma unroll
+        for (int ps = 0; ps < AP; ++ps) issue_a(ps, k0, buf);
+#pragma unroll
+        for (int ps = 0; ps < BP; ++ps) issue_b(ps, k0, buf);
+        advance_gather();
     };
 
     f32x16 acc[TM][2];
@@ -181,10 +221,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;     // 0: a phase without taps / an empty split (zeros)
-    if (nk > 0) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) issue_piece(ps, k_begin, 0);
-    }
+    if (nk > 0) issue_tile(k_begin, 0);
     __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
     const int frow = lane & 31, fhalf = lane >> 5;
     const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
@@ -198,9 +235,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         for (int t = 0; t < 2; ++t)
             bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + t * 4096)));
     };
-    // One K tile: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency hidden behind
-    // the matrix pipe), and the next tile's DMA pieces are issued one per k step between the MFMA groups, so a workgroup
-    // that owns the whole CU (256^2 configuration) never has all of its waves in a load-only phase.
+    // One K tile: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency hidden behind the
+    // matrix pipe).  The next tile's DMA: 4-wave tiles (two workgroups per CU) issue ALL of it right at the top, so that it has
+    // the whole tile's MFMA time to land before the closing barrier; the 8-wave 256^2 tile (one workgroup owns the CU) spreads
+    // it one A + one B piece per k step between the MFMA groups, so that its waves are never all in a load-only phase.
     auto k_tile = [&](int kt, auto has_next_tag) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int buf = kt & 1;
@@ -208,11 +246,18 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         const char* b_s = a_s + Cfg::A_BYTES;
         bf16x8 af[2][TM], bfr[2][2];
         read_frags(a_s, b_s, 0, af[0], bfr[0]);
+        const int k_next = k_begin + (kt + 1) * GBK;
+        if (Cfg::EARLY && HAS_NEXT) issue_tile(k_next, buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (the scheduler would sink it)
-            if (HAS_NEXT) issue_piece(ks, k_begin + (kt + 1) * GBK, buf ^ 1);
+            if (!Cfg::EARLY && HAS_NEXT) {
+                static_assert(Cfg::EARLY || (AP == 4 && BP == 4), "one A and one B piece per k step");
+                issue_a(ks, k_next, buf ^ 1);
+                issue_b(ks, k_next, buf ^ 1);
+                if (ks == 3) advance_gather();
+            }
             // operands swapped: D[i][j] with i = output column n (register rows), j = output row m (lane & 31),
             // so that a lane ends up holding 4 consecutive columns of one row
 #pragma unroll
@@ -249,13 +294,16 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
         }
         return;
     }
-    if constexpr (!OUT_F32 && Cfg::TM == 4) {
-        // Coalesced epilogue: the wave parks its 128 x 64 bf16 sub-tile in its own 16 KiB of the (now idle) staging LDS
+    if (!OUT_F32 && p.coalesce) {
+        // Coalesced epilogue (bf16 result, N % 8 == 0, 16-byte aligned rows): the wave parks its (TM*32) x 64 bf16 sub-tile in its own slice of the (now idle) staging LDS
         // -- 8-byte units XOR-swizzled by (row & 15) so the 16 rows of a ds_write_b64 lane group hit 16 different bank
         // pairs -- and writes it out as whole 128-byte row segments (8 lanes x 16 B per row, 8 rows per instruction)
         // instead of 8-byte pieces of 32 different rows.  The main loop's final barrier already separated the last
         // fragment reads from these writes; afterwards each wave only touches its own region (LDS ops of a wave are ordered).
-        char* mine = smem + wid * 16384;
+        // When the caller wants BatchNorm statistics (p.stats: the convolution feeds a training-mode BatchNorm), the same
+        // read-back accumulates per-column sum and sum of squares of the bf16-ROUNDED outputs: 8 columns per lane over the
+        // rows it copies, reduced over the 8 row lanes with three shuffles, one fp32 atomic per column and wave.
+        char* mine = smem + wid * (TM * 32 * 128);
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti) {
             const int row = ti * 32 + frow;
@@ -278,13 +326,25 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
                 }
         }
         const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < TM * 4; ++it) {
             const int row = it * 8 + (lane >> 3), sw = row & 15;
             const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
             const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
             const int m = m0 + wm * (TM * 32) + row;
             if (m >= p.M || n >= p.N) continue;
+            if (p.stats) {
+                const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
+                    ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
+                    ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
+                }
+            }
             long long orow = m;
             if (p.sc.enabled) {
                 const int hw = p.sc.Hg * p.sc.Wg;
@@ -294,6 +354,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_ke
             }
             uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
+            }
+            if (lane < 8 && n < p.N) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    atomicAdd(p.stats + n + k, ssum[k]);
+                    atomicAdd(p.stats + p.N + n + k, ssq[k]);
+                }
+            }
         }
         return;
     }
@@ -364,7 +438,10 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
     const int n_tiles = (p.N + AS_BN - 1) / AS_BN;
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
     float* bias_s = reinterpret_cast<float*>(smem + AS_RING * BTILE + AS_WAVES * 4096);
+    float* stats_s = bias_s + n_tiles * AS_BN;                 // [2][n_tiles * 64] per-column (sum | sum of squares) of this workgroup
     for (int n = tid; n < n_tiles * AS_BN; n += AS_THREADS) bias_s[n] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    if (p.stats)
+        for (int n = tid; n < 2 * n_tiles * AS_BN; n += AS_THREADS) stats_s[n] = 0.f;
 
     // ---- B slice DMA (loader waves only): piece q of loader w covers LDS rows (w*PIECES + q)*ROWS_PER_PIECE ..; lane l
     //      lands at row r = base + l / CHUNKS, physical chunk l % CHUNKS, and fetches logical chunk (l % CHUNKS) ^ (r % CHUNKS).
@@ -411,6 +488,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
+        if (p.stats) __builtin_amdgcn_s_barrier();      // pairs with the MFMA waves' barrier before the statistics flush
         return;
     }
     char* stage = smem + AS_RING * BTILE + wid * 4096;
@@ -465,6 +543,9 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
                 *reinterpret_cast<uint2*>(stage + frow * 128 + ((unit ^ (frow & 15)) << 3)) = t;
             }
         const int n = n0 + c8 * 8;
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + (lane >> 3), sw = row & 15;
@@ -474,7 +555,37 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
             if (m < p.M && n < p.N) {
                 uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
                 *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
+                if (p.stats) {      // BatchNorm statistics of the bf16-rounded outputs (see head_gemm_kernel's epilogue)
+                    const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
+                        ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
+                        ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
+                    }
+                }
             }
+        }
+        if (p.stats) {          // reduce over the 8 row lanes, then one LDS atomic per column and wave
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    atomicAdd(stats_s + n + k, ssum[k]);
+                    atomicAdd(stats_s + n_tiles * AS_BN + n + k, ssq[k]);
+                }
+            }
+        }
+    }
+    if (p.stats) {              // every wave's LDS atomics are in: one global atomic per column and workgroup
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int n = tid; n < p.N; n += 64 * AS_WAVES) {
+            atomicAdd(p.stats + n, stats_s[n]);
+            atomicAdd(p.stats + p.N + n, stats_s[n_tiles * AS_BN + n]);
         }
     }
 }
@@ -516,7 +627,8 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
 
 using namespace epi;
 
-struct GemmPlan { bool big; int nsplit, kps; long long tiles; };
+enum { CFG_SMALL = 0, CFG_TALL = 1, CFG_BIG = 2 };
+struct GemmPlan { int cfg; int nsplit, kps; long long tiles; };
 
 // EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
 static int gemm_tile_override() {
@@ -528,15 +640,15 @@ static int gemm_tile_override() {
     return v;
 }
 
-// Split-K factor for one tile configuration: split until every CU has a workgroup (small tile: two), each split
+// Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
 // keeping >= 512 of K.
-static GemmPlan gemm_plan_cfg(bool big, int M, int N, int K, int nphase) {
+static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase) {
     GemmPlan pl;
-    pl.big = big;
-    const int bm = big ? 256 : 128, bn = big ? 256 : 128;
+    pl.cfg = cfg;
+    const int bm = cfg == CFG_SMALL ? 128 : 256, bn = cfg == CFG_BIG ? 256 : (cfg == CFG_TALL ? 64 : 128);
     pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long long wgs = pl.tiles * nphase;
-    const long long enough = big ? 200 : 384, target = big ? 256 : 512;
+    const long long enough = cfg == CFG_BIG ? 200 : 384, target = cfg == CFG_BIG ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
         nsplit = (int)(target / wgs);               // floor: one workgroup over the resident capacity costs a whole extra round
@@ -558,17 +670,19 @@ static GemmPlan gemm_plan_cfg(bool big, int M, int N, int K, int nphase) {
 // Tile configuration.  big (256^2, 1 workgroup / CU) needs 16-byte output row segments, columns that fill 256-wide
 // tiles, and a deep K loop per workgroup: either enough tiles to fill the chip unsplit (K >= 512), or >= 1024 of K
 // left per split (measured on MI355X: below that the 128^2 tile at 2 workgroups / CU hides the pipeline prologue better).
+// tall (256 x 64) serves N <= 64 with enough rows to fill the chip.
 static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32) {
     const int ov = gemm_tile_override();
     const bool can_big = !out_f32 && N % 8 == 0 && ldc % 8 == 0;
     if (can_big && ov != 1) {
-        const GemmPlan pb = gemm_plan_cfg(true, M, N, K, nphase);
+        const GemmPlan pb = gemm_plan_cfg(CFG_BIG, M, N, K, nphase);
         const int tiles_n = (N + 255) / 256;
         const bool fills = M >= 256 && tiles_n * 256 <= N + N / 4;
         const bool deep = pb.nsplit == 1 ? (K >= 512 && pb.tiles * nphase >= 200) : pb.kps >= 1024;
         if (ov == 2 || (fills && deep)) return pb;
     }
-    return gemm_plan_cfg(false, M, N, K, nphase);
+    if (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) return gemm_plan_cfg(CFG_TALL, M, N, K, nphase);
+    return gemm_plan_cfg(CFG_SMALL, M, N, K, nphase);
 }
 
 extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
@@ -604,7 +718,13 @@ static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hi
     return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN>(a, pl, nphase, st);
 }
 
-static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st) {
+// stats_done (may be null): set to 1 when a.stats was accumulated by the GEMM launch itself (unsplit bf16 result), else 0 --
+// the caller then computes the statistics with its own pass
+static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr) {
+    if (stats_done) *stats_done = 0;
+    a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
+    float* const want_stats = a.stats;
+    a.stats = nullptr;
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
@@ -613,9 +733,10 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (!out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
         const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);
+        if (want_stats && !a.bias) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
 #define EPI_ASTAT(KS)                                                                                                      \
         do {                                                                                                               \
-            const size_t lds = AS_RING * (size_t)AS_BN * 32 * KS + AS_WAVES * 4096 + (size_t)((a.N + AS_BN - 1) / AS_BN) * AS_BN * 4;                                              \
+            const size_t lds = AS_RING * (size_t)AS_BN * 32 * KS + AS_WAVES * 4096 + (size_t)((a.N + AS_BN - 1) / AS_BN) * AS_BN * 4 * 3;                                          \
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_astat_kernel<KS>),  \
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             if (attr != hipSuccess) return EPI_ERR_LAUNCH;                                                                 \
@@ -635,9 +756,11 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
         a.slabs = (float*)workspace;
     }
     a.k_per_split = pl.kps;
+    if (want_stats && pl.nsplit == 1 && a.coalesce && !a.bias) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
     int rc;
-    if (pl.big) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
+    if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
+    else if (pl.cfg == CFG_TALL) rc = launch_gemm_cfg<false, CfgTall>(a, pl, nphase, st);
     else rc = launch_gemm_cfg<false, CfgSmall>(a, pl, nphase, st);
     if (rc != EPI_OK) return rc;
     if (pl.nsplit > 1) {
@@ -731,9 +854,12 @@ extern "C" int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout
 // "TN" GEMM for the weight gradients:  C[i][j] = sum_r A[r][i] * B(r)[j]   (reduction over the ROW index of both
 // operands: r enumerates batch*pixels).  Both tiles are row-major [r][cols] images of global memory filled by DMA, and
 // the MFMA operands (8 consecutive r per lane) are produced by the LDS transpose read ds_read_b64_tr_b16
-// (a 16-lane group reads a 4(r) x 16(col) block; lane c receives column c).  B may be an implicit gather
-// (ConvTranspose2d weight gradient: rows of dOut at (2*ih-1+kh, 2*iw-1+kw) for tap blockIdx.z).
-// The reduction is split across blockIdx.y; each split writes its own fp32 slab (reduced by slab_reduce_kernel).
+// (a 16-lane group reads a 4(r) x 16(col) block; lane c receives column c).
+// Convolution weight gradients are ONE such GEMM with the filter taps laid along j:  column j = tap*Cs + c reads the
+// activation pixel shifted by that tap (an implicit gather: every lane of a DMA piece supplies its own source address), so
+// the result [I][ntap*Cs] IS the channels_last weight gradient [Cout][KH][KW][Cin] and the dy tile is staged once for all
+// taps.  The reduction is split across blockIdx.y only as far as needed to give every CU a workgroup; a split writes an fp32
+// slab (summed by slab_reduce_kernel), an unsplit launch writes the result directly.
 // ---------------------------------------------------------------------------------------------------------------
 namespace epi {
 
@@ -741,30 +867,38 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmTnArgs {
     const unsigned short* A;      // [R][lda]
-    const unsigned short* B;      // plain [R][ldb] or gather source [n][Hs][Ws][ldb]
-    float* C;                     // slabs [nsplit][ntap][I][J]
-    int R, I, J, lda, ldb;
-    int rows_per_split;
-    GemmGather gb;                // gather for B (enabled = 0: plain)
+    const unsigned short* B;      // plain [R][ldb], or the gather source [n][Hs][Ws][ldb]
+    void* C;                      // result [I][J] (f32 or bf16) when nsplit == 1, else fp32 slabs [nsplit][I][J]
+    int R, I, J, lda, ldb;        // J = ntap * Cs for a gather
+    int rows_per_split, nsplit;
+    int out_bf16;                 // dtype of the direct (unsplit) result
+    int gather;                   // 0: B row r, column j.  1: rows enumerate (n, ih, iw) over Hg x Wg; column j = tap*Cs + c reads
+    int Hg, Wg, Hs, Ws, Cs;       //    B[n][ih*stride + kh - pad][iw*stride + kw - pad][c],  tap = kh*KW + kw
+    int stride, pad, KW;
 };
 
-// Tile configurations of the TN kernel (64 reduction rows per K tile; both operand tiles are row-major [r][cols] images
-// of global memory, UNPADDED rows of COLS*2 bytes, filled by direct-to-LDS DMA):
-//   small: 128(i) x 128(j), 4 waves (2 x 2, each 64 x 64),  64 KiB LDS, 2 workgroups / CU
-//   big:   256(i) x 256(j), 8 waves (2 x 4, each 128 x 64), 128 KiB LDS, 1 workgroup / CU  (half the operand traffic per flop)
-// Bank conflicts of the transpose reads are avoided by XOR-ing the 16-byte chunk index with 4*(row & 3) -- applied on the
-// SOURCE address of the DMA, like the NT kernel: a 32-lane ds_read_b64_tr_b16 group touches rows r..r+3 at two adjacent
-// 32-byte column blocks, which then fall into four disjoint 64-byte bank windows.
+// Tile configurations (64 reduction rows per K tile; UNPADDED row-major tiles of COLS*2 bytes per row, filled by DMA):
+//   small:  128(i) x 128(j), 4 waves (2 x 2, each 64 x 64),  64 KiB LDS, 2 workgroups / CU
+//   narrow:  64(i) x 128(j), 4 waves (2 x 2, each 32 x 64),  48 KiB LDS, 3 workgroups / CU   (64 output channels: layer1)
+//   big:    256(i) x 256(j), 8 waves (2 x 4, each 128 x 64), 128 KiB LDS, 1 workgroup / CU  (half the operand traffic per flop)
+// Bank conflicts of the transpose reads are avoided by XOR-ing the 16-byte chunk index with a function of the row -- applied on
+// the SOURCE address of the DMA, like the NT kernel: a 32-lane ds_read_b64_tr_b16 group touches rows r..r+3 at two adjacent
+// 32-byte column blocks, which then fall into disjoint 64-byte bank windows.
 template <int TI_, int WJ_> struct TnCfg {
     static constexpr int TI = TI_, WJ = WJ_, NW = 2 * WJ_, THREADS = 64 * NW;
     static constexpr int BI = 2 * TI_ * 32, BJ = WJ_ * 64;
     static constexpr int A_ROWB = BI * 2, B_ROWB = BJ * 2;                      // bytes per tile row
     static constexpr int A_BYTES = GBK * A_ROWB, B_BYTES = GBK * B_ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-    static constexpr int A_PIECES = A_BYTES / 1024 / NW, B_PIECES = B_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave
-    static_assert(A_PIECES == 4 && B_PIECES == 4, "one A and one B piece per k step");
+    static constexpr int A_PIECES = A_BYTES / 1024 / NW, B_PIECES = B_BYTES / 1024 / NW;   // 1 KiB DMA pieces per wave and K tile
+    static constexpr int WG_PER_CU = (2 * STAGE_BYTES <= 49152) ? 3 : (2 * STAGE_BYTES <= 65536 ? 2 : 1);
+    static_assert(A_PIECES >= 1 && B_PIECES >= 1 && A_PIECES <= 4 && B_PIECES <= 4, "pieces per wave");
 };
 typedef TnCfg<2, 2> TnSmall;
+typedef TnCfg<1, 2> TnNarrow;
 typedef TnCfg<4, 4> TnBig;
+
+// chunk swizzle of a tile row: rows that share banks (256-byte bank row) get different 64-byte windows
+template <int ROWB> __device__ __forceinline__ int tn_swz(int row) { return ROWB >= 256 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); }
 
 // MFMA operand (8 consecutive r per lane) by two transpose reads: a 16-lane group reads a 4(r) x 16(col) block, lane c
 // receives column c.  Lane c addresses row row0 + (c >> 2) (and +4), 4 columns at col + 4*(c & 3); col % 32 == 0, row0 % 8 == 0.
@@ -772,69 +906,103 @@ template <int ROWB>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col, int lane_c) {
     const int row = row0 + (lane_c >> 2);
     const int chunk = (col >> 3) + ((lane_c & 3) >> 1);
-    const char* p = tile + row * ROWB + ((chunk ^ (4 * (row & 3))) << 4) + 8 * (lane_c & 1);
+    const char* p = tile + row * ROWB + ((chunk ^ tn_swz<ROWB>(row)) << 4) + 8 * (lane_c & 1);
     struct { s16x4 lo, hi; } v;
     v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROWB));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * ROWB));     // row + 4: same swizzle term
     return __builtin_bit_cast(bf16x8, v);
 }
 
 template <typename Cfg, bool GATHER>
-__global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn_kernel(GemmTnArgs p) {
-    constexpr int TI = Cfg::TI, BI = Cfg::BI, BJ = Cfg::BJ;
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) void head_gemm_tn_kernel(GemmTnArgs p) {
+    constexpr int TI = Cfg::TI, BI = Cfg::BI, BJ = Cfg::BJ, AP = Cfg::A_PIECES, BP = Cfg::B_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / Cfg::WJ, wn = wid % Cfg::WJ;
     const int tiles_j = (p.J + BJ - 1) / BJ;
-    // logical id: tile fastest, then split, then tap: the tiles of one split (same rows r) stay on one XCD
-    const int total_wg = gridDim.x * gridDim.y * gridDim.z;
-    int lid = xcd_remap(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total_wg);
-    const int tile_id = lid % (int)gridDim.x;
-    lid /= (int)gridDim.x;
-    const int split = lid % (int)gridDim.y, tap = lid / (int)gridDim.y;
+    // logical id: tile fastest, then split: the tiles of one split (same rows r) stay on one XCD
+    const int total_wg = gridDim.x * gridDim.y;
+    int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, total_wg);
+    const int tile_id = lid % (int)gridDim.x, split = lid / (int)gridDim.x;
     const int tile_i = tile_id / tiles_j, tile_j = tile_id - tile_i * tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
     const int r_begin = split * p.rows_per_split;
     const int r_end = min(p.R, r_begin + p.rows_per_split);
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
 
-    // ---- DMA roles: piece q (0..3) of wave w covers tile rows (4w + q) * RPP .. + RPP-1 (RPP = 1024 / row bytes); lane l
-    //      lands at row base + l / CH, physical chunk l % CH and fetches logical chunk (l % CH) ^ 4*(row & 3) ----
+    // ---- DMA roles: piece q of wave w covers tile rows (w*PIECES + q) * RPP .. + RPP-1 (RPP = 1024 / row bytes); lane l lands at
+    //      row base + l / CH, physical chunk l % CH and fetches logical chunk (l % CH) ^ swz(row).  Everything that does not change
+    //      from K tile to K tile is computed once: the column (and with it the filter tap and its pixel shift), and the (n, ih, iw)
+    //      of the lane's row, which then ADVANCES by 64 rows per K tile with two conditional carries -- no division in the loop. ----
     constexpr int A_CH = Cfg::A_ROWB / 16, A_RPP = 1024 / Cfg::A_ROWB, B_CH = Cfg::B_ROWB / 16, B_RPP = 1024 / Cfg::B_ROWB;
-    int a_row[4], a_col[4], b_row[4], b_col[4];
+    int a_row[AP], b_row[BP];
+    const unsigned short* a_src[AP];
+    bool a_colok[AP], b_colok[BP];
+    const unsigned short* b_src[BP];          // plain: B + col;  gather: B + channel within the tap
+    int b_n[BP];                              // gather: image index of the lane's row in the current K tile (b_ih / b_iw below: its pixel)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        a_row[q] = (wid * 4 + q) * A_RPP + lane / A_CH;
-        a_col[q] = i0 + (((lane % A_CH) ^ (4 * (a_row[q] & 3))) << 3);
-        b_row[q] = (wid * 4 + q) * B_RPP + lane / B_CH;
-        b_col[q] = j0 + (((lane % B_CH) ^ (4 * (b_row[q] & 3))) << 3);
+    for (int q = 0; q < AP; ++q) {
+        a_row[q] = (wid * AP + q) * A_RPP + lane / A_CH;
+        const int col = i0 + (((lane % A_CH) ^ tn_swz<Cfg::A_ROWB>(a_row[q])) << 3);
+        a_colok[q] = col < p.I;
+        a_src[q] = p.A + (long long)(r_begin + a_row[q]) * p.lda + col;
     }
-    auto issue_piece = [&](int q, int r0, int buf) {
-        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * 4096;
-        char* b_s = a_s + Cfg::A_BYTES;
-        {
-            const int r = r0 + a_row[q];
-            const bool ok = r < r_end && a_col[q] < p.I;
-            const void* src = ok ? reinterpret_cast<const void*>(p.A + (long long)r * p.lda + a_col[q]) : reinterpret_cast<const void*>(zero_src);
-            glds16(src, a_s + q * 1024);
+    // advance of (iw, ih, n) per 64 rows
+    const int adv_w = GATHER ? GBK % p.Wg : 0, adv_h = GATHER ? (GBK / p.Wg) % p.Hg : 0, adv_n = GATHER ? GBK / (p.Wg * p.Hg) : 0;
+    int b_ih[BP], b_iw[BP], b_sy[BP], b_sx[BP];
+#pragma unroll
+    for (int q = 0; q < BP; ++q) {
+        b_row[q] = (wid * BP + q) * B_RPP + lane / B_CH;
+        const int col = j0 + (((lane % B_CH) ^ tn_swz<Cfg::B_ROWB>(b_row[q])) << 3);
+        b_colok[q] = col < p.J;
+        if (GATHER) {
+            const int tap = col / p.Cs, c = col - tap * p.Cs;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            b_sy[q] = kh - p.pad;
+            b_sx[q] = kw - p.pad;
+            const int r = r_begin + b_row[q], hw = p.Hg * p.Wg;
+            b_n[q] = r / hw;
+            const int rem = r - b_n[q] * hw;
+            b_ih[q] = rem / p.Wg;
+            b_iw[q] = rem - b_ih[q] * p.Wg;
+            b_src[q] = p.B + c;
+        } else {
+            b_src[q] = p.B + (long long)(r_begin + b_row[q]) * p.ldb + col;
+            b_n[q] = b_ih[q] = b_iw[q] = b_sy[q] = b_sx[q] = 0;
         }
-        {
-            const int r = r0 + b_row[q];
-            bool ok = r < r_end && b_col[q] < p.J;
-            long long off;
-            if (GATHER) {
-                const int hw = p.gb.Hg * p.gb.Wg;
-                const int n = r / hw, rem = r - n * hw;
-                const int ih = rem / p.gb.Wg, iw = rem - ih * p.gb.Wg;
-                const int y = ih * p.gb.stride + p.gb.dy[tap], x = iw * p.gb.stride + p.gb.dx[tap];
-                ok = ok && (unsigned)y < (unsigned)p.gb.Hs && (unsigned)x < (unsigned)p.gb.Ws;
-                off = (((long long)n * p.gb.Hs + y) * p.gb.Ws + x) * p.ldb + b_col[q];
-            } else {
-                off = (long long)r * p.ldb + b_col[q];
-            }
-            const void* src = ok ? reinterpret_cast<const void*>(p.B + off) : reinterpret_cast<const void*>(zero_src);
-            glds16(src, b_s + q * 1024);
+    }
+    // issue the DMA of one K tile (rows r0 .. r0+63) into buffer buf and step the row state to the next K tile
+    // (pointers stay immutable -- per-tile offsets are wave-uniform scalars -- so that the arrays live in registers, not scratch)
+    auto issue_tile_piece_a = [&](int q, int r0, int buf) {
+        char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * (AP * 1024);
+        const bool ok = a_colok[q] && r0 + a_row[q] < r_end;
+        const unsigned short* src = a_src[q] + (long long)(r0 - r_begin) * p.lda;
+        glds16(ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zero_src), a_s + q * 1024);
+    };
+    auto issue_tile_piece_b = [&](int q, int r0, int buf) {
+        char* b_s = smem + buf * Cfg::STAGE_BYTES + Cfg::A_BYTES + __builtin_amdgcn_readfirstlane(wid) * (BP * 1024);
+        bool ok = b_colok[q] && r0 + b_row[q] < r_end;
+        const unsigned short* src;
+        if (GATHER) {                // 32-bit element offsets (the launcher refuses sources of 2^31 elements or more)
+            const int y = b_ih[q] * p.stride + b_sy[q], x = b_iw[q] * p.stride + b_sx[q];
+            ok = ok && (unsigned)y < (unsigned)p.Hs && (unsigned)x < (unsigned)p.Ws;
+            const unsigned pix = (unsigned)((b_n[q] * p.Hs + y) * p.Ws + x);
+            src = b_src[q] + pix * (unsigned)p.ldb;
+            b_iw[q] += adv_w;
+            if (b_iw[q] >= p.Wg) { b_iw[q] -= p.Wg; b_ih[q] += 1; }
+            b_ih[q] += adv_h;
+            if (b_ih[q] >= p.Hg) { b_ih[q] -= p.Hg; b_n[q] += 1; }
+            b_n[q] += adv_n;
+        } else {
+            src = b_src[q] + (long long)(r0 - r_begin) * p.ldb;
         }
+        glds16(ok ? reinterpret_cast<const void*>(src) : reinterpret_cast<const void*>(zero_src), b_s + q * 1024);
+    };
+    auto issue_tile = [&](int r0, int buf) {
+#pragma unroll
+        for (int q = 0; q < AP; ++q) issue_tile_piece_a(q, r0, buf);
+#pragma unroll
+        for (int q = 0; q < BP; ++q) issue_tile_piece_b(q, r0, buf);
     };
 
     f32x16 acc[TI][2];
@@ -845,11 +1013,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (r_end - r_begin + GBK - 1) / GBK;
-    if (nk > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) issue_piece(q, r_begin, 0);
-    }
+    const int nk = r_end > r_begin ? (r_end - r_begin + GBK - 1) / GBK : 0;
+    if (nk > 0) issue_tile(r_begin, 0);
     __syncthreads();
     const int lane_c = lane & 15, grp = lane >> 4;
     const int cblk = 16 * (grp & 1), khalf = grp >> 1;
@@ -859,8 +1024,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
 #pragma unroll
         for (int t = 0; t < 2; ++t) bfr[t] = tr_frag<Cfg::B_ROWB>(b_s, ks * 16 + 8 * khalf, wn * 64 + t * 32 + cblk, lane_c);
     };
-    // one K tile (64 reduction rows): fragments of k step ks+1 requested before the MFMAs of step ks, the next tile's DMA
-    // pieces issued one per k step between the MFMA groups (same structure as head_gemm_kernel)
+    // one K tile (64 reduction rows): the NEXT tile's DMA is issued first (the whole tile's MFMA time hides its latency; its
+    // buffer was released by the barrier that ended the previous tile), fragments of k step ks+1 are requested before the MFMAs
+    // of step ks
     auto k_tile = [&](int kt, auto has_next_tag) {
         constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
         const int buf = kt & 1;
@@ -868,11 +1034,11 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
         const char* b_s = a_s + Cfg::A_BYTES;
         bf16x8 af[2][TI], bfr[2][2];
         read_frags(a_s, b_s, 0, af[0], bfr[0]);
+        if (HAS_NEXT) issue_tile(r_begin + (kt + 1) * GBK, buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (HAS_NEXT) issue_piece(ks, r_begin + (kt + 1) * GBK, buf ^ 1);
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -884,8 +1050,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
     for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type());
     if (nk > 0) k_tile(nk - 1, std::false_type());
     // D[i][j]: lane holds column j = lane & 31, rows i = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    float* slab = p.C + ((long long)split * gridDim.z + tap) * p.I * p.J;
     const int fcol = lane & 31, fhalf = lane >> 5;
+    const bool direct = p.nsplit == 1;
+    float* slab = reinterpret_cast<float*>(p.C) + (direct ? 0 : (long long)split * p.I * p.J);
+    unsigned short* out16 = reinterpret_cast<unsigned short*>(p.C);
 #pragma unroll
     for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -894,15 +1062,16 @@ __global__ __launch_bounds__(Cfg::THREADS, 512 / Cfg::THREADS) void head_gemm_tn
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int i = i0 + wm * (TI * 32) + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
-                if (i < p.I && j < p.J) slab[(long long)i * p.J + j] = acc[ti][tj][reg];
+                if (i < p.I && j < p.J) {
+                    if (direct && p.out_bf16) out16[(long long)i * p.J + j] = f32_to_bf16(acc[ti][tj][reg]);
+                    else slab[(long long)i * p.J + j] = acc[ti][tj][reg];
+                }
             }
         }
 }
 
-// out[e] = sum over the splits.  tap_inner != 0: the slabs are [tap][I][J], the result is written as [I][tap][J] (the memory
-// order of a channels_last convolution weight [Cout][KH][KW][Cin]); out_bf16: bf16 result (J % 2 == 0, two values per thread)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out, int ntap, int I, int J,
-                                   int tap_inner, int out_bf16) {
+// out[e] = sum over the splits; out_bf16: bf16 result (two values per thread, n even)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out, int out_bf16) {
     const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e >= n) return;
     float s0 = 0.f, s1 = 0.f;
@@ -910,36 +1079,33 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, 
         const float2 v = *reinterpret_cast<const float2*>(slabs + (long long)k * n + e);
         s0 += v.x; s1 += v.y;
     }
-    long long d = e;
-    if (tap_inner) {
-        const int j = (int)(e % J);
-        const long long ti = e / J;
-        const int i = (int)(ti % I), tap = (int)(ti / I);
-        d = ((long long)i * ntap + tap) * J + j;
-    }
-    if (out_bf16) reinterpret_cast<unsigned int*>(out)[d >> 1] = pack_bf16x2(s0, s1);
-    else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + d) = o; }
+    if (out_bf16) reinterpret_cast<unsigned int*>(out)[e >> 1] = pack_bf16x2(s0, s1);
+    else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e) = o; }
 }
 
 }  // namespace epi
 
-struct TnPlan { bool big; long long tiles; int nsplit, rps; };
+struct TnPlan { int cfg; long long tiles; int nsplit, rps; };      // cfg: 0 small, 1 narrow, 2 big
 
-// big (256 x 256, 1 workgroup / CU) when both output dimensions fill 256-wide tiles; the reduction is split until every CU
-// has a workgroup (small tile: four), each split keeping >= 512 (small tile: 1024) rows
-static TnPlan tn_plan(int R, int I, int J, int ntap) {
+// Tile configuration by output shape; the reduction is split only until every CU has about one workgroup (each split costs
+// an fp32 slab of the whole output, written and read back), each split keeping >= 256 rows.
+static TnPlan tn_plan(int R, int I, int J) {
     TnPlan pl;
     auto fills = [](int n) { const int t = (n + 255) / 256; return n >= 192 && t * 256 <= n + n / 4; };
-    pl.big = fills(I) && fills(J) && gemm_tile_override() != 1;
-    if (gemm_tile_override() == 2) pl.big = true;
-    const int b = pl.big ? 256 : 128;
-    pl.tiles = (long long)((I + b - 1) / b) * ((J + b - 1) / b);
-    const long long wgs = pl.tiles * ntap, target = pl.big ? 256 : 1024;
-    int nsplit = (int)(target / wgs);               // floor: never one workgroup more than the CUs can hold at once
-    const int min_rows = pl.big ? 512 : 1024;
-    const int max_split = (R + min_rows - 1) / min_rows;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit < 1) nsplit = 1;
+    const int ov = gemm_tile_override();
+    pl.cfg = (fills(I) && fills(J) && ov != 1) ? 2 : (I <= 64 ? 1 : 0);
+    if (ov == 2) pl.cfg = 2;
+    const int bi = pl.cfg == 2 ? 256 : (pl.cfg == 1 ? 64 : 128), bj = pl.cfg == 2 ? 256 : 128;
+    pl.tiles = (long long)((I + bi - 1) / bi) * ((J + bj - 1) / bj);
+    const long long cap = pl.cfg == 2 ? 256 : (pl.cfg == 1 ? 768 : 512);      // workgroups the chip holds at once
+    int nsplit = 1;
+    if (pl.tiles < 200) {
+        nsplit = (int)((256 + pl.tiles - 1) / pl.tiles);                        // one workgroup per CU ...
+        if ((long long)nsplit * pl.tiles > cap) nsplit = (int)(cap / pl.tiles); // ... never more than fit at once
+        const int max_split = (R + 255) / 256;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+    }
     int rps = (R + nsplit - 1) / nsplit;
     rps = (rps + GBK - 1) / GBK * GBK;
     pl.rps = rps;
@@ -948,42 +1114,50 @@ static TnPlan tn_plan(int R, int I, int J, int ntap) {
 }
 
 template <typename Cfg, bool GATHER>
-static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, int ntap, hipStream_t st) {
+static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, hipStream_t st) {
     const size_t lds = 2 * Cfg::STAGE_BYTES;
     if (lds > 65536) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_tn_kernel<Cfg, GATHER>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((head_gemm_tn_kernel<Cfg, GATHER>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)ntap), dim3(Cfg::THREADS),
-                       lds, st, a);
+    hipLaunchKernelGGL((head_gemm_tn_kernel<Cfg, GATHER>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
-static int launch_tn(GemmTnArgs a, int ntap, void* out, float* slab_ws, size_t slab_bytes, hipStream_t st, int tap_inner = 0,
-                     int out_bf16 = 0) {
-    if (!a.A || !a.B || !out || !slab_ws || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
-    if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8) return EPI_ERR_UNSUPPORTED;
+static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size_t slab_bytes, hipStream_t st) {
+    if (!a.A || !a.B || !out || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8 || (a.gather && a.Cs % 8)) return EPI_ERR_UNSUPPORTED;
+    if (a.gather && (long long)((a.R + a.Hg * a.Wg - 1) / (a.Hg * a.Wg)) * a.Hs * a.Ws * a.ldb >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15u) return EPI_ERR_UNSUPPORTED;
-    const TnPlan pl = tn_plan(a.R, a.I, a.J, ntap);
-    const long long n = (long long)ntap * a.I * a.J;
-    if ((size_t)pl.nsplit * n * sizeof(float) > slab_bytes) return EPI_ERR_WORKSPACE;
+    const TnPlan pl = tn_plan(a.R, a.I, a.J);
+    const long long n = (long long)a.I * a.J;
     a.rows_per_split = pl.rps;
-    a.C = slab_ws;
+    a.nsplit = pl.nsplit;
+    a.out_bf16 = out_bf16;
+    if (pl.nsplit > 1) {
+        if (!slab_ws || (size_t)pl.nsplit * n * sizeof(float) > slab_bytes) return EPI_ERR_WORKSPACE;
+        a.C = slab_ws;
+    } else {
+        a.C = out;
+    }
     int rc;
-    if (pl.big) rc = a.gb.enabled ? launch_tn_cfg<TnBig, true>(a, pl, ntap, st) : launch_tn_cfg<TnBig, false>(a, pl, ntap, st);
-    else rc = a.gb.enabled ? launch_tn_cfg<TnSmall, true>(a, pl, ntap, st) : launch_tn_cfg<TnSmall, false>(a, pl, ntap, st);
+    if (pl.cfg == 2) rc = a.gather ? launch_tn_cfg<TnBig, true>(a, pl, st) : launch_tn_cfg<TnBig, false>(a, pl, st);
+    else if (pl.cfg == 1) rc = a.gather ? launch_tn_cfg<TnNarrow, true>(a, pl, st) : launch_tn_cfg<TnNarrow, false>(a, pl, st);
+    else rc = a.gather ? launch_tn_cfg<TnSmall, true>(a, pl, st) : launch_tn_cfg<TnSmall, false>(a, pl, st);
     if (rc != EPI_OK) return rc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, ntap, a.I, a.J,
-                       tap_inner, out_bf16);
-    EPI_CHECK_LAUNCH();
+    if (pl.nsplit > 1) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, out_bf16);
+        EPI_CHECK_LAUNCH();
+    }
     return EPI_OK;
 }
 
 extern "C" size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap) {
     if (R <= 0 || I <= 0 || J <= 0 || ntap <= 0) return 0;
-    return (size_t)tn_plan(R, I, J, ntap).nsplit * ntap * I * J * sizeof(float);
+    const TnPlan pl = tn_plan(R, I, J * ntap);
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * ntap * I * J * sizeof(float) : 0;
 }
 
 // C[I][J] (f32) = A[R][I]^T * B[R][J]   (weight gradient of the 1x1 convolution: A = dlogits, B = activations)
@@ -991,40 +1165,37 @@ extern "C" int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
                                 size_t workspace_bytes, epi_stream_t stream) {
     GemmTnArgs a = {};
     a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.R = R; a.I = I; a.J = J; a.lda = lda; a.ldb = ldb;
-    return launch_tn(a, 1, C, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_tn(a, C, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// dW_taps[16][Cin][Cout] (f32, tap = kh*4 + kw) of ConvTranspose2d(k4 s2 p1): x [B][H][W][Cin], dy [B][2H][2W][Cout]
+// dw[Cin][16 taps][Cout] (f32, tap = kh*4 + kw) of ConvTranspose2d(k4 s2 p1): x [B][H][W][Cin], dy [B][2H][2W][Cout]
 extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
                                           void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0) return EPI_ERR_INVALID_ARGUMENT;
     GemmTnArgs a = {};
-    a.A = (const unsigned short*)x; a.B = (const unsigned short*)dy; a.R = B * H * W; a.I = Cin; a.J = Cout; a.lda = Cin; a.ldb = Cout;
-    a.gb.enabled = 1; a.gb.Hg = H; a.gb.Wg = W; a.gb.Hs = 2 * H; a.gb.Ws = 2 * W; a.gb.Cs = Cout; a.gb.stride = 2;
-    for (int kh = 0; kh < 4; ++kh)
-        for (int kw = 0; kw < 4; ++kw) { a.gb.dy[4 * kh + kw] = kh - 1; a.gb.dx[4 * kh + kw] = kw - 1; }
-    return launch_tn(a, 16, dw_taps, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    a.A = (const unsigned short*)x; a.B = (const unsigned short*)dy; a.R = B * H * W; a.I = Cin; a.J = 16 * Cout; a.lda = Cin; a.ldb = Cout;
+    // the input pixel (ih, iw) reaches the output pixels (2*ih - 1 + kh, 2*iw - 1 + kw)
+    a.gather = 1; a.Hg = H; a.Wg = W; a.Hs = 2 * H; a.Ws = 2 * W; a.Cs = Cout; a.stride = 2; a.pad = 1; a.KW = 4;
+    return launch_tn(a, dw_taps, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Weight gradient of a Conv2d (groups = 1, dilation = 1), NHWC bf16:  x [B][H][W][Cin], dy [B][Ho][Wo][Cout]  ->
 // dw [Cout][KH][KW][Cin] (the memory order of a channels_last weight; for KH = KW = 1 also the contiguous one), f32 or bf16.
 //   dW[co][kh][kw][ci] = sum over (n, oh, ow) of dy[n][oh][ow][co] * x[n][oh*stride + kh - pad][ow*stride + kw - pad][ci]
-// = KH*KW taps of the TN GEMM with A = dy (plain rows) and B = x gathered per tap.  Replaces MIOpen's split-K wrw kernels
+// = the TN GEMM with A = dy (plain rows) and B = x gathered per tap along the columns.  Replaces MIOpen's split-K wrw kernels
 // and the memset / zero-fill / cast launches around them.  workspace: epi_gemm_tn_workspace_bytes(B*Ho*Wo, Cout, Cin, KH*KW).
 extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
                                      int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return EPI_ERR_INVALID_ARGUMENT;
-    if (KH * KW > 16 || (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16)) return EPI_ERR_UNSUPPORTED;
+    if (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16) return EPI_ERR_UNSUPPORTED;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return EPI_ERR_INVALID_ARGUMENT;
     GemmTnArgs a = {};
-    a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.R = B * Ho * Wo; a.I = Cout; a.J = Cin; a.lda = Cout; a.ldb = Cin;
+    a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.R = B * Ho * Wo; a.I = Cout; a.J = KH * KW * Cin; a.lda = Cout; a.ldb = Cin;
     if (!(KH == 1 && KW == 1 && stride == 1 && pad == 0)) {
-        a.gb.enabled = 1; a.gb.Hg = Ho; a.gb.Wg = Wo; a.gb.Hs = H; a.gb.Ws = W; a.gb.Cs = Cin; a.gb.stride = stride;
-        for (int kh = 0; kh < KH; ++kh)
-            for (int kw = 0; kw < KW; ++kw) { a.gb.dy[kh * KW + kw] = kh - pad; a.gb.dx[kh * KW + kw] = kw - pad; }
+        a.gather = 1; a.Hg = Ho; a.Wg = Wo; a.Hs = H; a.Ws = W; a.Cs = Cin; a.stride = stride; a.pad = pad; a.KW = KW;
     }
-    return launch_tn(a, KH * KW, dw, (float*)workspace, workspace_bytes, (hipStream_t)stream, 1, dw_dtype == EPI_BF16);
+    return launch_tn(a, dw, dw_dtype == EPI_BF16, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1196,7 +1367,9 @@ extern "C" size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int C
 }
 
 extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                              int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+                              int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
+                              epi_stream_t stream) {
+    if (bn_sums_done) *bn_sums_done = 0;
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
@@ -1212,8 +1385,10 @@ extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int 
         a.ga.enabled = 1; a.ga.Hg = Ho; a.ga.Wg = Wo; a.ga.Hs = H; a.ga.Ws = W; a.ga.Cs = Cin; a.ga.stride = stride;
         for (int kh = 0; kh < KH; ++kh)
             for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = kh - pad; a.ga.dx[kh * KW + kw] = kw - pad; }
+        if ((long long)B * H * W * Cin >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;      // 32-bit element offsets in the gather
     }
-    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    a.stats = bn_sums;
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
 }
 
 extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,

@@ -54,15 +54,16 @@ struct BnBuffers {
 };
 
 // x: raw input [B,C,H,W] NHWC bf16.  Returns y; `stats` receives (mean | rstd | scale | shift).
+// sums_ready: the producer already accumulated the batch sums into b.sums_ws (and ran the flag protocol): no statistics pass
 Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, bool training, double momentum, double eps, bool relu,
-                  Tensor* stats) {
+                  Tensor* stats, bool sums_ready = false) {
     const bool has_res = residual.defined();
     if (has_res) TORCH_CHECK(nhwc_bf16(residual) && residual.sizes() == x.sizes(), "FusedBatchNormAct: residual layout");
     const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
     TORCH_CHECK(b.weight.numel() == C, "FusedBatchNormAct: channel count mismatch");
     int* fl = b.flags.data_ptr<int>();
     Tensor sums_ws = b.sums_ws;
-    if (training) {
+    if (training && !sums_ready) {
         if (fl[0]) sums_ws.zero_();
         fl[0] = 1;
         fl[1] = 0;
@@ -71,7 +72,7 @@ Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, b
     *stats = at::empty({4 * C}, b.weight.options().dtype(at::kFloat));
     float* sp = stats->data_ptr<float>();
     check(epi_bn_act_fwd(x.data_ptr(), has_res ? residual.data_ptr() : nullptr, B * H * W, (int)C, b.weight.data_ptr<float>(),
-                         b.bias.data_ptr<float>(), (float)eps, (float)momentum, training ? 1 : 0, relu ? 1 : 0,
+                         b.bias.data_ptr<float>(), (float)eps, (float)momentum, training ? (sums_ready ? 2 : 1) : 0, relu ? 1 : 0,
                          b.running_mean.data_ptr<float>(), b.running_var.data_ptr<float>(),
                          reinterpret_cast<long long*>(b.num_batches.data_ptr<int64_t>()), sp, sp + C, sp + 2 * C, sums_ws.data_ptr<float>(),
                          training ? b.bwd_sums.data_ptr<float>() : nullptr, y.data_ptr(), current_stream(x)),
@@ -174,12 +175,27 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
         const Tensor w16 = channels_last_bf16_weight(w.detach());
         Tensor raw = at::empty({B, Cout, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
         Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
-        check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P, ws.data_ptr(), (size_t)ws.numel(),
+        int sums_done = 0;
+        if (training) {             // the accumulator hand-over of bn_forward, done here because the GEMM epilogue may fill sums_ws
+            int* fl = flags.data_ptr<int>();
+            if (fl[0]) sums_ws.zero_();
+            fl[0] = 1;
+            fl[1] = 0;
+        }
+        check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                             training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(), (size_t)ws.numel(),
                              current_stream(x)),
               "epi_conv2d_fwd");
         BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
         Tensor stats;
-        Tensor y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats);
+        Tensor y;
+        if (training && !sums_done) {       // split-K launch: the statistics pass runs separately; the flags are already set
+            int* fl = flags.data_ptr<int>();
+            fl[0] = 0;
+            y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats, false);
+        } else {
+            y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats, training);
+        }
         ctx->saved_data["training"] = training;
         if (training) {
             Tensor wb;

@@ -48,7 +48,7 @@ _SIGNATURES = {
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_conv2d_workspace_bytes": (_sz, [_i] * 9),
-    "epi_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_conv2d_pack_weight_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "epi_conv2d_pack_row_bytes": (_sz, []),
     "epi_conv2d_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
@@ -562,14 +562,14 @@ def deconv4x4s2_bwd_weight(x, dy):
     x, dy = _nhwc_bf16(x, "x"), _nhwc_bf16(dy, "dy")
     b, cin, h, w = x.shape
     cout = dy.shape[1]
-    taps = torch.empty((16, cin, cout), dtype=torch.float32, device=x.device)
+    taps = torch.empty((cin, 16, cout), dtype=torch.float32, device=x.device)
     ws = _workspace(lib.epi_gemm_tn_workspace_bytes(b * h * w, cin, cout, 16), x.device)
     with _on(x.device):
         ev = timer.start("epi_deconv4x4s2_bwd_weight")
         _check(lib.epi_deconv4x4s2_bwd_weight(_ptr(x), _ptr(dy), _ptr(taps), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
                "epi_deconv4x4s2_bwd_weight")
         timer.stop(ev)
-    return taps.reshape(4, 4, cin, cout).permute(2, 3, 0, 1).contiguous()
+    return taps.reshape(cin, 4, 4, cout).permute(0, 3, 1, 2).contiguous()
 
 
 def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
@@ -600,9 +600,10 @@ def _cl_weight_bf16(weight):
     return w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
 
 
-def conv2d_fwd(x, weight, stride=1, padding=0):
+def conv2d_fwd(x, weight, stride=1, padding=0, bn_sums=None):
     """x [B, Cin, H, W] channels_last bf16, weight [Cout, Cin, KH, KW] (channels_last memory) -> y [B, Cout, Ho, Wo]
-    channels_last bf16.  Reference: the nn.Conv2d calls of pose3d_resnet.py:21-88."""
+    channels_last bf16.  Reference: the nn.Conv2d calls of pose3d_resnet.py:21-88.  ``bn_sums`` (zeroed f32 [2*Cout]): asks for
+    the per-channel (sum, sum of squares) of the result from the GEMM epilogue; returns (y, done) then."""
     lib = load()
     x = _nhwc_bf16(x, "x")
     w = _cl_weight_bf16(weight)
@@ -612,10 +613,11 @@ def conv2d_fwd(x, weight, stride=1, padding=0):
     y = torch.empty((b, cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     ws = _workspace(lib.epi_conv2d_workspace_bytes(b, h, wd, cin, cout, kh, kw, stride, padding), x.device)
     ev = timer.start("epi_conv2d_fwd")
-    _check(lib.epi_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(ws), ws.numel(), _stream()),
-           "epi_conv2d_fwd")
+    done = ctypes.c_int(0)
+    _check(lib.epi_conv2d_fwd(_ptr(x), _ptr(w), _ptr(y), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(bn_sums),
+                              ctypes.addressof(done) if bn_sums is not None else None, _ptr(ws), ws.numel(), _stream()), "epi_conv2d_fwd")
     timer.stop(ev)
-    return y
+    return y if bn_sums is None else (y, bool(done.value))
 
 
 def conv2d_pack_weight_bwd(weight, stride=1, padding=0, out=None):

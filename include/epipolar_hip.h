@@ -198,7 +198,8 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  *                    it again (steady-state training and graph replays then need no memset); a caller that runs a
  *                    training-mode forward without the backward clears it itself before the next forward.
  *   training != 0  : batch statistics, running stats updated with `momentum` (unbiased variance),
- *                    num_batches_tracked += 1;   training == 0: running statistics.
+ *                    num_batches_tracked += 1;   training == 0: running statistics;   training == 2: like 1, but sums_ws
+ *                    ALREADY holds the batch sums (accumulated by the producing convolution, epi_conv2d_fwd) -- no statistics pass.
  *   bwd_sums       : [2C] f32 or NULL: zeroed by the forward so that it can serve as `dbeta_dgamma` of this
  *                    layer's next backward pass without a separate memset
  * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
@@ -231,8 +232,13 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
  * workspace: epi_conv2d_workspace_bytes(...) covers forward and backward-data of one layer.
  * ------------------------------------------------------------------------------------------------ */
 size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+/* bn_sums [2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
+ * the launch can do it (unsplit result), the GEMM epilogue adds the per-channel (sum, sum of squares) of the bf16 outputs and sets
+ * *bn_sums_done = 1 -- pass training = 2 to epi_bn_act_fwd then (its statistics pass is skipped); otherwise *bn_sums_done = 0 and
+ * bn_sums is untouched. */
 int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                   int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+                   int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
+                   epi_stream_t stream);
 int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
                                epi_stream_t stream);
 /* The same for MANY layers in one launch (every backbone weight after an optimizer step).  The caller keeps a table of
@@ -253,9 +259,10 @@ int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype,
                           int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
- * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (ntap = 1 for epi_gemm_tn_bf16, 16 for the deconvolution).
+ * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (J = columns per filter tap; ntap = 1 for epi_gemm_tn_bf16, 16 for the
+ * deconvolution; may be 0: a reduction that needs no split writes its result directly).
  *   epi_gemm_tn_bf16:            C[I][J] = A[R][I]^T * B[R][J]  (final conv: A = dlogits, B = activations -> dW[Cout][Cin])
- *   epi_deconv4x4s2_bwd_weight:  dw_taps[16][Cin][Cout], tap = kh*4+kw, from x [B][H][W][Cin], dy [B][2H][2W][Cout]
+ *   epi_deconv4x4s2_bwd_weight:  dw_taps[Cin][16][Cout], tap = kh*4+kw, from x [B][H][W][Cin], dy [B][2H][2W][Cout]
  *   epi_column_sums_bf16:        sums[2C] += per-column (sum, sum of squares) of x [R][C]  (bias gradient; zero it first) */
 size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap);
 int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J,

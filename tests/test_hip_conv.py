@@ -123,7 +123,7 @@ def test_conv_bn_act_node_vs_torch_fp32(geo):
     for wdtype in (torch.float32, torch.bfloat16):
         bn.zero_grad()
         xo = x.clone().requires_grad_(True)
-        wo = w32.to(wdtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wo = w32.detach().clone().to(wdtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         ro = res.clone().requires_grad_(True) if with_res else None
         bn.train()
         y = hip.glue().conv_bn_act(xo, wo, None, stride, pad, *bn._tensors()[:2], ro, *bn._tensors()[2:], bn._flags, True, bn.momentum,
@@ -201,3 +201,29 @@ def test_fused_adam_maintains_packed_backward_weights():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         model(x)                                     # the forward notices the new masters and re-syncs copy + packed operand
     check()
+
+
+@pytest.mark.parametrize("geo", [(256, 64, 1, 1, 64, 8), (64, 64, 3, 1, 64, 8), (64, 256, 1, 1, 64, 8), (128, 512, 1, 1, 32, 16), (128, 128, 3, 2, 64, 8),
+                                 (512, 512, 3, 1, 8, 32), (256, 256, 3, 1, 16, 32), (64, 64, 1, 1, 16, 2)],
+                         ids=lambda g: "%dto%d_k%ds%d_h%d_b%d" % g)
+def test_conv2d_fwd_fused_bn_statistics(geo):
+    """The BatchNorm batch sums accumulated by the convolution's own epilogue (tall / small / big / A-stationary kernels) equal the
+    column sums of the bf16 tensor it wrote; launches that cannot do it (split-K) say so and leave the accumulator alone."""
+    from epipolarpose_amd import hip
+    cin, cout, k, stride, h, b = geo
+    pad = k // 2
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin + cout + k + h)
+    x = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    w = _rand((cout, cin, k, k), gen, scale=(2.0 / (cin * k * k)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    sums = torch.zeros(2 * cout, dtype=torch.float32, device=dev)
+    y, done = hip.conv2d_fwd(x, w, stride, pad, bn_sums=sums)
+    ref = hip.conv2d_fwd(x, w, stride, pad)
+    assert torch.equal(y, ref)
+    if done:
+        yf = y.float()
+        s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
+        torch.testing.assert_close(sums[:cout], s1, rtol=2e-4, atol=2e-3 * float(yf.abs().max()) * (yf.numel() / cout) ** 0.5)
+        torch.testing.assert_close(sums[cout:], s2, rtol=2e-4, atol=1e-3)
+    else:
+        assert float(sums.abs().max()) == 0.0
