@@ -723,7 +723,11 @@ static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hi
 static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr) {
     if (stats_done) *stats_done = 0;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
-    float* const want_stats = a.stats;
+    // BatchNorm statistics from the GEMM epilogue are OFF by default (EPI_FUSE_BN_STATS=1 enables them): measured on MI355X the
+    // per-channel fp32 atomics of 512 .. 2048 workgroups on the same 64 .. 256 addresses serialise in L2 at ~200 ns each -- the
+    // 64-channel layer-1 convolutions went from 26 us to 230 .. 430 us (profiles/r02_*, DESIGN.md "measured and rejected")
+    static const bool fuse_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS"); return e && e[0] == '1'; }();
+    float* const want_stats = fuse_stats ? a.stats : nullptr;
     a.stats = nullptr;
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
@@ -1070,8 +1074,33 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) 
         }
 }
 
-// out[e] = sum over the splits; out_bf16: bf16 result (two values per thread, n even)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out, int out_bf16) {
+// out[e] = sum over the splits; out_bf16: bf16 result.  256 threads = 32 element pairs x 8 split lanes: every lane sums
+// nsplit / 8 slabs (independent loads in flight), the 8 partial sums meet through shuffles (lanes 8 apart hold the same pair).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out,
+                                                          int out_bf16) {
+    const int pair = threadIdx.x & 7, sl = threadIdx.x >> 3;            // 8 pairs per 64-byte line x 32 split lanes
+    const long long e = ((long long)blockIdx.x * 8 + pair) * 2;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < n) {
+        for (int k = sl; k < nsplit; k += 32) {
+            const float2 v = *reinterpret_cast<const float2*>(slabs + (long long)k * n + e);
+            s0 += v.x; s1 += v.y;
+        }
+    }
+    __shared__ float2 part[32][8];
+    part[sl][pair].x = s0;
+    part[sl][pair].y = s1;
+    __syncthreads();
+    if (sl == 0 && e < n) {
+#pragma unroll 8
+        for (int k = 1; k < 32; ++k) { s0 += part[k][pair].x; s1 += part[k][pair].y; }
+        if (out_bf16) reinterpret_cast<unsigned int*>(out)[e >> 1] = pack_bf16x2(s0, s1);
+        else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e) = o; }
+    }
+}
+
+// few splits: one thread per element pair, every slab read in turn (coalesced 8-byte loads)
+__global__ void slab_reduce_few_kernel(const float* __restrict__ slabs, int nsplit, long long n, void* __restrict__ out, int out_bf16) {
     const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (e >= n) return;
     float s0 = 0.f, s1 = 0.f;
@@ -1087,30 +1116,34 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, 
 
 struct TnPlan { int cfg; long long tiles; int nsplit, rps; };      // cfg: 0 small, 1 narrow, 2 big
 
-// Tile configuration by output shape; the reduction is split only until every CU has about one workgroup (each split costs
-// an fp32 slab of the whole output, written and read back), each split keeping >= 256 rows.
+// Tile configuration and reduction split by a small cost model (microseconds, calibrated on MI355X with tools/bench_conv.py):
+// a workgroup spends ~t_tile per 64-row K tile plus a fixed prologue / epilogue; the chip holds `slots` workgroups at once; every
+// split writes an fp32 slab of the whole result that the reduce kernel reads back (~3 TB/s through L2 / MALL, + one launch).
 static TnPlan tn_plan(int R, int I, int J) {
-    TnPlan pl;
+    struct Cfg { int id, bi, bj, slots; double t_tile, t_fixed; };
+    static const Cfg cfgs[3] = {{0, 128, 128, 512, 1.0, 4.0}, {1, 64, 128, 768, 0.7, 3.0}, {2, 256, 256, 256, 2.0, 8.0}};
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     auto fills = [](int n) { const int t = (n + 255) / 256; return n >= 192 && t * 256 <= n + n / 4; };
     const int ov = gemm_tile_override();
-    pl.cfg = (fills(I) && fills(J) && ov != 1) ? 2 : (I <= 64 ? 1 : 0);
-    if (ov == 2) pl.cfg = 2;
-    const int bi = pl.cfg == 2 ? 256 : (pl.cfg == 1 ? 64 : 128), bj = pl.cfg == 2 ? 256 : 128;
-    pl.tiles = (long long)((I + bi - 1) / bi) * ((J + bj - 1) / bj);
-    const long long cap = pl.cfg == 2 ? 256 : (pl.cfg == 1 ? 768 : 512);      // workgroups the chip holds at once
-    int nsplit = 1;
-    if (pl.tiles < 200) {
-        nsplit = (int)((256 + pl.tiles - 1) / pl.tiles);                        // one workgroup per CU ...
-        if ((long long)nsplit * pl.tiles > cap) nsplit = (int)(cap / pl.tiles); // ... never more than fit at once
-        const int max_split = (R + 255) / 256;
-        if (nsplit > max_split) nsplit = max_split;
-        if (nsplit < 1) nsplit = 1;
+    TnPlan best = {0, 0, 1, 0};
+    double best_t = 1e30;
+    for (const Cfg& c : cfgs) {
+        if (c.id == 1 && I > 64) continue;
+        if (c.id == 0 && I <= 64 && ov == 0) continue;
+        if (c.id == 2 && !((fills(I) && fills(J)) || ov == 2)) continue;
+        if ((ov == 1 && c.id == 2) || (ov == 2 && c.id != 2)) continue;
+        const long long tiles = (long long)((I + c.bi - 1) / c.bi) * ((J + c.bj - 1) / c.bj);
+        for (int ns : cand) {
+            if (ns > 1 && (long long)ns * 128 > R) break;
+            int rps = ((R + ns - 1) / ns + GBK - 1) / GBK * GBK;
+            const int nsplit = (R + rps - 1) / rps;
+            const double rounds = (double)((tiles * nsplit + c.slots - 1) / c.slots);
+            const double t_main = rounds * ((rps / GBK) * c.t_tile + c.t_fixed);
+            const double t_slab = nsplit > 1 ? (double)nsplit * I * J * 8.0 / 3.0e6 + 3.0 : 0.0;
+            if (t_main + t_slab < best_t) { best_t = t_main + t_slab; best = {c.id, tiles, nsplit, rps}; }
+        }
     }
-    int rps = (R + nsplit - 1) / nsplit;
-    rps = (rps + GBK - 1) / GBK * GBK;
-    pl.rps = rps;
-    pl.nsplit = (R + rps - 1) / rps;
-    return pl;
+    return best;
 }
 
 template <typename Cfg, bool GATHER>
@@ -1148,7 +1181,10 @@ static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size
     else rc = a.gather ? launch_tn_cfg<TnSmall, true>(a, pl, st) : launch_tn_cfg<TnSmall, false>(a, pl, st);
     if (rc != EPI_OK) return rc;
     if (pl.nsplit > 1) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, out_bf16);
+        if (pl.nsplit >= 16 && n / 2 < 262144)       // many slabs of a small result: spread the split dimension over the threads
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 7) / 8)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, out_bf16);
+        else
+            hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, out_bf16);
         EPI_CHECK_LAUNCH();
     }
     return EPI_OK;

@@ -13,7 +13,11 @@
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "../../include/epipolar_hip.h"
@@ -34,6 +38,40 @@ inline void check(int status, const char* what) {
 
 inline bool nhwc_bf16(const Tensor& t) {
     return t.scalar_type() == at::kBFloat16 && t.dim() == 4 && t.is_contiguous(at::MemoryFormat::ChannelsLast);
+}
+
+// ---- optional per-entry-point timing with HIP events on the launch stream (bench.py's live roofline figures; off by default) ----
+struct TimingRec { const char* name; double flops, bytes; hipEvent_t a, b; };
+bool g_timing = false;
+std::vector<TimingRec> g_recs;
+struct ScopedTimer {
+    TimingRec r;
+    hipStream_t st;
+    bool on;
+    ScopedTimer(const char* name, double flops, double bytes, epi_stream_t stream) : st((hipStream_t)stream), on(g_timing) {
+        if (!on) return;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess && hipEventRecord(r.a, st) == hipSuccess;
+    }
+    ~ScopedTimer() {
+        if (on && hipEventRecord(r.b, st) == hipSuccess) g_recs.push_back(r);
+    }
+};
+void timing_enable(bool on) { g_timing = on; }
+// {name: (launches, total ms, total algorithmic FLOPs, total algorithmic bytes)}; synchronises; clears the records
+std::map<std::string, std::tuple<int64_t, double, double, double>> timing_collect() {
+    std::map<std::string, std::tuple<int64_t, double, double, double>> out;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& e = out[r.name];
+            std::get<0>(e) += 1; std::get<1>(e) += ms; std::get<2>(e) += r.flops; std::get<3>(e) += r.bytes;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    return out;
 }
 
 // split-K / slab scratch shared by every GEMM-type launch of this process (one process per GPU; launches on one stream are
@@ -71,6 +109,9 @@ Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, b
     Tensor y = at::empty_like(x);
     *stats = at::empty({4 * C}, b.weight.options().dtype(at::kFloat));
     float* sp = stats->data_ptr<float>();
+    const double tbytes = 2.0 * (double)x.numel();
+    ScopedTimer timer(training ? (sums_ready ? "bn_fwd_apply" : "bn_fwd_stats+apply") : "bn_fwd_eval", 0.0,
+                      tbytes * ((training && !sums_ready ? 1 : 0) + 2 + (has_res ? 1 : 0)), current_stream(x));
     check(epi_bn_act_fwd(x.data_ptr(), has_res ? residual.data_ptr() : nullptr, B * H * W, (int)C, b.weight.data_ptr<float>(),
                          b.bias.data_ptr<float>(), (float)eps, (float)momentum, training ? (sums_ready ? 2 : 1) : 0, relu ? 1 : 0,
                          b.running_mean.data_ptr<float>(), b.running_var.data_ptr<float>(),
@@ -97,6 +138,9 @@ BnGrads bn_backward(Tensor dy, const Tensor& x, const Tensor& y, const Tensor& s
     // a gradient that is still waiting for the optimizer (gradient accumulation, a forward between backward and step)
     Tensor pg = at::empty({2 * C}, stats.options());
     const float* sp = stats.data_ptr<float>();
+    const double tbytes = 2.0 * (double)x.numel();
+    const int reads = 2 + (y.defined() ? 1 : 0);
+    ScopedTimer timer("bn_bwd_reduce+apply", 0.0, tbytes * (2 * reads + 1 + (has_res ? 1 : 0)), current_stream(x));
     check(epi_bn_act_bwd(dy.data_ptr(), x.data_ptr(), y.defined() ? y.data_ptr() : nullptr, B * H * W, (int)C, weight.data_ptr<float>(), sp,
                          sp + C, sp + 2 * C, relu ? 1 : 0, sums.data_ptr<float>(), g.dx.data_ptr(), has_res ? g.dres.data_ptr() : nullptr,
                          sums_ws.data_ptr<float>(), pg.data_ptr<float>(), current_stream(x)),
@@ -182,10 +226,15 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
             fl[0] = 1;
             fl[1] = 0;
         }
-        check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
-                             training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(), (size_t)ws.numel(),
-                             current_stream(x)),
-              "epi_conv2d_fwd");
+        const double conv_flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
+        const double conv_bytes = 2.0 * ((double)x.numel() + (double)raw.numel() + (double)w.numel());
+        {
+            ScopedTimer timer("conv_fwd", conv_flops, conv_bytes, current_stream(x));
+            check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                                 training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(),
+                                 (size_t)ws.numel(), current_stream(x)),
+                  "epi_conv2d_fwd");
+        }
         BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
         Tensor stats;
         Tensor y;
@@ -243,6 +292,8 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
             const Tensor wb = ctx->saved_data["w_bwd"].toTensor();
             dx = at::empty_like(x);
             Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
+            ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
+                              2.0 * ((double)x.numel() + (double)raw.numel() + (double)wb.numel()), current_stream(x));
             check(epi_conv2d_bwd_data(g.dx.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P, ws.data_ptr(),
                                       (size_t)ws.numel(), current_stream(x)),
                   "epi_conv2d_bwd_data");
@@ -252,6 +303,8 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
             dw = at::empty_strided(ctx->saved_data["w_sizes"].toIntVector(), ctx->saved_data["w_strides"].toIntVector(),
                                    x.options().dtype(f32 ? at::kFloat : at::kBFloat16));
             Tensor& ws = workspace(epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K), x);
+            ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
+                              2.0 * ((double)x.numel() + (double)raw.numel() + (double)dw.numel()), current_stream(x));
             check(epi_conv2d_bwd_weight(x.data_ptr(), g.dx.data_ptr(), dw.data_ptr(), f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, K, K, S, P,
                                         ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
                   "epi_conv2d_bwd_weight");
@@ -316,5 +369,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");
+    m.def("timing_enable", &timing_enable, "record HIP events around every epi_* launch made by this extension");
+    m.def("timing_collect", &timing_collect, "{name: (launches, total ms, algorithmic FLOPs, algorithmic bytes)}; clears the records");
     m.def("abi_version", []() { return epi_version(); });
 }
