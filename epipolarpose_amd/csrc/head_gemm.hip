@@ -29,17 +29,24 @@ constexpr int GBK = 64;                            // K (reduction) depth of one
 //   tall:  256 x  64, 4 waves (4 x 1), 80 KiB LDS (2 workgroups / CU)  -- N <= 64 (the 64-channel layers): no half-empty MFMA tiles
 //   big:   256 x 256, 8 waves (2 x 4), 128 KiB LDS (1 workgroup / CU)  -- twice the MFMA work per staged byte and per DMA
 //          instruction, 1.5x less LDS read traffic per MFMA
-template <int TM_, int WM_, int WN_, int MIN_WAVES_> struct GemmCfg {
-    static constexpr int TM = TM_, WM = WM_, WN = WN_, NW = WM_ * WN_, THREADS = 64 * NW, MIN_WAVES = MIN_WAVES_;
+template <int TM_, int WM_, int WN_, int MIN_WAVES_, int NSTAGE_> struct GemmCfg {
+    static constexpr int TM = TM_, WM = WM_, WN = WN_, NW = WM_ * WN_, THREADS = 64 * NW, MIN_WAVES = MIN_WAVES_, NSTAGE = NSTAGE_;
     static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;       // 1 KiB DMA pieces (8 rows x 128 B) per wave and K tile
-    static constexpr bool EARLY = NW == 4;                         // issue the next K tile's DMA at the top of the current one
+    static constexpr bool EARLY = NW == 4 && NSTAGE_ == 2;         // 2-stage 4-wave tiles: issue the next K tile's DMA at the top of the current one
     static_assert(AP >= 1 && BP >= 1 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "whole pieces per wave");
+    static_assert(NSTAGE_ >= 2 && NSTAGE_ <= 4, "LDS ring depth");
 };
-typedef GemmCfg<2, 2, 2, 2> CfgSmall;
-typedef GemmCfg<2, 4, 1, 2> CfgTall;
-typedef GemmCfg<4, 2, 4, 1> CfgBig;
+typedef GemmCfg<2, 2, 2, 2, 2> CfgSmall;
+typedef GemmCfg<2, 4, 1, 2, 2> CfgTall;
+typedef GemmCfg<4, 2, 4, 1, 2> CfgBig;
+// Pipelined variants: a ring of 4 (3) LDS stages owned by ONE workgroup per CU; the DMA of K tile kt+3 (kt+2) is issued while tile
+// kt computes and is waited for with a COUNTED vmcnt, so a load has three (two) tile times to land instead of one.  For the
+// convolution GEMMs of this network (a few hundred workgroups, 9 .. 72 K tiles each) the 2-stage loop spends most of every K
+// tile waiting for its DMA at the closing barrier (~1.0-1.4 us per tile against 0.21 us of MFMA work).
+typedef GemmCfg<2, 2, 2, 1, 4> CfgSmallP;
+typedef GemmCfg<2, 4, 1, 1, 3> CfgTallP;
 
 struct GemmGather {        // maps GEMM row m / K tile to an NHWC source pixel
     int enabled;           // 0: plain A[m*lda + k]
@@ -221,8 +228,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;     // 0: a phase without taps / an empty split (zeros)
-    if (nk > 0) issue_tile(k_begin, 0);
-    __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
     const int frow = lane & 31, fhalf = lane >> 5;
     const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
     // fragment address of (row + 32*t, k step ks): rows 32 apart share the swizzle term -> + t*4096; the k step flips
@@ -235,29 +240,28 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         for (int t = 0; t < 2; ++t)
             bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + t * 4096)));
     };
-    // One K tile: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency hidden behind the
-    // matrix pipe).  The next tile's DMA: 4-wave tiles (two workgroups per CU) issue ALL of it right at the top, so that it has
-    // the whole tile's MFMA time to land before the closing barrier; the 8-wave 256^2 tile (one workgroup owns the CU) spreads
-    // it one A + one B piece per k step between the MFMA groups, so that its waves are never all in a load-only phase.
-    auto k_tile = [&](int kt, auto has_next_tag) {
-        constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
-        const int buf = kt & 1;
+    // the share of one K tile's DMA that goes between the MFMA groups of k step ks (a quarter of the A and of the B pieces)
+    auto issue_quarter = [&](int ks, int k0, int buf) {
+#pragma unroll
+        for (int ps = 0; ps < AP; ++ps)
+            if (ps * 4 / AP == ks) issue_a(ps, k0, buf);
+#pragma unroll
+        for (int ps = 0; ps < BP; ++ps)
+            if ((BP >= 4 ? ps * 4 / BP : ps) == ks) issue_b(ps, k0, buf);
+        if (ks == 3) advance_gather();
+    };
+    // One K tile from buffer `buf`: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency
+    // hidden behind the matrix pipe); `spread_next` interleaves a later tile's DMA, a quarter per k step, between the MFMA groups.
+    auto compute_tile = [&](int buf, bool spread_next, int k_next, int buf_next) {
         const char* a_s = smem + buf * Cfg::STAGE_BYTES;
         const char* b_s = a_s + Cfg::A_BYTES;
         bf16x8 af[2][TM], bfr[2][2];
         read_frags(a_s, b_s, 0, af[0], bfr[0]);
-        const int k_next = k_begin + (kt + 1) * GBK;
-        if (Cfg::EARLY && HAS_NEXT) issue_tile(k_next, buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (the scheduler would sink it)
-            if (!Cfg::EARLY && HAS_NEXT) {
-                static_assert(Cfg::EARLY || (AP == 4 && BP == 4), "one A and one B piece per k step");
-                issue_a(ks, k_next, buf ^ 1);
-                issue_b(ks, k_next, buf ^ 1);
-                if (ks == 3) advance_gather();
-            }
+            if (spread_next) issue_quarter(ks, k_next, buf_next);
             // operands swapped: D[i][j] with i = output column n (register rows), j = output row m (lane & 31),
             // so that a lane ends up holding 4 consecutive columns of one row
 #pragma unroll
@@ -266,10 +270,45 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                 for (int tj = 0; tj < 2; ++tj)
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][tj], af[ks & 1][ti], acc[ti][tj], 0, 0, 0);
         }
-        __syncthreads();
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) k_tile(kt, std::true_type());
-    if (nk > 0) k_tile(nk - 1, std::false_type());
+    if constexpr (Cfg::NSTAGE > 2) {
+        // ---- pipelined loop: tiles kt+1 .. kt+S-2 stay in flight across the barrier of tile kt ----
+        // RAW: a wave's `s_waitcnt vmcnt(N)` retires ITS pieces of tile kt (DMA completes in issue order), the barrier that
+        // follows makes every wave's pieces visible to every reader.  WAR: tile kt+S-1 goes into the buffer of tile kt-1, whose
+        // last fragment reads were consumed by MFMAs that precede this barrier in every wave.
+        constexpr int S = Cfg::NSTAGE, DPT = AP + BP;
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t)
+            if (t < nk) issue_tile(k_begin + t * GBK, t);
+        int kt = 0;
+        for (; kt + (S - 2) < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * DPT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nxt = kt + S - 1;
+            compute_tile(kt % S, nxt < nk, k_begin + nxt * GBK, nxt % S);
+        }
+        for (; kt < nk; ++kt) {                      // drain: fewer tiles behind this one
+            if (S > 3 && nk - 1 - kt == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute_tile(kt % S, false, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // the epilogue reuses the staging LDS
+    } else {
+        if (nk > 0) issue_tile(k_begin, 0);
+        __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
+        // 2-stage loop.  The next tile's DMA: 4-wave tiles (two workgroups per CU) issue ALL of it right at the top, so that it
+        // has the whole tile's MFMA time to land before the closing barrier; the 8-wave 256^2 tile (one workgroup owns the CU)
+        // spreads it a quarter per k step between the MFMA groups, so that its waves are never all in a load-only phase.
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool has_next = kt + 1 < nk;
+            const int k_next = k_begin + (kt + 1) * GBK, buf = kt & 1;
+            if (Cfg::EARLY && has_next) issue_tile(k_next, buf ^ 1);
+            compute_tile(buf, !Cfg::EARLY && has_next, k_next, buf ^ 1);
+            __syncthreads();
+        }
+    }
 
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*TM*32 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
@@ -628,7 +667,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
 using namespace epi;
 
 enum { CFG_SMALL = 0, CFG_TALL = 1, CFG_BIG = 2 };
-struct GemmPlan { int cfg; int nsplit, kps; long long tiles; };
+struct GemmPlan { int cfg; int nsplit, kps; long long tiles; int pipe; };
 
 // EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
 static int gemm_tile_override() {
@@ -642,13 +681,21 @@ static int gemm_tile_override() {
 
 // Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
 // keeping >= 512 of K.
-static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase) {
+// EPI_GEMM_PIPE=0 never / 2 always (where a pipelined variant exists); default 1: when a workgroup's K loop is long enough
+static int gemm_pipe_mode() {
+    static const int v = [] { const char* e = getenv("EPI_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pipe = false) {
     GemmPlan pl;
     pl.cfg = cfg;
+    pl.pipe = pipe ? 1 : 0;
     const int bm = cfg == CFG_SMALL ? 128 : 256, bn = cfg == CFG_BIG ? 256 : (cfg == CFG_TALL ? 64 : 128);
     pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long long wgs = pl.tiles * nphase;
-    const long long enough = cfg == CFG_BIG ? 200 : 384, target = cfg == CFG_BIG ? 256 : 512;
+    const bool one_per_cu = cfg == CFG_BIG || pipe;
+    const long long enough = one_per_cu ? 200 : 384, target = one_per_cu ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
         nsplit = (int)(target / wgs);               // floor: one workgroup over the resident capacity costs a whole extra round
@@ -681,8 +728,13 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         const bool deep = pb.nsplit == 1 ? (K >= 512 && pb.tiles * nphase >= 200) : pb.kps >= 1024;
         if (ov == 2 || (fills && deep)) return pb;
     }
-    if (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) return gemm_plan_cfg(CFG_TALL, M, N, K, nphase);
-    return gemm_plan_cfg(CFG_SMALL, M, N, K, nphase);
+    const int cfg = (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) ? CFG_TALL : CFG_SMALL;
+    const int pm = out_f32 ? 0 : gemm_pipe_mode();
+    if (pm) {       // pipelined ring (one workgroup per CU): pays when every workgroup still has a K loop of >= 6 tiles
+        const GemmPlan pp = gemm_plan_cfg(cfg, M, N, K, nphase, true);
+        if (pm == 2 || pp.kps >= 6 * GBK) return pp;
+    }
+    return gemm_plan_cfg(cfg, M, N, K, nphase);
 }
 
 extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
@@ -700,7 +752,7 @@ extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
 
 template <bool OUT_F32, typename Cfg, int MODE>
 static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
-    const size_t lds = 2 * Cfg::STAGE_BYTES;
+    const size_t lds = (size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES;
     if (lds > 65536) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -764,8 +816,8 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     int rc;
     if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
-    else if (pl.cfg == CFG_TALL) rc = launch_gemm_cfg<false, CfgTall>(a, pl, nphase, st);
-    else rc = launch_gemm_cfg<false, CfgSmall>(a, pl, nphase, st);
+    else if (pl.cfg == CFG_TALL) rc = pl.pipe ? launch_gemm_cfg<false, CfgTallP>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgTall>(a, pl, nphase, st);
+    else rc = pl.pipe ? launch_gemm_cfg<false, CfgSmallP>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall>(a, pl, nphase, st);
     if (rc != EPI_OK) return rc;
     if (pl.nsplit > 1) {
         const long long n = (long long)nphase * a.M * (a.N >> 2);
