@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--force-grad-sync", action="store_true", help="diagnostic: run the N>1 gradient-bucket path at N=1 (copies "
                     "into the flat buckets, no collective) to price its overhead on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ss-leg", action="store_true", help="skip the extra configs[2] (self-supervised) measurement that rides along")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
 
@@ -142,6 +143,117 @@ def cpu_baseline(args, scenes):
     return out
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md)
+
+
+def stem_conv_ms(model, images, reps=5):
+    """The 7x7 stem is the one convolution left to the library (3 input channels): timed on its own after the timed region
+    (forward + weight gradient; it has no data gradient), so that the conv-stack figure covers EVERY convolution."""
+    conv = model.conv1
+    x = images.to(torch.bfloat16)
+    w = (getattr(conv, "weight_lp", None) if getattr(conv, "weight_lp", None) is not None else conv.weight).detach().to(torch.bfloat16)
+    y = torch.nn.functional.conv2d(x, w, stride=2, padding=3)
+    dy = torch.randn_like(y)
+
+    def run():
+        torch.nn.functional.conv2d(x, w, stride=2, padding=3)
+        torch.ops.aten.convolution_backward(dy, x, w, None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (False, True, False))
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        run()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, 2.0 * 2 * x.shape[0] * y.shape[2] * y.shape[3] * 64 * 147
+
+
+def build_roofline(args, ksum, glue_times, model, images):
+    """``roofline`` object of the JSON line.  Every duration is a HIP-event measurement on the launch stream taken INSIDE the timed
+    region: the C++ glue brackets its epi_* launches (backbone convolutions, BatchNorm), ``hip.timer`` the ctypes entry points
+    (deconvolution head, final 1x1 convolution, soft-argmax criterion, Adam).  FLOPs / bytes are the algorithmic ones of
+    BASELINE.md section 3 (2 x MACs; one read + one write of what the operation must touch)."""
+    steps = float(args.steps)
+    b, hm, cd, jd = args.batch, args.image // 4, 256, args.joints * args.depth
+    elem = 4 if args.fp32 else 2
+    vox = args.joints * args.depth * hm * hm
+    fam = {}
+
+    def add(name, bound, n, ms_total, flops=0.0, nbytes=0.0):
+        if n <= 0 or ms_total <= 0:
+            return
+        e = {"bound": bound, "launches_per_step": round(n / steps, 2), "ms_per_step": round(ms_total / steps, 4)}
+        if bound == "mfma":
+            e["achieved_tflops"] = round(flops / (ms_total * 1e-3) / 1e12, 1)
+            e["frac"] = round(e["achieved_tflops"] / MFMA_PEAK_TFLOPS, 4)
+            e["flops_per_step"] = flops / steps
+        else:
+            e["achieved_gbs"] = round(nbytes / (ms_total * 1e-3) / 1e9, 1)
+            e["frac"] = round(e["achieved_gbs"] / HBM_PEAK_GBS, 4)
+            e["algorithmic_bytes_per_step"] = nbytes / steps
+        fam[name] = e
+    for name, (n, ms, flops, nbytes) in glue_times.items():         # backbone convolutions + every BatchNorm routed through the glue
+        if name.startswith("conv_"):
+            add("backbone_" + name, "mfma", n, ms, flops=flops)
+        else:
+            add(name, "hbm", n, ms, nbytes=nbytes)
+    deconv_macs = [2048 * 256 * 16 * (hm // 8) ** 2, 256 * 256 * 16 * (hm // 4) ** 2, 256 * 256 * 16 * (hm // 2) ** 2]
+    final_macs = cd * jd * hm * hm
+    head = {"epi_deconv4x4s2_fwd": 2.0 * b * sum(deconv_macs), "epi_deconv4x4s2_bwd_data": 2.0 * b * sum(deconv_macs),
+            "epi_deconv4x4s2_bwd_weight": 2.0 * b * sum(deconv_macs), "epi_gemm_bf16": 2.0 * b * final_macs * 2,
+            "epi_gemm_tn_bf16": 2.0 * b * final_macs}
+    for name, per_step in head.items():
+        if name in ksum:
+            n, ms = ksum[name]
+            add("head_" + name[4:], "mfma", n, ms * n, flops=per_step * steps)
+    for name, factor in (("epi_softargmax3d_fwd", 1.0), ("epi_softargmax3d_bwd", 2.0)):
+        if name in ksum:
+            n, ms = ksum[name]
+            add(name[4:], "hbm", n, ms * n, nbytes=factor * b * vox * elem * n)
+    if "epi_adam_step" in ksum:
+        n, ms = ksum["epi_adam_step"]
+        nparam = sum(p.numel() for p in model.parameters())
+        add("adam_step", "hbm", n, ms * n, nbytes=30.0 * nparam * n)
+    gemm = {k: v for k, v in fam.items() if v["bound"] == "mfma"}
+    bn = {k: v for k, v in fam.items() if k.startswith("bn_")}
+    out = {}
+    if gemm:
+        ms = sum(v["ms_per_step"] for v in gemm.values())
+        flops = sum(v["flops_per_step"] for v in gemm.values())
+        launches = sum(v["launches_per_step"] for v in gemm.values())
+        ach = flops / (ms * 1e-3) / 1e12
+        out = {"kernel": "head_gemm_kernel / head_gemm_tn_kernel / head_gemm_astat_kernel -- the implicit-GEMM family that runs EVERY convolution "
+                         "of the network behind the 7x7 stem (backbone conv1..3 + downsample forward / backward-data / backward-weight, the "
+                         "deconvolution head, the final 1x1 convolution; split-K finish kernels included in the time): the largest "
+                         "share of the step",
+               "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+               "traffic": None, "algorithmic_flops_per_launch": flops / max(launches, 1e-9), "avg_ms": round(ms / max(launches, 1e-9), 5),
+               "launches_per_step": round(launches, 1), "ms_per_step": round(ms, 4)}
+        stem_ms, stem_flops = stem_conv_ms(model, images)
+        out["conv_stack"] = {"what": "every convolution incl. the library 7x7 stem (timed separately after the timed region)",
+                             "flops_per_step": flops + stem_flops, "ms_per_step": round(ms + stem_ms, 4),
+                             "achieved_tflops": round((flops + stem_flops) / ((ms + stem_ms) * 1e-3) / 1e12, 1),
+                             "frac": round((flops + stem_flops) / ((ms + stem_ms) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    if bn:
+        ms = sum(v["ms_per_step"] for v in bn.values())
+        nbytes = sum(v["algorithmic_bytes_per_step"] for v in bn.values())
+        out["batchnorm"] = {"what": "bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_apply: the dominant HBM-bound family (fused BatchNorm + "
+                                    "residual + ReLU, forward and backward)", "bound": "hbm", "ms_per_step": round(ms, 4),
+                            "launches_per_step": round(sum(v["launches_per_step"] for v in bn.values()) * 2, 1),
+                            "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if not out:          # hipGraph replay: only the criterion probe was timed
+        k = "softargmax3d_bwd"
+        e = fam.get(k, {})
+        out = {"kernel": "softargmax_bwd_kernel", "bound": "hbm", "achieved": e.get("achieved_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": e.get("frac"), "traffic": None}
+    out["families"] = fam
+    out["note"] = "traffic: not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*pmc*)"
+    return out
+
+
 def main():
     args = parse_args()
     from epipolarpose_amd import distributed as epd
@@ -195,6 +307,8 @@ def main():
     barrier()
     hip.timer.reset()
     hip.timer.enabled = not use_graph            # events cannot be recorded inside a replayed graph
+    hip.glue().timing_collect()                  # (clears) -- the C++ glue's launches carry their own HIP events
+    hip.glue().timing_enable(not use_graph)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -204,6 +318,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hip.timer.enabled = False
+    hip.glue().timing_enable(False)
+    glue_times = hip.glue().timing_collect()
     if use_graph:
         # per-kernel durations for the roofline: the same criterion kernels on the same resident logits-sized tensor,
         # launched eagerly with HIP events on the launch stream right after the timed region
@@ -221,65 +337,40 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    # the other single-GPU workload of BASELINE.json (configs[2]: pseudo labels from multi-view triangulation inside the step)
+    # rides along as an extra field of the same JSON line: same model / optimizer state, `steps` more steps, same timing rules
+    ss_line = None
+    if args.workload == "fs" and not use_graph and not args.no_ss_leg:
+        from epipolarpose_amd.hip import DeviceMeta
+        ss_meta = DeviceMeta(scenes.meta, device)
+
+        def ss_step():
+            return train_step(model, criterion, optimizer, images, label, weight, meta=ss_meta, n_view=args.views,
+                              autocast=not args.fp32, grad_sync=grad_sync)
+        for _ in range(2):
+            ss_step()
+        torch.cuda.synchronize()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            ss_loss = ss_step()
+        torch.cuda.synchronize()
+        barrier()
+        ss_elapsed = time.perf_counter() - ts
+        if world > 1:
+            t = torch.tensor([ss_elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ss_elapsed = float(t.item())
+        ss_line = {"workload": "configs[2]: self-supervised, %d-view epipolar-triangulation pseudo-labels inside the step, batch=%d/GPU"
+                               % (args.views, args.batch), "value": round(args.batch * world * args.steps / ss_elapsed, 2), "unit": "images/s",
+                   "ms_per_step": round(ss_elapsed / args.steps * 1e3, 3), "final_loss": round(float(ss_loss.item()), 6)}
 
     if rank == 0:
         global_batch = args.batch * world
         elem = 4 if args.fp32 else 2
         vox = args.joints * args.depth * (args.image // 4) ** 2
         ksum = hip.timer.summary()
-        MFMA_PEAK = 2500.0      # dense bf16 TFLOP/s (MI355X_MICROARCH.md)
-        b, hm, cd, jd = args.batch, args.image // 4, 256, args.joints * args.depth
-        # algorithmic FLOPs (2 x MACs, BASELINE.md section 3 / SURVEY 2.2), B = per-GPU batch
-        deconv_macs = [2048 * 256 * 16 * (hm // 8) ** 2, 256 * 256 * 16 * (hm // 4) ** 2, 256 * 256 * 16 * (hm // 2) ** 2]
-        final_macs = cd * jd * hm * hm
-        per_step_flops = {"epi_deconv4x4s2_fwd": 2.0 * b * sum(deconv_macs), "epi_deconv4x4s2_bwd_data": 2.0 * b * sum(deconv_macs),
-                          "epi_deconv4x4s2_bwd_weight": 2.0 * b * sum(deconv_macs), "epi_gemm_bf16": 2.0 * b * final_macs * 2,
-                          "epi_gemm_tn_bf16": 2.0 * b * final_macs}
-        per_kernel = {}
-        steps_timed = args.steps
-        for name, fl in per_step_flops.items():
-            if name in ksum:
-                n, ms = ksum[name]
-                step_ms = ms * n / steps_timed
-                per_kernel[name] = {"launches_per_step": n / steps_timed, "ms_per_step": round(step_ms, 4),
-                                    "achieved_tflops": round(fl / (step_ms * 1e-3) / 1e12, 1)}
-        # dominant hand-written kernel: head_gemm_kernel = the 8 NT launches per step (3 deconv fwd, 3 deconv bwd-data,
-        # final 1x1 fwd + bwd-data); "achieved" = their algorithmic FLOPs / their summed HIP-event durations
-        nt = ("epi_deconv4x4s2_fwd", "epi_deconv4x4s2_bwd_data", "epi_gemm_bf16")
-        head_ms = sum(per_kernel[k]["ms_per_step"] for k in nt if k in per_kernel)
-        head_flops = sum(per_step_flops[k] for k in nt if k in per_kernel)
-        head_launches = sum(per_kernel[k]["launches_per_step"] for k in nt if k in per_kernel)
-        n_b, ms_b = ksum["epi_softargmax3d_bwd"]
-        n_f, ms_f = ksum["epi_softargmax3d_fwd"]
-        bytes_bwd = 2.0 * args.batch * vox * elem          # 1 read of the logits + 1 write of dlogits
-        bytes_fwd = 1.0 * args.batch * vox * elem          # 1 read of the logits
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("head_gemm_kernel/b%d" % args.batch)
-            except Exception:
-                traffic = None
-        hbm = {"softargmax_bwd_kernel (epi_softargmax3d_bwd)": {
-                   "bound": "hbm", "achieved": round(bytes_bwd / (ms_b * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(bytes_bwd / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": bytes_bwd,
-                   "avg_ms": round(ms_b, 5), "launches": n_b},
-               "softargmax_partial+combine (epi_softargmax3d_fwd)": {
-                   "bound": "hbm", "achieved": round(bytes_fwd / (ms_f * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(bytes_fwd / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": bytes_fwd,
-                   "avg_ms": round(ms_f, 5), "launches": n_f}}
-        if head_ms > 0:
-            ach = head_flops / (head_ms * 1e-3) / 1e12
-            roofline = {"kernel": "head_gemm_kernel + head_gemm_astat_kernel (deconvolution head fwd + bwd-data, final 1x1 conv bwd-data; "
-                                  "final 1x1 conv fwd on the A-stationary variant: %d launches per step; the hand-written kernel "
-                                  "family with the largest share of the step)" % round(head_launches),
-                        "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK, 4),
-                        "traffic": traffic, "algorithmic_flops_per_launch": head_flops / max(head_launches, 1),
-                        "avg_ms": round(head_ms / max(head_launches, 1), 5), "launches_per_step": head_launches,
-                        "entry_points": per_kernel, "other": hbm}
-        else:
-            k = "softargmax_bwd_kernel (epi_softargmax3d_bwd)"
-            roofline = dict(hbm[k], kernel=k, traffic=None, other={kk: v for kk, v in hbm.items() if kk != k})
+        roofline = build_roofline(args, ksum, glue_times, model, images)
         line = {
             "metric": "images/sec (4-view 256x256, ResNet-50) at 1/2/4/8 MI355X; MPJPE vs ref",
             "value": round(global_batch * args.steps / elapsed, 2), "unit": "images/s",
@@ -296,6 +387,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
                        "host_enqueue_ms_one_step_empty_queue": round(host_one * 1e3, 3)},
             "roofline": roofline,
+            "workload_ss": ss_line,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, scenes)

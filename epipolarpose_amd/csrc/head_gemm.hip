@@ -681,9 +681,11 @@ static int gemm_tile_override() {
 
 // Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
 // keeping >= 512 of K.
-// EPI_GEMM_PIPE=0 never / 2 always (where a pipelined variant exists); default 1: when a workgroup's K loop is long enough
+// EPI_GEMM_PIPE: 0 (default) never, 1 when a workgroup's K loop has >= 6 tiles, 2 always (where a pipelined variant exists).
+// Measured on MI355X (profiles/r02_conv_layers_c_pipelined_ab.txt): the ring removes the DMA-latency stall but these GEMMs are bound by
+// the global->LDS fill itself (32 KB per 128x128x64 tile step, ~23 GB/s per CU = ~6 TB/s over the chip), so it gains nothing here
 static int gemm_pipe_mode() {
-    static const int v = [] { const char* e = getenv("EPI_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("EPI_GEMM_PIPE"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -695,7 +697,9 @@ static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pip
     pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long long wgs = pl.tiles * nphase;
     const bool one_per_cu = cfg == CFG_BIG || pipe;
-    const long long enough = one_per_cu ? 200 : 384, target = one_per_cu ? 256 : 512;
+    // no split once (nearly) every CU has a workgroup: measured per layer (tools/bench_conv.py), an unsplit 256-workgroup launch of
+    // 16 K tiles beats two splits + the finish kernel (ResNet-50 layer4.conv1: 16 us vs 27 us)
+    const long long enough = 200, target = one_per_cu ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
         nsplit = (int)(target / wgs);               // floor: one workgroup over the resident capacity costs a whole extra round
