@@ -1,0 +1,133 @@
+// Input pipeline on the GPU: crop + scale + rotate a person patch out of a decoded camera frame and
+// normalise it -- one byte-streaming kernel for what the reference does per sample on the host with OpenCV and NumPy
+// (lib/utils/img_utils.py:114-127 generate_patch_image_cv -> cv2.warpAffine(INTER_LINEAR), :265-279 BGR -> RGB, colour
+// scaling, clip, mean / std normalisation; lib/dataset/JointIntegralDataset.py:67-68 the ImageNet mean / std in 0..255 units).
+//
+// cv2.warpAffine semantics restated (OpenCV 4.1 imgwarp.cpp, the pin of the reference's environment.yml; cv2 itself is not
+// installed -> parity unpinned): the forward map M is inverted in double; destination pixel (x, y) reads the
+// source position in FIXED POINT, X = (round((M10*y + M12) * 1024) + 16 + round(M00*x * 1024)) >> 5 (5 fractional bits), samples
+// the 2 x 2 neighbourhood with integer weights of scale 2^15 (rounded products of the two linear weights, corrected so that the
+// four sum to 2^15), adds 2^14 and shifts by 15; taps outside the frame contribute 0 (BORDER_CONSTANT).
+#include "common.h"
+
+namespace epi {
+
+struct PatchArgs {
+    const unsigned char* frames;       // BGR bytes
+    const long long* frame_offset;     // [B] byte offset of sample b's frame
+    const int* frame_hw;               // [B][2] (height, width)
+    const double* trans;               // [B][2][3] forward affine (frame -> patch), as gen_trans_from_patch_cv returns it
+    const int* do_flip;                // [B] or null: mirror the frame first (generate_patch_image_cv:120-122)
+    const float* color_scale;          // [B][3] (per RGB output channel) or null
+    float mean[3], inv_std_is_std[3];  // per RGB channel; std (the kernel divides, as the reference does)
+    int normalize;
+    void* out;
+    int out_bf16, out_nhwc;
+    int B, PH, PW;
+};
+
+__device__ __forceinline__ int round_half_even(double v) { return (int)__double2ll_rn(v); }   // cvRound / saturate_cast<int>(double)
+
+// integer bilinear weights of OpenCV's table (initInterTab2D, INTER_LINEAR): products of the float32 1-D weights scaled by 2^15,
+// rounded to nearest-even, the largest (smallest) entry corrected when the sum misses 2^15
+__device__ __forceinline__ void bilinear_itab(int ax, int ay, int (&w)[4]) {
+    const float fx = (float)ax * (1.f / 32.f), fy = (float)ay * (1.f / 32.f);
+    const float tx[2] = {1.f - fx, fx}, ty[2] = {1.f - fy, fy};
+    int isum = 0;
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const float v = ty[k1] * tx[k2];
+            int iv = (int)__float2ll_rn(v * 32768.f);
+            iv = iv > 32767 ? 32767 : (iv < -32768 ? -32768 : iv);       // saturate_cast<short>
+            w[k1 * 2 + k2] = iv;
+            isum += iv;
+        }
+    if (isum != 32768) {
+        const int diff = isum - 32768;
+        int mk = 0;      // search window of OpenCV: ksize2 = 1 -> rows/cols [1, 2) -> only entry (1,1)? no: for ksize 2 the window is k in [ksize/2, ksize/2+... ) = the 2x2 block itself
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (diff < 0 ? w[k] > w[mk] : w[k] < w[mk]) mk = k;
+        }
+        w[mk] -= diff;
+    }
+}
+
+__global__ __launch_bounds__(256) void patch_crop_kernel(PatchArgs p) {
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= p.PH * p.PW) return;
+    const int y = pix / p.PW, x = pix - y * p.PW;
+    const double* m = p.trans + (long long)b * 6;
+    // invert the forward map exactly as cv::warpAffine does (double)
+    double M0 = m[0], M1 = m[1], M2 = m[2], M3 = m[3], M4 = m[4], M5 = m[5];
+    double D = M0 * M4 - M1 * M3;
+    D = D != 0.0 ? 1.0 / D : 0.0;
+    const double A11 = M4 * D, A22 = M0 * D;
+    M0 = A11; M1 *= -D; M3 *= -D; M4 = A22;
+    const double b1 = -M0 * M2 - M1 * M5, b2 = -M3 * M2 - M4 * M5;
+    M2 = b1; M5 = b2;
+    const int adelta = round_half_even(M0 * x * 1024.0), bdelta = round_half_even(M3 * x * 1024.0);
+    const int X0 = round_half_even((M1 * y + M2) * 1024.0) + 16, Y0 = round_half_even((M4 * y + M5) * 1024.0) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+    int w[4];
+    bilinear_itab(ax, ay, w);
+    const int H = p.frame_hw[2 * b], W = p.frame_hw[2 * b + 1];
+    const unsigned char* img = p.frames + p.frame_offset[b];
+    const bool flip = p.do_flip && p.do_flip[b];
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int yy = sy + k1, xx = sx + k2;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const int xs = flip ? W - 1 - xx : xx;
+                const unsigned char* px = img + ((long long)yy * W + xs) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] += (int)px[c] * w[k1 * 2 + k2];
+            }
+        }
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {            // output channel c = RGB; source channel 2 - c (frames are BGR: img_utils.py:269)
+        int v = (acc[2 - c] + (1 << 14)) >> 15;
+        v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        float f = (float)v;
+        if (p.color_scale) f = fminf(fmaxf(f * p.color_scale[3 * b + c], 0.f), 255.f);      // img_utils.py:276
+        if (p.normalize) f = (f - p.mean[c]) / p.inv_std_is_std[c];                          // :277-278
+        o[c] = f;
+    }
+    const long long plane = (long long)p.PH * p.PW;
+    if (p.out_nhwc) {
+        const long long base = ((long long)b * plane + pix) * 3;
+        if (p.out_bf16) { unsigned short* q = (unsigned short*)p.out + base; q[0] = f32_to_bf16(o[0]); q[1] = f32_to_bf16(o[1]); q[2] = f32_to_bf16(o[2]); }
+        else { float* q = (float*)p.out + base; q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; }
+    } else {
+        const long long base = (long long)b * 3 * plane + pix;
+        if (p.out_bf16) { unsigned short* q = (unsigned short*)p.out + base; q[0] = f32_to_bf16(o[0]); q[plane] = f32_to_bf16(o[1]); q[2 * plane] = f32_to_bf16(o[2]); }
+        else { float* q = (float*)p.out + base; q[0] = o[0]; q[plane] = o[1]; q[2 * plane] = o[2]; }
+    }
+}
+
+}  // namespace epi
+
+extern "C" int epi_crop_patches(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
+                                const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
+                                int patch_h, int patch_w, void* out, int out_dtype, int out_layout, epi_stream_t stream) {
+    if (!frames || !frame_offset || !frame_hw || !trans || !out || B <= 0 || patch_h <= 0 || patch_w <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if ((out_dtype != EPI_F32 && out_dtype != EPI_BF16) || (out_layout != EPI_NCHW && out_layout != EPI_NHWC)) return EPI_ERR_UNSUPPORTED;
+    if ((mean_host == nullptr) != (std_host == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
+    epi::PatchArgs a = {};
+    a.frames = (const unsigned char*)frames; a.frame_offset = frame_offset; a.frame_hw = frame_hw; a.trans = trans; a.do_flip = do_flip;
+    a.color_scale = color_scale; a.normalize = mean_host ? 1 : 0;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean_host ? mean_host[c] : 0.f; a.inv_std_is_std[c] = std_host ? std_host[c] : 1.f; }
+    a.out = out; a.out_bf16 = out_dtype == EPI_BF16; a.out_nhwc = out_layout == EPI_NHWC; a.B = B; a.PH = patch_h; a.PW = patch_w;
+    const dim3 grid((unsigned)((patch_h * patch_w + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(epi::patch_crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}

@@ -44,6 +44,12 @@ inline bool nhwc_bf16(const Tensor& t) {
 struct TimingRec { const char* name; double flops, bytes; hipEvent_t a, b; };
 bool g_timing = false;
 std::vector<TimingRec> g_recs;
+std::vector<hipEvent_t> g_event_pool;         // events are created once and reused: hipEventCreate per launch made the step host-bound
+hipEvent_t pooled_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 struct ScopedTimer {
     TimingRec r;
     hipStream_t st;
@@ -51,13 +57,25 @@ struct ScopedTimer {
     ScopedTimer(const char* name, double flops, double bytes, epi_stream_t stream) : st((hipStream_t)stream), on(g_timing) {
         if (!on) return;
         r.name = name; r.flops = flops; r.bytes = bytes;
-        on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess && hipEventRecord(r.a, st) == hipSuccess;
+        r.a = pooled_event();
+        r.b = pooled_event();
+        on = r.a && r.b && hipEventRecord(r.a, st) == hipSuccess;
     }
     ~ScopedTimer() {
         if (on && hipEventRecord(r.b, st) == hipSuccess) g_recs.push_back(r);
     }
 };
-void timing_enable(bool on) { g_timing = on; }
+void timing_enable(bool on) {
+    if (on && g_event_pool.size() < 16384) {       // warm the pool outside the timed region
+        g_event_pool.reserve(16384);
+        while (g_event_pool.size() < 16384) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            g_event_pool.push_back(e);
+        }
+    }
+    g_timing = on;
+}
 // {name: (launches, total ms, total algorithmic FLOPs, total algorithmic bytes)}; synchronises; clears the records
 std::map<std::string, std::tuple<int64_t, double, double, double>> timing_collect() {
     std::map<std::string, std::tuple<int64_t, double, double, double>> out;
@@ -67,8 +85,8 @@ std::map<std::string, std::tuple<int64_t, double, double, double>> timing_collec
             auto& e = out[r.name];
             std::get<0>(e) += 1; std::get<1>(e) += ms; std::get<2>(e) += r.flops; std::get<3>(e) += r.bytes;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_event_pool.push_back(r.a);
+        g_event_pool.push_back(r.b);
     }
     g_recs.clear();
     return out;

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "epi_adam_tensor_bytes": (_sz, []),
     "epi_adam_chunk_elems": (_i, []),
     "epi_adam_step": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _vp]),
+    "epi_crop_patches": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i, _i, _i, _vp,
+                              _i, _i, _vp]),
     "epi_evaluate_poses": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -681,3 +683,28 @@ def evaluate_poses(pred_img, gt_img, pelvis_z, fl, c_p, root, j14):
     _check(lib.epi_evaluate_poses(_ptr(pred_img), _ptr(gt_img), _ptr(pelvis_z.contiguous()), _ptr(fl.contiguous()), _ptr(c_p.contiguous()),
                                   n, j, root, _ptr(j14_t), len(j14), _ptr(metrics), _ptr(per_joint), _stream()), "epi_evaluate_poses")
     return metrics, per_joint
+
+
+def crop_patches(frames, frame_offset, frame_hw, trans, patch_h, patch_w, do_flip=None, color_scale=None, mean=None, std=None,
+                 dtype=torch.float32, channels_last=False):
+    """Batched crop + warp + normalise (``epi_crop_patches``).  frames: uint8 CUDA tensor holding the BGR frames back to back;
+    frame_offset int64 [B]; frame_hw int32 [B, 2]; trans float64 [B, 2, 3] (forward affine frame -> patch).  -> [B, 3, ph, pw]
+    (logical NCHW; channels_last memory when asked), RGB order.  Reference: img_utils.py:114-127,265-279."""
+    lib = load()
+    _dev(frames, torch.uint8, "frames")
+    frame_offset = _dev(frame_offset, torch.int64, "frame_offset").contiguous()
+    frame_hw = _dev(frame_hw, torch.int32, "frame_hw").contiguous()
+    trans = _dev(trans, torch.float64, "trans").contiguous()
+    b = trans.shape[0]
+    if do_flip is not None:
+        do_flip = _dev(do_flip, name="do_flip").to(torch.int32).contiguous()
+    if color_scale is not None:
+        color_scale = _dev(color_scale, name="color_scale").to(torch.float32).contiguous()
+    out = torch.empty((b, 3, patch_h, patch_w), dtype=dtype, device=frames.device,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+    _check(lib.epi_crop_patches(_ptr(frames), _ptr(frame_offset), _ptr(frame_hw), _ptr(trans), _ptr(do_flip), _ptr(color_scale), m3, s3, b,
+                                patch_h, patch_w, _ptr(out), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32,
+                                EPI_NHWC if channels_last else EPI_NCHW, _stream()), "epi_crop_patches")
+    return out

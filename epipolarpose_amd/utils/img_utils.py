@@ -103,3 +103,59 @@ def trans_coords_from_patch_to_org_3d(coords_in_patch, c_x, c_y, bb_width, bb_he
     out = trans_coords_from_patch_to_org(coords_in_patch, c_x, c_y, bb_width, bb_height, patch_width, patch_height, scale, rot)
     out[:, 2] = coords_in_patch[:, 2] / patch_width * rect_3d_width
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Input pipeline on the GPU: img_utils.py:114-127 + :265-279, batched.
+# ------------------------------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (123.675, 116.280, 103.530)        # JointIntegralDataset.py:67
+IMAGENET_STD = (58.395, 57.120, 57.375)            # JointIntegralDataset.py:68
+
+
+def generate_patch_images_device(frames, center_x, center_y, bb_width, bb_height, patch_width, patch_height, do_flip=None, scale=None,
+                                 rot=None, color_scale=None, mean=IMAGENET_MEAN, std=IMAGENET_STD, dtype=torch.float32,
+                                 channels_last=False, device=None):
+    """The reference's per-sample ``generate_patch_image_cv`` + colour / normalisation stage for a whole batch in one launch.
+
+    frames: list of uint8 arrays / tensors [H, W, 3] in BGR order (what ``cv2.imread`` yields), sizes may differ.  The per-sample
+    affine (``gen_trans_from_patch_cv``; with ``do_flip`` the centre is mirrored first, :120-122) is set up on the host, the
+    bilinear warp, BGR -> RGB, colour scaling, clipping and (x - mean) / std run on the device.
+    -> (patches [B, 3, ph, pw] on the device, trans float64 ndarray [B, 2, 3])."""
+    b = len(frames)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    scale = np.ones(b) if scale is None else np.asarray(scale, np.float64)
+    rot = np.zeros(b) if rot is None else np.asarray(rot, np.float64)
+    flip = np.zeros(b, np.int32) if do_flip is None else np.asarray(do_flip).astype(np.int32)
+    hw = np.zeros((b, 2), np.int32)
+    offs = np.zeros(b, np.int64)
+    trans = np.zeros((b, 2, 3))
+    flat, total = [], 0
+    for i, f in enumerate(frames):
+        t = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(f))
+        assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[2] == 3, "frames must be uint8 [H, W, 3] (BGR)"
+        hw[i] = (t.shape[0], t.shape[1])
+        offs[i] = total
+        total += t.numel()
+        flat.append(t.reshape(-1))
+        cx = t.shape[1] - float(center_x[i]) - 1 if flip[i] else float(center_x[i])
+        trans[i] = gen_trans_from_patch_cv(cx, float(center_y[i]), float(bb_width[i]), float(bb_height[i]), patch_width, patch_height,
+                                           float(scale[i]), float(rot[i]), inv=False)
+    buf = torch.cat([t.to(device, non_blocking=True) for t in flat])
+    cs = None if color_scale is None else torch.as_tensor(np.asarray(color_scale, np.float32).reshape(b, 3), device=device)
+    out = hip.crop_patches(buf, torch.from_numpy(offs).to(device), torch.from_numpy(hw).to(device), torch.from_numpy(trans).to(device),
+                           int(patch_height), int(patch_width), do_flip=torch.from_numpy(flip).to(device), color_scale=cs, mean=mean, std=std,
+                           dtype=dtype, channels_last=channels_last)
+    return out, trans
+
+
+def generate_patch_image_cv(cvimg, c_x, c_y, bb_width, bb_height, patch_width, patch_height, do_flip, scale, rot):
+    """img_utils.py:114-127 for one frame: -> (uint8-valued patch [ph, pw, 3] in BGR as the reference returns it, trans)."""
+    out, trans = generate_patch_images_device([cvimg], [c_x], [c_y], [bb_width], [bb_height], patch_width, patch_height, [do_flip], [scale],
+                                              [rot], mean=None, std=None)
+    rgb = out[0].permute(1, 2, 0).round().to(torch.uint8).cpu().numpy()
+    return rgb[:, :, ::-1].copy(), trans[0]
+
+
+def convert_cvimg_to_tensor(cvimg, occlusion_aug=True):
+    """img_utils.py:130-138: HWC -> CHW float32 (no colour reordering there)."""
+    return np.transpose(np.asarray(cvimg), (2, 0, 1)).astype(np.float32)

@@ -286,6 +286,22 @@ int epi_adam_step(const void* table, const void* chunks, int nchunks, float lr, 
                   long long step, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input pipeline -- replaces, per batch instead of per sample on the host, generate_patch_image_cv
+ * (lib/utils/img_utils.py:114-127: cv2.warpAffine, INTER_LINEAR, constant border) and the colour / normalisation stage of
+ * get_single_patch_sample (:265-279: BGR -> RGB, per-channel colour scale, clip to [0, 255], (x - mean) / std).
+ *   frames        device bytes holding B decoded BGR frames; sample b starts at frames + frame_offset[b], size frame_hw[b] = (h, w)
+ *   trans         [B][2][3] f64: the FORWARD affine frame -> patch of gen_trans_from_patch_cv (:72-105); inverted in the kernel
+ *                 exactly as cv::warpAffine does, sampled in OpenCV's 5-bit fixed point with its 2^15-scaled integer weights
+ *   do_flip       [B] int32 or NULL: mirror the frame horizontally first (:120-122)
+ *   color_scale   [B][3] f32 per RGB channel or NULL;   mean_host / std_host: 3 floats each (HOST pointers) or both NULL (no normalisation)
+ *   out           [B][3][ph][pw] (EPI_NCHW) or [B][ph][pw][3] (EPI_NHWC), f32 or bf16, channels in RGB order
+ * Not covered: the synthetic-occlusion augmentation (lib/utils/augmentation.py:61-114 pastes Pascal-VOC objects; needs that dataset).
+ * ------------------------------------------------------------------------------------------------ */
+int epi_crop_patches(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
+                     const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
+                     int patch_h, int patch_w, void* out, int out_dtype, int out_layout, epi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Pose evaluation -- replaces the per-sample loop of H36M_Integral.evaluate
  * (lib/dataset/h36m.py:168-378) incl. compute_similarity_transform (lib/utils/prep_h36m.py:108-168).
  *   pred_img, gt_img [N][J][3] f64: (u, v, root-relative depth mm) in image coordinates; pelvis_z [N]: camera-space

@@ -1,0 +1,81 @@
+"""Input pipeline: the oracle's restatement of cv2.warpAffine(INTER_LINEAR) pinned by its defining properties
+(CPU), and the HIP kernel against the oracle (GPU): bytes exact before normalisation, float32 normalisation to 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import imgproc as o_img
+
+
+def _frame(h, w, seed):
+    return np.random.default_rng(seed).integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+def test_warp_affine_identity_translation_and_scale():
+    img = _frame(40, 56, 0)
+    ident = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    np.testing.assert_array_equal(o_img.warp_affine_linear(img, ident, (56, 40)), img)
+    shift = np.array([[1.0, 0, 5.0], [0, 1.0, -3.0]])                 # dst(x, y) = src(x - 5, y + 3); outside -> 0
+    out = o_img.warp_affine_linear(img, shift, (56, 40))
+    np.testing.assert_array_equal(out[0:37, 5:56], img[3:40, 0:51])
+    assert out[:, :5].max() == 0 and out[37:].max() == 0
+    up = np.array([[2.0, 0, 0], [0, 2.0, 0]])                          # 2x up-scaling: odd pixels are rounded means of neighbours
+    out = o_img.warp_affine_linear(img, up, (112, 80))
+    np.testing.assert_array_equal(out[0:80:2, 0:112:2], img)
+    a, b = img[:, :-1].astype(np.int64), img[:, 1:].astype(np.int64)
+    np.testing.assert_array_equal(out[0:80:2, 1:111:2], ((a * 16384 + b * 16384 + 16384) >> 15).astype(np.uint8))
+    tab = o_img._itab()
+    assert (tab.sum(axis=2) == 32768).all() and tab.min() >= 0
+    np.testing.assert_array_equal(tab[0, 0], [32768, 0, 0, 0])
+    np.testing.assert_array_equal(tab[16, 16], [8192] * 4)
+
+
+def test_generate_patch_flip_and_rotation_consistency():
+    img = _frame(64, 64, 1)
+    # the reference maps the box centre onto patch_width / 2 (img_utils.py:88): a 64-pixel box centred at 32.0 is the identity crop
+    p0, _ = o_img.generate_patch_image(img, 32.0, 32.0, 64, 64, 64, 64, False, 1.0, 0.0)
+    np.testing.assert_array_equal(p0, img)
+    # flip: the frame is mirrored and the centre becomes W - c_x - 1 = 31 (:120-122) -> the mirrored frame, one pixel to the right
+    pf, _ = o_img.generate_patch_image(img, 32.0, 32.0, 64, 64, 64, 64, True, 1.0, 0.0)
+    np.testing.assert_array_equal(pf[:, 1:], img[:, ::-1][:, :-1])
+    # a half turn about (32, 32): pixel (x, y) reads (64 - x, 64 - y) (up to the 2^-10 fixed-point grid)
+    p180, _ = o_img.generate_patch_image(img, 32.0, 32.0, 64, 64, 64, 64, False, 1.0, 180.0)
+    assert np.abs(p180[1:, 1:].astype(int) - img[::-1, ::-1][:-1, :-1].astype(int)).max() <= 2
+    out, _ = o_img.normalized_patch(img, 32.0, 32.0, 64, 64, 64, 64, color_scale=(1.2, 1.0, 0.8), mean=(123.675, 116.28, 103.53),
+                                    std=(58.395, 57.12, 57.375))
+    want_r = (np.clip(img[:, :, 2].astype(np.float32) * np.float32(1.2), 0, 255) - np.float32(123.675)) / np.float32(58.395)
+    np.testing.assert_allclose(out[0], want_r, rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,channels_last", [(torch.float32, False), (torch.bfloat16, True)])
+def test_crop_patches_kernel_vs_oracle(dtype, channels_last):
+    from epipolarpose_amd.utils import img_utils
+    rng = np.random.default_rng(7)
+    frames = [_frame(200, 240, 10), _frame(180, 180, 11), _frame(256, 200, 12), _frame(120, 300, 13)]
+    cx = [120.3, 88.7, 100.0, 150.5]
+    cy = [99.1, 91.2, 128.0, 60.25]
+    bw = [150.0, 120.5, 260.0, 90.0]                                   # the third box exceeds its frame: constant border
+    bh = [150.0, 120.5, 260.0, 90.0]
+    flip = [0, 1, 0, 1]
+    scale = [1.0, 1.17, 0.8, 1.25]
+    rot = [0.0, 23.0, -47.5, 60.0]
+    cs = rng.uniform(0.8, 1.2, size=(4, 3)).astype(np.float32)
+    out, trans = img_utils.generate_patch_images_device(frames, cx, cy, bw, bh, 64, 64, do_flip=flip, scale=scale, rot=rot, color_scale=cs,
+                                                        dtype=dtype, channels_last=channels_last)
+    assert out.shape == (4, 3, 64, 64) and out.dtype == dtype
+    assert out.is_contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    raw, _ = img_utils.generate_patch_images_device(frames, cx, cy, bw, bh, 64, 64, do_flip=flip, scale=scale, rot=rot, mean=None, std=None)
+    for i in range(4):
+        want, otrans = o_img.normalized_patch(frames[i], cx[i], cy[i], bw[i], bh[i], 64, 64, bool(flip[i]), scale[i], rot[i], cs[i],
+                                              img_utils.IMAGENET_MEAN, img_utils.IMAGENET_STD)
+        np.testing.assert_allclose(trans[i], otrans, atol=1e-12)
+        opatch, _ = o_img.generate_patch_image(frames[i], cx[i], cy[i], bw[i], bh[i], 64, 64, bool(flip[i]), scale[i], rot[i])
+        np.testing.assert_array_equal(raw[i].cpu().numpy().astype(np.uint8), np.transpose(opatch[:, :, ::-1], (2, 0, 1)))   # bytes: exact
+        got = out[i].float().cpu().numpy()
+        if dtype == torch.float32:
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2 ** -8, atol=2 ** -8)
+    patch_bgr, t0 = img_utils.generate_patch_image_cv(frames[0], cx[0], cy[0], bw[0], bh[0], 64, 64, False, 1.0, 0.0)
+    np.testing.assert_array_equal(patch_bgr, o_img.generate_patch_image(frames[0], cx[0], cy[0], bw[0], bh[0], 64, 64, False, 1.0, 0.0)[0])
