@@ -25,6 +25,10 @@ _LIB_ALIASES = {
     "lib.utils.utils": "epipolarpose_amd.utils.utils",
     "lib.utils.prep_h36m": "epipolarpose_amd.utils.prep_h36m",
     "lib.utils.cameras": "epipolarpose_amd.utils.cameras",
+    "refiner": "epipolarpose_amd.refiner",
+    "refiner.model": "epipolarpose_amd.refiner.model",
+    "refiner.utils": "epipolarpose_amd.refiner.utils",
+    "refiner.main": "epipolarpose_amd.refiner.main",
     "lib.dataset": "epipolarpose_amd.dataset",
     "lib.dataset.h36m": "epipolarpose_amd.dataset.synthetic",
 }

@@ -17,10 +17,30 @@ struct AdamTensor {            // one row of the device-resident table (48 bytes
 constexpr int ADAM_THREADS = 256;
 constexpr int ADAM_CHUNK = 16384;       // elements per workgroup
 
-__global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks,
-                                                                  float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+// sum of squares of every gradient (the total norm torch.nn.utils.clip_grad_norm_ computes; refiner/main.py:53): one atomic per chunk
+__global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks,
+                                                                  float* __restrict__ sumsq) {
+    __shared__ float red[17];
     const int2 ck = chunks[blockIdx.x];
     const AdamTensor t = table[ck.x];
+    const long long base = (long long)ck.y * ADAM_CHUNK;
+    const long long end = (base + ADAM_CHUNK < t.n) ? base + ADAM_CHUNK : t.n;
+    float s = 0.f;
+    for (long long j = base + threadIdx.x; j < end; j += ADAM_THREADS) {
+        const float g = t.g_bf16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(t.g)[j]) : reinterpret_cast<const float*>(t.g)[j];
+        s = fmaf(g, g, s);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(sumsq, s);
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks,
+                                                                  float b1, float b2, float eps, float step_size, float inv_sqrt_bc2,
+                                                                  const float* __restrict__ clip_sumsq, float max_norm) {
+    const int2 ck = chunks[blockIdx.x];
+    const AdamTensor t = table[ck.x];
+    // gradient clipping by total norm (clip_grad_norm_): every gradient is scaled by min(1, max_norm / (norm + 1e-6))
+    const float gscale = clip_sumsq ? fminf(1.f, max_norm / (sqrtf(*clip_sumsq) + 1e-6f)) : 1.f;
     const long long base = (long long)ck.y * ADAM_CHUNK;
     const long long end = (base + ADAM_CHUNK < t.n) ? base + ADAM_CHUNK : t.n;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15u) == 0 &&
@@ -41,6 +61,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTens
                 const float4v r = *reinterpret_cast<const float4v*>(reinterpret_cast<const float*>(t.g) + i);
                 g[0] = r.x; g[1] = r.y; g[2] = r.z; g[3] = r.w;
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] *= gscale;
             float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -65,7 +87,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTens
     // scalar path: the <= 3 leftover elements of a vectorised chunk, or every element of an unaligned tensor
     const long long sbegin = vec_ok ? end - ((end - base) & 3) : base;
     for (long long j = sbegin + threadIdx.x; j < end; j += ADAM_THREADS) {
-        const float g = t.g_bf16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(t.g)[j]) : reinterpret_cast<const float*>(t.g)[j];
+        const float g = gscale * (t.g_bf16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(t.g)[j]) : reinterpret_cast<const float*>(t.g)[j]);
         float m = t.m[j], v = t.v[j], p = t.p[j];
         m = m + (g - m) * (1.f - b1);
         v = v * b2 + g * g * (1.f - b2);
@@ -86,7 +108,25 @@ extern "C" int epi_adam_step(const void* table, const void* chunks, int nchunks,
     if (!table || !chunks || nchunks <= 0 || step < 1) return EPI_ERR_INVALID_ARGUMENT;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(epi::adam_multi_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
-                       (const epi::AdamTensor*)table, (const int2*)chunks, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+                       (const epi::AdamTensor*)table, (const int2*)chunks, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
+                       (const float*)nullptr, 0.f);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+// The same with torch.nn.utils.clip_grad_norm_(parameters, max_norm) folded in (reference refiner/main.py:53-54): one launch
+// reduces the squared total gradient norm into `norm_sq` (device scalar, ZERO on entry; it holds the squared norm afterwards),
+// the Adam launch scales every gradient by min(1, max_norm / (norm + 1e-6)) as it reads it.  The gradients are not modified.
+extern "C" int epi_adam_step_clipped(const void* table, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                                     long long step, float max_norm, float* norm_sq, epi_stream_t stream) {
+    if (!table || !chunks || !norm_sq || nchunks <= 0 || step < 1 || !(max_norm > 0.f)) return EPI_ERR_INVALID_ARGUMENT;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(epi::grad_sumsq_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
+                       (const epi::AdamTensor*)table, (const int2*)chunks, norm_sq);
+    EPI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(epi::adam_multi_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
+                       (const epi::AdamTensor*)table, (const int2*)chunks, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
+                       (const float*)norm_sq, max_norm);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

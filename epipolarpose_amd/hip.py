@@ -65,6 +65,9 @@ _SIGNATURES = {
     "epi_adam_tensor_bytes": (_sz, []),
     "epi_adam_chunk_elems": (_i, []),
     "epi_adam_step": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _vp]),
+    "epi_adam_step_clipped": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong,
+                                   ctypes.c_float, _vp, _vp]),
+    "epi_dropout_bf16": (_i, [_vp, _vp, ctypes.c_longlong, ctypes.c_float, ctypes.c_ulonglong, _vp]),
     "epi_crop_patches": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i, _i, _i, _vp,
                               _i, _i, _vp]),
     "epi_evaluate_poses": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -667,6 +670,23 @@ def adam_step(table_dev, chunks_dev, nchunks, lr, beta1, beta2, eps, step):
     ev = timer.start("epi_adam_step")
     _check(lib.epi_adam_step(_ptr(table_dev), _ptr(chunks_dev), nchunks, lr, beta1, beta2, eps, step, _stream()), "epi_adam_step")
     timer.stop(ev)
+
+
+def adam_step_clipped(table_dev, chunks_dev, nchunks, lr, beta1, beta2, eps, step, max_norm, norm_sq):
+    """Fused Adam with clip_grad_norm_(max_norm) folded in; ``norm_sq`` (zeroed f32 device scalar) receives the squared total norm."""
+    lib = load()
+    _check(lib.epi_adam_step_clipped(_ptr(table_dev), _ptr(chunks_dev), nchunks, lr, beta1, beta2, eps, step, max_norm, _ptr(norm_sq),
+                                     _stream()), "epi_adam_step_clipped")
+
+
+def dropout_bf16(x, p, seed, out=None):
+    """Inverted dropout of a bf16 tensor with a stateless (seed, index) mask; the same call on the gradient is the backward."""
+    lib = load()
+    _dev(x, torch.bfloat16, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x) if out is None else out
+    _check(lib.epi_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "epi_dropout_bf16")
+    return out
 
 
 def evaluate_poses(pred_img, gt_img, pelvis_z, fl, c_p, root, j14):

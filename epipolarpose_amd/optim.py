@@ -52,7 +52,11 @@ def _dense(t):
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, low_precision_convs=True):
+    def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, low_precision_convs=True, max_grad_norm=None):
+        """``max_grad_norm``: fold ``torch.nn.utils.clip_grad_norm_(params, max_grad_norm)`` into the step (reference refiner/main.py:53);
+        ``last_grad_norm_sq`` then holds the squared total norm of the step (device scalar)."""
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm_sq = None
         lp_modules = []
         if isinstance(model_or_params, nn.Module):
             params = [p for p in model_or_params.parameters() if p.requires_grad]
@@ -189,8 +193,13 @@ class FusedAdam(torch.optim.Optimizer):
             self._table_event.record()
         group = self.param_groups[0]
         self._step += 1
-        hip.adam_step(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
-                      group["eps"], self._step)
+        if self.max_grad_norm is not None:
+            self.last_grad_norm_sq = torch.zeros((), dtype=torch.float32, device=self._table_dev.device)
+            hip.adam_step_clipped(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
+                                  group["eps"], self._step, float(self.max_grad_norm), self.last_grad_norm_sq)
+        else:
+            hip.adam_step(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
+                          group["eps"], self._step)
         del keep
         self._pack_weights()                         # backward-data operands of the implicit-GEMM convolutions follow the update
         return loss

@@ -284,6 +284,15 @@ size_t epi_adam_tensor_bytes(void);
 int epi_adam_chunk_elems(void);
 int epi_adam_step(const void* table, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
                   long long step, epi_stream_t stream);
+/* The same with torch.nn.utils.clip_grad_norm_(parameters, max_norm) folded in (refiner/main.py:53-54): norm_sq is a device scalar,
+ * ZERO on entry, that receives the squared total gradient norm; every gradient is scaled by min(1, max_norm / (norm + 1e-6)) as the
+ * Adam launch reads it (the stored gradients are left untouched). */
+int epi_adam_step_clipped(const void* table, const void* chunks, int nchunks, float lr, float beta1, float beta2, float eps,
+                          long long step, float max_norm, float* norm_sq, epi_stream_t stream);
+
+/* Inverted dropout, bf16 (refiner/model.py:26: nn.Dropout(p)): y_i = keep_i ? x_i / (1 - p) : 0 with keep_i a stateless hash of
+ * (seed, i); calling it on the output gradient with the same seed IS the backward pass.  y may alias x. */
+int epi_dropout_bf16(const void* x, void* y, long long n, float p, unsigned long long seed, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Input pipeline -- replaces, per batch instead of per sample on the host, generate_patch_image_cv

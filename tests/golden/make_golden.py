@@ -362,7 +362,55 @@ def gen_evaluation():
     save("evaluation.npz", **out)
 
 
+
+# --------------------------------------------------------------------------------------------------
+# 7. refinement MLP: the reference's refiner/model.py executed live (fp32, CPU)
+# --------------------------------------------------------------------------------------------------
+REFINER_GRADS = ("w1.weight", "w1.bias", "w4.weight", "w2.bias", "batch_norm1.weight", "linear_stages.0.w2.weight",
+                 "linear_stages.1.w3.weight", "linear_stages.1.batch_norm3.bias", "linear_stages.0.batch_norm1.weight")
+
+
+def gen_refiner():
+    import importlib
+    rmodel = importlib.import_module("refiner.model")
+    out = {}
+    b, n = 64, 45
+    x = torch.from_numpy(seeded_array("refiner/x", (b, n)))
+    t = torch.from_numpy(seeded_array("refiner/t", (b, n)))
+    model = rmodel.LinearModelPG()                                   # defaults of refiner/main.py:102: 1024 wide, 2 stages, dropout 0.5
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    out["keys"] = np.array(list(shapes.keys()))
+    out["shapes"] = np.array([str(s) for s in shapes.values()])
+    model.load_state_dict(fill_state_dict(shapes, seed=3))
+    model.eval()
+    with torch.no_grad():
+        p1, p2 = model(x)
+    out["eval/p1"], out["eval/p2"] = p1.numpy(), p2.numpy()
+    m0 = rmodel.LinearModelPG(p_dropout=0.0)                         # training-mode arithmetic without the random mask
+    m0.load_state_dict(fill_state_dict(shapes, seed=3))
+    m0.train()
+    opt = torch.optim.Adam(m0.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss(reduction='mean')
+    p1, p2 = m0(x)
+    loss = crit(p1, t) + crit(p2, t)                                 # refiner/main.py:49
+    opt.zero_grad()
+    loss.backward()
+    out["train/p1"], out["train/p2"], out["train/loss"] = p1.detach().numpy(), p2.detach().numpy(), np.float32(loss.item())
+    grads = {k: p.grad.clone() for k, p in m0.named_parameters()}
+    sub = lambda a: a if a.size <= 20000 else a.reshape(-1)[::97].copy()      # noqa: E731  (large matrices: every 97th element)
+    for k in REFINER_GRADS:
+        out["train/grad/" + k] = sub(grads[k].numpy())
+    norm = torch.nn.utils.clip_grad_norm_(m0.parameters(), max_norm=1.)      # refiner/main.py:53
+    out["train/grad_norm"] = np.float32(float(norm))
+    before = {k: v.detach().clone() for k, v in m0.named_parameters()}
+    opt.step()
+    for k in ("w4.weight", "w1.bias", "linear_stages.0.w1.weight"):
+        out["train/delta/" + k] = sub((dict(m0.named_parameters())[k].detach() - before[k]).numpy())
+    out["train/running_mean"] = m0.state_dict()["batch_norm1.running_mean"].numpy()
+    save("refiner.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation"]
+    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation", "network_big", "refiner"]
     for w in which:
         globals()["gen_" + w]()

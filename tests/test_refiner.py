@@ -1,0 +1,142 @@
+"""Refinement MLP against the reference's refiner/model.py executed live in fp32 (tests/golden/refiner.npz):
+state_dict surface (CPU), forward in eval and training mode, two-headed MSE, gradients, clip_grad_norm_ + Adam step (GPU).
+Our arithmetic: bf16 MFMA operands with fp32 accumulation, bf16 activations -- tolerances are bf16-grade and stated per check."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from det_weights import fill_state_dict, seeded_array
+
+
+def _shapes(g):
+    return {k: ast.literal_eval(s) for k, s in zip(g["keys"].tolist(), g["shapes"].tolist())}
+
+
+def test_refiner_state_dict_surface_and_utils(golden):
+    import epipolarpose_amd
+    from epipolarpose_amd.refiner import LinearModelPG, get_model
+    from epipolarpose_amd.refiner.utils import lr_decay
+    g = golden("refiner")
+    m = LinearModelPG()
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["keys"].tolist()
+    assert [tuple(v.shape) for v in sd.values()] == list(_shapes(g).values())
+    m.load_state_dict(fill_state_dict(_shapes(g), seed=3))
+    assert get_model(None, input_size=48, output_size=48).w1.weight.shape == (1024, 48)
+    epipolarpose_amd.install_as_lib()
+    import refiner.model as rm                                            # the reference's import name (refiner/main.py:13)
+    assert rm.LinearModelPG is LinearModelPG
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    assert lr_decay(opt, 100000, 1e-3, 100000, 0.96) == pytest.approx(0.96e-3) and opt.param_groups[0]["lr"] == pytest.approx(0.96e-3)
+
+
+def _sub(a, ref):
+    a = a.reshape(-1)
+    return a if a.size == ref.size else a[::97]
+
+
+@pytest.mark.gpu
+def test_refiner_forward_backward_and_clipped_adam_vs_reference(golden):
+    from epipolarpose_amd.refiner import LinearModelPG
+    from epipolarpose_amd.refiner.main import TwoHeadMSE, make_optimizer
+    g = golden("refiner")
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(seeded_array("refiner/x", (64, 45))).to(dev)
+    t = torch.from_numpy(seeded_array("refiner/t", (64, 45))).to(dev)
+    model = LinearModelPG().to(dev)
+    model.load_state_dict(fill_state_dict(_shapes(g), seed=3))
+    model.eval()
+    with torch.no_grad():
+        p1, p2 = model(x)
+    for got, key in ((p1, "eval/p1"), (p2, "eval/p2")):
+        ref = g[key]
+        assert np.abs(got.cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max(), key             # bf16 operands through 14 GEMMs
+    m0 = LinearModelPG(p_dropout=0.0).to(dev)
+    m0.load_state_dict(fill_state_dict(_shapes(g), seed=3))
+    m0.train()
+    opt = make_optimizer(m0, lr=1e-3)
+    p1, p2 = m0(x)
+    for got, key in ((p1, "train/p1"), (p2, "train/p2")):
+        ref = g[key]
+        assert np.abs(got.detach().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max(), key
+    loss = TwoHeadMSE()((p1, p2), t)
+    np.testing.assert_allclose(loss.item(), g["train/loss"], rtol=2e-2)
+    opt.zero_grad()
+    loss.backward()
+    grads = dict(m0.named_parameters())
+    for key in [k for k in g if k.startswith("train/grad/")]:
+        name = key[len("train/grad/"):]
+        ref = g[key].reshape(-1)
+        got = _sub(grads[name].grad.float().cpu().numpy(), ref)
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
+        assert cos >= 0.995, (name, cos)
+        assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) <= 3e-2, name
+    before = {k: grads[k].detach().clone() for k in ("w4.weight", "w1.bias", "linear_stages.0.w1.weight")}
+    opt.step()
+    np.testing.assert_allclose(float(opt.last_grad_norm_sq.sqrt().item()), g["train/grad_norm"], rtol=2e-2)
+    for k, b in before.items():
+        ref = g["train/delta/" + k].reshape(-1)
+        got = _sub((grads[k].detach() - b).float().cpu().numpy(), ref)
+        # the first Adam step moves every weight by lr * sign(g) (|delta| = 1e-3 up to eps): compare where the reference gradient is not ~0
+        agree = np.mean(np.sign(got) == np.sign(ref))
+        assert agree >= 0.97, (k, agree)
+        np.testing.assert_allclose(np.abs(got).mean(), np.abs(ref).mean(), rtol=5e-2)
+    np.testing.assert_allclose(m0.state_dict()["batch_norm1.running_mean"].cpu().numpy(), g["train/running_mean"], atol=2e-2 * np.abs(g["train/running_mean"]).max() + 1e-4)
+
+
+@pytest.mark.gpu
+def test_dropout_kernel_statistics_and_backward_mask():
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    x = torch.ones(1 << 20, dtype=torch.bfloat16, device=dev)
+    y = hip.dropout_bf16(x, 0.5, seed=123)
+    keep = (y != 0)
+    assert abs(float(keep.float().mean()) - 0.5) < 5e-3 and float(y[keep].float().mean()) == 2.0
+    y2 = hip.dropout_bf16(x, 0.5, seed=123)
+    assert torch.equal(y, y2) and not torch.equal(y, hip.dropout_bf16(x, 0.5, seed=124))
+    k = keep.view(1024, 1024).float()
+    assert abs(float((k[:, :-1] * k[:, 1:]).mean()) - 0.25) < 5e-3                  # neighbouring elements are independent
+    y3 = hip.dropout_bf16(x, 0.2, seed=9)
+    assert abs(float((y3 != 0).float().mean()) - 0.8) < 5e-3 and float(y3.max()) == 1.25
+    # the refiner trains (loss falls) with dropout on, and the module's backward reuses the forward mask
+    from epipolarpose_amd.refiner import LinearModelPG
+    from epipolarpose_amd.refiner.main import TwoHeadMSE, make_optimizer
+    torch.manual_seed(0)
+    m = LinearModelPG().to(dev)
+    opt = make_optimizer(m, lr=1e-3)
+    xin = torch.randn(64, 45, device=dev)
+    tgt = 0.5 * xin
+    crit = TwoHeadMSE()
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = crit(m(xin), tgt)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.gpu
+def test_refiner_train_and_test_loops():
+    from types import SimpleNamespace
+    from epipolarpose_amd.refiner import LinearModelPG, weight_init
+    from epipolarpose_amd.refiner.data import SyntheticLift
+    from epipolarpose_amd.refiner.main import TwoHeadMSE, make_optimizer, test, train
+    torch.manual_seed(1)
+    tr = SyntheticLift(True, n=256)
+    va = SyntheticLift(False, n=128, norm=tr.norm())
+    train_dl = torch.utils.data.DataLoader(tr, batch_size=64, shuffle=True)
+    test_dl = torch.utils.data.DataLoader(va, batch_size=64, shuffle=False)
+    model = LinearModelPG().cuda()
+    model.apply(weight_init)
+    opt = make_optimizer(model, lr=1e-3)
+    args = SimpleNamespace(lr=1e-3, lr_decay=100000, lr_gamma=0.96)
+    step, lr_now, first = train(model, train_dl, opt, 0, 1e-3, TwoHeadMSE(), args)
+    for _ in range(4):
+        step, lr_now, last = train(model, train_dl, opt, step, lr_now, TwoHeadMSE(), args)
+    assert step == 20 and last < first
+    err, err_align = test(model, test_dl)
+    assert np.isfinite(err) and err_align <= err + 1e-6
