@@ -250,6 +250,8 @@ def build_roofline(args, ksum, glue_times, model, images):
         out = {"kernel": "softargmax_bwd_kernel", "bound": "hbm", "achieved": e.get("achieved_gbs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": e.get("frac"), "traffic": None}
     out["families"] = fam
+    out["measured"] = ("HIP events on the launch stream around every launch, over `steps` additional steps of the same workload right after "
+                       "the timed region (recording them inside it makes the step host-bound and would falsify `value`)")
     out["note"] = "traffic: not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*pmc*)"
     return out
 
@@ -305,10 +307,6 @@ def main():
     host_one = time.perf_counter() - th              # into an empty queue, i.e. without back-pressure from the GPU
     torch.cuda.synchronize()
     barrier()
-    hip.timer.reset()
-    hip.timer.enabled = not use_graph            # events cannot be recorded inside a replayed graph
-    hip.glue().timing_collect()                  # (clears) -- the C++ glue's launches carry their own HIP events
-    hip.glue().timing_enable(not use_graph)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -317,9 +315,21 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    hip.timer.enabled = False
-    hip.glue().timing_enable(False)
-    glue_times = hip.glue().timing_collect()
+    # Per-kernel durations for the roofline: the SAME step, `steps` more times, now with a HIP event pair around every launch
+    # (on the launch stream).  Kept out of the timed region above: ~660 hipEventRecord calls per step cost the host ~8 us each on
+    # ROCm 7.2 and turn the step host-bound (10.9 ms instead of 8.9 ms measured), which would falsify `value`.
+    glue_times = {}
+    if not use_graph:
+        hip.timer.reset()
+        hip.timer.enabled = True
+        hip.glue().timing_collect()              # (clears) -- the C++ glue's launches carry their own HIP events
+        hip.glue().timing_enable(True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        hip.timer.enabled = False
+        hip.glue().timing_enable(False)
+        glue_times = hip.glue().timing_collect()
     if use_graph:
         # per-kernel durations for the roofline: the same criterion kernels on the same resident logits-sized tensor,
         # launched eagerly with HIP events on the launch stream right after the timed region

@@ -6,6 +6,7 @@
 //   lib/utils/img_utils.py:63-111,141-243, lib/utils/triangulation.py:8-181, lib/utils/prep_h36m.py:170-204.
 // One thread owns one (group, joint); the fused kernel keeps the whole SS step in ONE launch.
 #include "common.h"
+#include <type_traits>
 #include "linalg3.h"
 
 namespace epi {
@@ -499,6 +500,162 @@ EPI_HD inline int fundamental_8point_one(const double* u1, const double* u2, int
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Bulk (fp32-storage) variants.  The drop-in float64 path above follows the reference operation by operation (Householder QR of
+// the 2V x 3 system per re-weighting round, one-sided Jacobi SVD of the 2V x 4 system) and is fp64-VALU-bound: ~3000 float64
+// operations and ~200 live registers per joint.  When the inputs are float32 anyway (tolerance 1e-2 mm, include/epipolar_hip.h)
+// the same iteration runs on 3 x 3 normal equations:  every re-weighting round scales BOTH rows of view v by 1/d_v, so
+// A^T W^2 A = sum_v s_v G_v with G_v = a_v0 a_v0^T + a_v1 a_v1^T (6 numbers per view) fixed and only s_v = prod 1/d_v^2 changing:
+// ~25 fused multiply-adds to rebuild, a closed-form symmetric 3 x 3 solve, V depths -- an order of magnitude fewer float64
+// operations and a quarter of the registers.  cond(A)^2 ~ 1e4 costs ~1e-12 relative in float64: far inside the float32 envelope.
+// ---------------------------------------------------------------------------------------------------------------------
+EPI_HD __forceinline__ void solve_sym3(const double (&n)[6], const double (&r)[3], double (&x)[3]) {
+    // n = (n00, n01, n02, n11, n12, n22); adjugate / determinant
+    const double c00 = n[3] * n[5] - n[4] * n[4], c01 = n[2] * n[4] - n[1] * n[5], c02 = n[1] * n[4] - n[2] * n[3];
+    const double c11 = n[0] * n[5] - n[2] * n[2], c12 = n[1] * n[2] - n[0] * n[4], c22 = n[0] * n[3] - n[1] * n[1];
+    const double inv = 1.0 / (n[0] * c00 + n[1] * c01 + n[2] * c02);
+    x[0] = (c00 * r[0] + c01 * r[1] + c02 * r[2]) * inv;
+    x[1] = (c01 * r[0] + c11 * r[1] + c12 * r[2]) * inv;
+    x[2] = (c02 * r[0] + c12 * r[1] + c22 * r[2]) * inv;
+}
+
+template <int NV>
+EPI_HD __forceinline__ int tri_iterative_ne(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double tol, int max_iter,
+                                            double (&x)[3]) {
+    double G[NV][6], h[NV][3], s[NV], d[NV], dn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool on = v < nv;
+        double a[2][3], b[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[r][c] = on ? (u[v][r] * P[v][8 + c] - P[v][4 * r + c]) : 0.0;     // triangulation.py:138-148
+            b[r] = on ? (P[v][4 * r + 3] - u[v][r] * P[v][11]) : 0.0;
+        }
+        G[v][0] = a[0][0] * a[0][0] + a[1][0] * a[1][0]; G[v][1] = a[0][0] * a[0][1] + a[1][0] * a[1][1];
+        G[v][2] = a[0][0] * a[0][2] + a[1][0] * a[1][2]; G[v][3] = a[0][1] * a[0][1] + a[1][1] * a[1][1];
+        G[v][4] = a[0][1] * a[0][2] + a[1][1] * a[1][2]; G[v][5] = a[0][2] * a[0][2] + a[1][2] * a[1][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) h[v][c] = a[0][c] * b[0] + a[1][c] * b[1];
+        s[v] = 1.0; d[v] = 1.0; dn[v] = 1.0;                                                               // :151
+    }
+    x[0] = x[1] = x[2] = 0;
+    for (int it = 0; it < max_iter; ++it) {                                                                // :153
+        double n[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) n[k] = fma(s[v], G[v][k], n[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r[k] = fma(s[v], h[v][k], r[k]);
+        }
+        solve_sym3(n, r, x);                                                                               // :155
+        bool conv = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                dn[v] = P[v][8] * x[0] + P[v][9] * x[1] + P[v][10] * x[2] + P[v][11];                      // :158-159
+                if (!(fabs(dn[v] - d[v]) <= tol)) conv = false;                                            // :161-162
+            }
+        }
+        if (conv) break;                                                                                   // :163
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                const double w = 1.0 / dn[v];                                                              // :166-169 (cumulative)
+                s[v] *= w * w;
+                d[v] = dn[v];
+            }
+        }
+    }
+    bool all_front = true;
+    int code = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+            if (!(dn[v] > 0)) all_front = false;
+            if (dn[v] <= 0) code -= (1 << v);                                                              // :178-179
+        }
+    }
+    return all_front ? 1 : code;
+}
+
+// Homogeneous DLT for fp32-storage bulk batches: the right-singular vector of the smallest singular value of the 2V x 4 system
+// M is the eigenvector of the smallest eigenvalue of the 4 x 4 Gram matrix M^T M -- found by inverse iteration on its (shifted)
+// LDL^T factorisation instead of a Jacobi SVD of M.  The eigenvalue gap is enormous (lambda_4 / lambda_3 = noise^2), three
+// solves converge to float64 round-off; squaring the condition number (1e4 -> 1e8) costs 1e-8 relative, inside the fp32 envelope.
+template <int NV>
+EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
+    double g[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[a][b] = 0.0;
+    double scale2 = 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                double m[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[c] = u[v][r] * P[v][8 + c] - P[v][4 * r + c];                 // cv2.triangulatePoints rows
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = a; b < 4; ++b) g[a][b] = fma(m[a], m[b], g[a][b]);
+            }
+        }
+    }
+    scale2 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
+    const double shift = 1e-14 * scale2;                 // keeps the factorisation regular when the matches are exact (lambda_4 = 0)
+    // LDL^T of (G + shift I), unit lower triangular L stored in the lower part
+    double L[4][4], D[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double dj = g[j][j] + shift;
+#pragma unroll
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * D[k];
+        D[j] = dj;
+        const double inv = 1.0 / dj;
+#pragma unroll
+        for (int i = j + 1; i < 4; ++i) {
+            double t = g[j][i];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = t * inv;
+        }
+    }
+    double hv[4] = {0.5, 0.5, 0.5, 0.5};
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        double y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                   // L y = h
+            double t = hv[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= L[i][k] * y[k];
+            y[i] = t;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] /= D[i];
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {                  // L^T z = y
+            double t = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 4; ++k) t -= L[k][i] * y[k];
+            y[i] = t;
+        }
+        const double nrm = 1.0 / sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hv[i] = y[i] * nrm;
+    }
+    x[0] = hv[0] / hv[3]; x[1] = hv[1] / hv[3]; x[2] = hv[2] / hv[3];                                      // triangulation.py:24
+    const double mx = fmax(fabs(x[0]), fmax(fabs(x[1]), fabs(x[2])));
+    return (mx <= 1.0e16) ? 1 : 0;                                                                         // :25
+}
+
 enum { TRI_ITER = 0, TRI_LS = 1, TRI_DLT = 2, TRI_POLY = 3 };
 
 template <typename T, int NV, int METHOD>
@@ -550,8 +707,12 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ 
         fundamental_from_P(P[0], P[1], F);
         correct_match(F, u[0], u[1]);
         st = tri_dlt<NV>(u, P, V, x);
-    } else if constexpr (METHOD == TRI_DLT) st = tri_dlt<NV>(u, P, V, x);
-    else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
+    } else if constexpr (METHOD == TRI_DLT) {
+        if constexpr (std::is_same<S, float>::value) st = tri_dlt_gram<NV>(u, P, V, x);       // bulk fp32 storage: Gram + inverse iteration
+        else st = tri_dlt<NV>(u, P, V, x);
+    } else if constexpr (METHOD == TRI_ITER && std::is_same<S, float>::value) {
+        st = tri_iterative_ne<NV>(u, P, V, tol, max_iter, x);                                 // bulk fp32 storage: 3 x 3 normal equations
+    } else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
     X[3 * t] = (S)x[0]; X[3 * t + 1] = (S)x[1]; X[3 * t + 2] = (S)x[2];
     if (status) status[t] = st;
 }
