@@ -509,11 +509,23 @@ EPI_HD inline int fundamental_8point_one(const double* u1, const double* u2, int
 // ~25 fused multiply-adds to rebuild, a closed-form symmetric 3 x 3 solve, V depths -- an order of magnitude fewer float64
 // operations and a quarter of the registers.  cond(A)^2 ~ 1e4 costs ~1e-12 relative in float64: far inside the float32 envelope.
 // ---------------------------------------------------------------------------------------------------------------------
+// 1 / x to float64 round-off without the IEEE division sequence (~30 instructions on gfx950): hardware estimate + two Newton steps
+EPI_HD __forceinline__ double fast_rcp(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / v;
+#endif
+}
+
 EPI_HD __forceinline__ void solve_sym3(const double (&n)[6], const double (&r)[3], double (&x)[3]) {
     // n = (n00, n01, n02, n11, n12, n22); adjugate / determinant
     const double c00 = n[3] * n[5] - n[4] * n[4], c01 = n[2] * n[4] - n[1] * n[5], c02 = n[1] * n[4] - n[2] * n[3];
     const double c11 = n[0] * n[5] - n[2] * n[2], c12 = n[1] * n[2] - n[0] * n[4], c22 = n[0] * n[3] - n[1] * n[1];
-    const double inv = 1.0 / (n[0] * c00 + n[1] * c01 + n[2] * c02);
+    const double inv = fast_rcp(n[0] * c00 + n[1] * c01 + n[2] * c02);
     x[0] = (c00 * r[0] + c01 * r[1] + c02 * r[2]) * inv;
     x[1] = (c01 * r[0] + c11 * r[1] + c12 * r[2]) * inv;
     x[2] = (c02 * r[0] + c12 * r[1] + c22 * r[2]) * inv;
@@ -563,7 +575,7 @@ EPI_HD __forceinline__ int tri_iterative_ne(const double (&u)[NV][2], const doub
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             if (v < nv) {
-                const double w = 1.0 / dn[v];                                                              // :166-169 (cumulative)
+                const double w = fast_rcp(dn[v]);                                                          // :166-169 (cumulative)
                 s[v] *= w * w;
                 d[v] = dn[v];
             }

@@ -70,6 +70,9 @@ def test_refiner_forward_backward_and_clipped_adam_vs_reference(golden):
         name = key[len("train/grad/"):]
         ref = g[key].reshape(-1)
         got = _sub(grads[name].grad.float().cpu().numpy(), ref)
+        if np.linalg.norm(ref) < 1e-5:          # a bias in front of a training-mode BatchNorm: its gradient is mathematically zero
+            assert np.linalg.norm(got) < 5e-2, (name, np.linalg.norm(got))     # (reference 1e-7 of fp32 round-off, ours bf16 round-off)
+            continue
         cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
         assert cos >= 0.98, (name, cos)            # bf16 operands through up to 14 GEMMs back to the first layer (measured 0.989 .. 0.999)
         assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) <= 3e-2, name
