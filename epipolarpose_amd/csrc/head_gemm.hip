@@ -81,6 +81,7 @@ struct GemmArgs {
     GemmPhases ph;         // enabled: K = the LARGEST phase's extent (split-K planning); ldb is per phase ntap * Cs
     int k_per_split;       // split-K: blockIdx.y handles K range [y*k_per_split, ...) and writes an fp32 slab (plain rows)
     float* slabs;          // [nsplit][nphase][M][N] when gridDim.y > 1
+    const unsigned short* addend;   // bf16 [same rows / stride as C] or null: C = A*B + addend (the other branch's gradient at a residual junction)
     float* stats;          // [2N] or null: += per-column (sum, sum of squares) of the bf16 result (unsplit bf16 launches only)
     int coalesce;          // bf16 result with N % 8 == 0, ldc % 8 == 0: LDS-staged 128-byte row segments
 };
@@ -104,6 +105,18 @@ __device__ uint4v epi_zero_chunk[1];
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// eight bf16 values + eight bf16 values, in fp32, rounded back (the residual-junction add of the backward pass)
+__device__ __forceinline__ uint4v add_bf16x8(uint4v a, uint4v b) {
+    const unsigned int aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    unsigned int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = pack_bf16x2(__uint_as_float(aw[k] << 16) + __uint_as_float(bw[k] << 16),
+                           __uint_as_float(aw[k] & 0xffff0000u) + __uint_as_float(bw[k] & 0xffff0000u));
+    uint4v r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    return r;
 }
 
 enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
@@ -392,6 +405,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                 orow = ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
             }
             uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+            if (p.addend) o = add_bf16x8(o, *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n));
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
         }
         if (p.stats) {
@@ -439,6 +453,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                         else for (int e = 0; e < 4 && n + e < p.N; ++e) c[e] = v[e];
                     } else {
                         unsigned short* c = reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n;
+                        if (p.addend)
+                            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] = bf16_to_f32(f32_to_bf16(v[e])) + bf16_to_f32(p.addend[orow * p.ldc + n + e]);
                         if (n + 3 < p.N) {
                             uint2 t;
                             t.x = pack_bf16x2(v[0], v[1]);
@@ -593,6 +609,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
             const int m = m0 + row;
             if (m < p.M && n < p.N) {
                 uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+                if (p.addend) o = add_bf16x8(o, *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + n));
                 *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
                 if (p.stats) {      // BatchNorm statistics of the bf16-rounded outputs (see head_gemm_kernel's epilogue)
                     const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
@@ -655,6 +672,11 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
     if (OUT_F32) {
         *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = a;
     } else {
+        if (p.addend) {
+            const uint2 r = *reinterpret_cast<const uint2*>(p.addend + orow * p.ldc + n);
+            a.x = bf16_to_f32(f32_to_bf16(a.x)) + __uint_as_float(r.x << 16); a.y = bf16_to_f32(f32_to_bf16(a.y)) + __uint_as_float(r.x & 0xffff0000u);
+            a.z = bf16_to_f32(f32_to_bf16(a.z)) + __uint_as_float(r.y << 16); a.w = bf16_to_f32(f32_to_bf16(a.w)) + __uint_as_float(r.y & 0xffff0000u);
+        }
         uint2 o;
         o.x = pack_bf16x2(a.x, a.y);
         o.y = pack_bf16x2(a.z, a.w);
@@ -778,6 +800,7 @@ static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hi
 // the caller then computes the statistics with its own pass
 static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr) {
     if (stats_done) *stats_done = 0;
+    if (a.addend && (out_f32 || (reinterpret_cast<uintptr_t>(a.addend) & 15u))) return EPI_ERR_UNSUPPORTED;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
     // BatchNorm statistics from the GEMM epilogue are OFF by default (EPI_FUSE_BN_STATS=1 enables them): measured on MI355X the
     // per-channel fp32 atomics of 512 .. 2048 workgroups on the same 64 .. 256 addresses serialise in L2 at ~200 ns each -- the
@@ -1260,15 +1283,17 @@ extern "C" int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, 
     return launch_tn(a, C, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// dw[Cin][16 taps][Cout] (f32, tap = kh*4 + kw) of ConvTranspose2d(k4 s2 p1): x [B][H][W][Cin], dy [B][2H][2W][Cout]
-extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
+// dw[Cin][16 taps][Cout] (f32 or bf16, tap = kh*4 + kw: the memory order of a channels_last [Cin, Cout, 4, 4] weight) of
+// ConvTranspose2d(k4 s2 p1): x [B][H][W][Cin], dy [B][2H][2W][Cout]
+extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, void* dw_taps, int dw_dtype, int B, int H, int W, int Cin, int Cout,
                                           void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16) return EPI_ERR_UNSUPPORTED;
     GemmTnArgs a = {};
     a.A = (const unsigned short*)x; a.B = (const unsigned short*)dy; a.R = B * H * W; a.I = Cin; a.J = 16 * Cout; a.lda = Cin; a.ldb = Cout;
     // the input pixel (ih, iw) reaches the output pixels (2*ih - 1 + kh, 2*iw - 1 + kw)
     a.gather = 1; a.Hg = H; a.Wg = W; a.Hs = 2 * H; a.Ws = 2 * W; a.Cs = Cout; a.stride = 2; a.pad = 1; a.KW = 4;
-    return launch_tn(a, dw_taps, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_tn(a, dw_taps, dw_dtype == EPI_BF16, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // Weight gradient of a Conv2d (groups = 1, dilation = 1), NHWC bf16:  x [B][H][W][Cin], dy [B][Ho][Wo][Cout]  ->
@@ -1413,6 +1438,46 @@ static int conv_pack_args(PackArgs* a, const void* w, void* w_bwd, int Cout, int
     return EPI_OK;
 }
 
+// ConvTranspose2d(k4 s2 p1) weight in channels_last memory [Cin][kh][kw][Cout] (which IS the backward-data operand [Cin][16*Cout])
+// -> the forward operand w_phase [4][Cout][4*Cin]: per tap a (Cin x Cout) -> (Cout x Cin) transpose, i.e. the same tile kernel with
+// the roles of the two channel counts exchanged.  Tap (kh, kw) belongs to output parity ph = kh even, position ty (see
+// epi_deconv4x4s2_pack_weight).
+static int deconv_phase_pack_args(PackArgs* a, const void* w_cl, void* w_phase, int Cin, int Cout) {
+    if (!w_cl || !w_phase || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    *a = PackArgs();
+    a->w = (const unsigned short*)w_cl; a->out = (unsigned short*)w_phase; a->Cout = Cin; a->Cin = Cout; a->ntap = 16;
+    a->tiles_ci = (Cout + 31) / 32; a->tiles_co = (Cin + 31) / 32;
+    for (int kh = 0; kh < 4; ++kh)
+        for (int kw = 0; kw < 4; ++kw) {
+            const int ph = (kh & 1) ? 0 : 1, ty = ph ? (kh == 0 ? 0 : 1) : (kh == 1 ? 0 : 1);
+            const int pw = (kw & 1) ? 0 : 1, tx = pw ? (kw == 0 ? 0 : 1) : (kw == 1 ? 0 : 1);
+            a->dst_base[kh * 4 + kw] = ((long long)(2 * ph + pw) * Cout * 4 + (2 * ty + tx)) * Cin;
+            a->dst_ci_stride[kh * 4 + kw] = 4 * Cin;
+        }
+    return EPI_OK;
+}
+
+extern "C" int epi_deconv4x4s2_pack_phase_cl(const void* w_cl, int Cin, int Cout, void* w_phase, epi_stream_t stream) {
+    PackArgs a;
+    const int rc = deconv_phase_pack_args(&a, w_cl, w_phase, Cin, Cout);
+    if (rc != EPI_OK) return rc;
+    hipLaunchKernelGGL(epi::conv_pack_weight_bwd_kernel, dim3((unsigned)a.tiles_ci, (unsigned)a.tiles_co, 16u), dim3(256), 0, (hipStream_t)stream, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_deconv4x4s2_pack_fill_row(void* row_host, const void* w_cl, void* w_phase, int Cin, int Cout, long long tile_begin,
+                                             long long* ntiles) {
+    if (!row_host || !ntiles) return EPI_ERR_INVALID_ARGUMENT;
+    PackArgs a;
+    const int rc = deconv_phase_pack_args(&a, w_cl, w_phase, Cin, Cout);
+    if (rc != EPI_OK) return rc;
+    a.tile_begin = tile_begin;
+    *reinterpret_cast<PackArgs*>(row_host) = a;
+    *ntiles = (long long)a.tiles_ci * a.tiles_co * a.ntap;
+    return EPI_OK;
+}
+
 extern "C" size_t epi_conv2d_pack_row_bytes(void) { return sizeof(PackArgs); }
 
 extern "C" int epi_conv2d_pack_fill_row(void* row_host, const void* w, void* w_bwd, int Cout, int Cin, int KH, int KW, int stride,
@@ -1484,7 +1549,8 @@ extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int 
 }
 
 extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
-                                   int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+                                   int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
+                                   epi_stream_t stream) {
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
@@ -1493,6 +1559,7 @@ extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, 
     if (!conv_bwd_layout(KH, KW, stride, pad, Cin, Cout, &L) || Cin % 4) return EPI_ERR_UNSUPPORTED;
     GemmArgs a = {};
     a.A = (const unsigned short*)dy; a.Bt = (const unsigned short*)w_bwd; a.C = dx; a.N = Cin; a.ldc = Cin;
+    a.addend = (const unsigned short*)addend;
     if (stride == 1) {
         a.M = B * H * W; a.K = KH * KW * Cout; a.ldb = KH * KW * Cout;
         if (KH == 1 && KW == 1 && pad == 0) {

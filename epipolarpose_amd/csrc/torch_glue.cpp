@@ -11,6 +11,7 @@
 //                 stage of BasicBlock / Bottleneck, pose3d_resnet.py:31-47,68-88)   4 backward
 //   adam_prepare  the per-step pointer table of FusedAdam (170 parameters) without a Python loop
 #include <torch/extension.h>
+#include <torch/custom_class.h>
 #include <c10/hip/HIPStream.h>
 
 #include <hip/hip_runtime_api.h>
@@ -211,10 +212,11 @@ Tensor bn_act(Tensor x, Tensor weight, Tensor bias, c10::optional<Tensor> residu
                         bwd_sums, flags, training, momentum, eps, relu);
 }
 
-// ---- Conv2d -> BatchNorm (+ residual) (+ ReLU) as ONE autograd node ------------------------------------------------
+// ---- Conv2d -> BatchNorm (+ residual) (+ ReLU): the stage shared by conv_bn_act (one stage = one autograd node) and residual_unit
+//      (a whole BasicBlock / Bottleneck = one node) ------------------------------------------------------------------------
 // w: [Cout, Cin, k, k], bf16 training copy (gradient returned in bf16, channels_last order) or the fp32 master (converted per
 // call, gradient returned in fp32); w_bwd: the packed backward-data operand kept up to date by the optimizer
-// (epi_conv2d_pack_weight_bwd_multi after every step), or None -> packed here.
+// (epi_conv2d_pack_weight_bwd_multi after every step), or undefined / empty -> packed here.
 inline Tensor channels_last_bf16_weight(const Tensor& w) {
     Tensor w16 = w.scalar_type() == at::kBFloat16 ? w : w.to(at::kBFloat16);
     if (w16.is_contiguous(at::MemoryFormat::ChannelsLast)) return w16;
@@ -222,112 +224,149 @@ inline Tensor channels_last_bf16_weight(const Tensor& w) {
     return w16.contiguous(at::MemoryFormat::ChannelsLast);
 }
 
+struct StageParams {      // what the Python side hands over per conv/bn pair
+    Tensor w, w_bwd, gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags;
+    int64_t stride, pad;
+    bool relu;
+};
+constexpr int STAGE_TENSORS = 10;
+
+struct StageSaved {       // what a stage's backward needs
+    Tensor x, raw, y, stats, gamma, wb, sums_ws, bwd_sums, flags;
+    std::vector<int64_t> w_sizes, w_strides;
+    int K, S, P;
+    bool relu, has_res, w_f32, need_dx;
+};
+
+Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& residual, bool training, double momentum, double eps, bool need_dx,
+                     StageSaved* save) {
+    Tensor x = x_in;
+    TORCH_CHECK(x.is_cuda() && sp.w.is_cuda(), "conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
+    if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+    const Tensor& w = sp.w;
+    TORCH_CHECK(w.dim() == 4 && w.size(1) == x.size(1) && w.size(2) == w.size(3), "conv_bn_act: weight shape");
+    const bool has_res = residual.defined();
+    const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
+    const int Cout = (int)w.size(0), K = (int)w.size(2), S = (int)sp.stride, P = (int)sp.pad;
+    const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
+    const Tensor w16 = channels_last_bf16_weight(w.detach());
+    Tensor raw = at::empty({B, Cout, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+    Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
+    int sums_done = 0;
+    Tensor sums_ws = sp.sums_ws;
+    if (training) {             // the accumulator hand-over of bn_forward, done here because the GEMM epilogue may fill sums_ws
+        int* fl = sp.flags.data_ptr<int>();
+        if (fl[0]) sums_ws.zero_();
+        fl[0] = 1;
+        fl[1] = 0;
+    }
+    const double conv_flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
+    const double conv_bytes = 2.0 * ((double)x.numel() + (double)raw.numel() + (double)w.numel());
+    {
+        ScopedTimer timer("conv_fwd", conv_flops, conv_bytes, current_stream(x));
+        check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                             training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(),
+                             (size_t)ws.numel(), current_stream(x)),
+              "epi_conv2d_fwd");
+    }
+    BnBuffers b{sp.gamma, sp.beta, sp.running_mean, sp.running_var, sp.num_batches, sp.sums_ws, sp.bwd_sums, sp.flags};
+    Tensor stats;
+    Tensor y;
+    if (training && !sums_done) {       // the statistics pass runs separately; re-arm the flag protocol for bn_forward
+        sp.flags.data_ptr<int>()[0] = 0;
+        y = bn_forward(raw, residual, b, training, momentum, eps, sp.relu, &stats, false);
+    } else {
+        y = bn_forward(raw, residual, b, training, momentum, eps, sp.relu, &stats, training);
+    }
+    if (training && save) {
+        Tensor wb;
+        if (need_dx) {                              // backward-data operand: the optimizer's packed copy, or packed now
+            if (sp.w_bwd.defined() && sp.w_bwd.numel() == w.numel()) {
+                wb = sp.w_bwd;
+                TORCH_CHECK(wb.scalar_type() == at::kBFloat16, "conv_bn_act: packed weight dtype");
+            } else {
+                wb = at::empty({w.numel()}, w16.options().memory_format(at::MemoryFormat::Contiguous));
+                check(epi_conv2d_pack_weight_bwd(w16.data_ptr(), Cout, Cin, K, K, S, P, wb.data_ptr(), current_stream(x)),
+                      "epi_conv2d_pack_weight_bwd");
+            }
+        }
+        save->x = x; save->raw = raw;
+        // a detached alias: the returned tensor itself will carry this node as grad_fn -- holding it would close a reference cycle
+        save->y = (sp.relu && has_res) ? y.detach() : Tensor(); save->stats = stats; save->gamma = sp.gamma; save->wb = wb;
+        save->sums_ws = sp.sums_ws; save->bwd_sums = sp.bwd_sums; save->flags = sp.flags;
+        save->w_sizes = w.sizes().vec();
+        save->w_strides = (w.is_contiguous(at::MemoryFormat::ChannelsLast) || (K == 1 && w.is_contiguous())) ? w.strides().vec() : w16.strides().vec();
+        save->K = K; save->S = S; save->P = P; save->relu = sp.relu; save->has_res = has_res; save->w_f32 = w.scalar_type() != at::kBFloat16;
+        save->need_dx = need_dx;
+    }
+    return y;
+}
+
+struct StageGrads { Tensor dx, dw, dgamma, dbeta, dres; };
+
+// dy: gradient of the stage output; addend: added to dx in the backward-data epilogue (the other branch of a residual junction)
+StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, bool need_dw, const Tensor& addend) {
+    BnGrads g = bn_backward(dy, sv.raw, sv.y, sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, sv.has_res);
+    const Tensor& x = sv.x;
+    const int K = sv.K, S = sv.S, P = sv.P;
+    const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)sv.raw.size(1);
+    const int Ho = (int)sv.raw.size(2), Wo = (int)sv.raw.size(3);
+    StageGrads out;
+    out.dgamma = g.dgamma; out.dbeta = g.dbeta; out.dres = g.dres;
+    if (need_dx) {
+        TORCH_CHECK(sv.wb.defined(), "conv_bn_act: input gradient requested but no backward-data weight was prepared");
+        if (addend.defined()) TORCH_CHECK(nhwc_bf16(addend) && addend.sizes() == x.sizes(), "conv_bn_act: residual-junction addend layout");
+        out.dx = at::empty_like(x);
+        Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
+        ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
+                          2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)sv.wb.numel()), current_stream(x));
+        check(epi_conv2d_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                                  addend.defined() ? addend.data_ptr() : nullptr, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
+              "epi_conv2d_bwd_data");
+    }
+    if (need_dw) {
+        out.dw = at::empty_strided(sv.w_sizes, sv.w_strides, x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
+        Tensor& ws = workspace(epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K), x);
+        ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
+                          2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), current_stream(x));
+        check(epi_conv2d_bwd_weight(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, K, K, S,
+                                    P, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
+              "epi_conv2d_bwd_weight");
+    }
+    return out;
+}
+
+// The saved state of a node lives in a small holder object kept alive by the autograd context (an IValue capsule, released with the
+// graph): tensors inside
+// are plain references (the differentiable inputs among them -- x of the first stage -- are recorded through save_for_backward).
+struct SavedHolder : torch::CustomClassHolder {
+    std::vector<StageSaved> stages;
+    bool has_downsample = false;
+    int n_main = 0;
+};
+
 struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, c10::optional<Tensor> w_bwd_opt, int64_t stride, int64_t pad, Tensor gamma,
                           Tensor beta, c10::optional<Tensor> residual_opt, Tensor running_mean, Tensor running_var, Tensor num_batches,
                           Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
-        TORCH_CHECK(x.is_cuda() && w.is_cuda(), "conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
-        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
-        TORCH_CHECK(w.dim() == 4 && w.size(1) == x.size(1) && w.size(2) == w.size(3), "conv_bn_act: weight shape");
-        const bool has_res = residual_opt.has_value() && residual_opt->defined();
-        const Tensor residual = has_res ? *residual_opt : Tensor();
-        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3);
-        const int Cout = (int)w.size(0), K = (int)w.size(2), S = (int)stride, P = (int)pad;
-        const int Ho = (H + 2 * P - K) / S + 1, Wo = (W + 2 * P - K) / S + 1;
-        const Tensor w16 = channels_last_bf16_weight(w.detach());
-        Tensor raw = at::empty({B, Cout, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
-        Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
-        int sums_done = 0;
-        if (training) {             // the accumulator hand-over of bn_forward, done here because the GEMM epilogue may fill sums_ws
-            int* fl = flags.data_ptr<int>();
-            if (fl[0]) sums_ws.zero_();
-            fl[0] = 1;
-            fl[1] = 0;
-        }
-        const double conv_flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
-        const double conv_bytes = 2.0 * ((double)x.numel() + (double)raw.numel() + (double)w.numel());
-        {
-            ScopedTimer timer("conv_fwd", conv_flops, conv_bytes, current_stream(x));
-            check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
-                                 training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(),
-                                 (size_t)ws.numel(), current_stream(x)),
-                  "epi_conv2d_fwd");
-        }
-        BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
-        Tensor stats;
-        Tensor y;
-        if (training && !sums_done) {       // split-K launch: the statistics pass runs separately; the flags are already set
-            int* fl = flags.data_ptr<int>();
-            fl[0] = 0;
-            y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats, false);
-        } else {
-            y = bn_forward(raw, residual, b, training, momentum, eps, relu, &stats, training);
-        }
+        StageParams sp{w, (w_bwd_opt.has_value() && w_bwd_opt->defined()) ? *w_bwd_opt : Tensor(), gamma, beta, running_mean, running_var,
+                       num_batches, sums_ws, bwd_sums, flags, stride, pad, relu};
+        const Tensor residual = (residual_opt.has_value() && residual_opt->defined()) ? *residual_opt : Tensor();
+        auto holder = c10::make_intrusive<SavedHolder>();
+        holder->stages.resize(1);
+        Tensor y = stage_forward(x, sp, residual, training, momentum, eps, x.requires_grad(), &holder->stages[0]);
         ctx->saved_data["training"] = training;
-        if (training) {
-            Tensor wb;
-            if (x.requires_grad()) {                       // backward-data operand: the optimizer's packed copy, or packed now
-                if (w_bwd_opt.has_value() && w_bwd_opt->defined()) {
-                    wb = *w_bwd_opt;
-                    TORCH_CHECK(wb.numel() == w.numel() && wb.scalar_type() == at::kBFloat16, "conv_bn_act: packed weight mismatch");
-                } else {
-                    wb = at::empty({w.numel()}, w16.options().memory_format(at::MemoryFormat::Contiguous));
-                    check(epi_conv2d_pack_weight_bwd(w16.data_ptr(), Cout, Cin, K, K, S, P, wb.data_ptr(), current_stream(x)),
-                          "epi_conv2d_pack_weight_bwd");
-                }
-            }
-            ctx->saved_data["relu"] = relu;
-            ctx->saved_data["has_res"] = has_res;
-            ctx->saved_data["sums_ws"] = sums_ws;
-            ctx->saved_data["bwd_sums"] = bwd_sums;
-            ctx->saved_data["flags"] = flags;
-            ctx->saved_data["geom"] = std::vector<int64_t>{K, S, P};
-            ctx->saved_data["w_f32"] = w.scalar_type() != at::kBFloat16;
-            ctx->saved_data["w_sizes"] = w.sizes().vec();
-            ctx->saved_data["w_strides"] = (w.is_contiguous(at::MemoryFormat::ChannelsLast) || (K == 1 && w.is_contiguous())) ? w.strides().vec()
-                                                                                                                             : w16.strides().vec();
-            // wb is not a differentiable input and is rewritten in place by the optimizer: keep it out of the version-checked list
-            if (wb.defined()) ctx->saved_data["w_bwd"] = wb;
-            ctx->save_for_backward({x, raw, (relu && has_res) ? y : Tensor(), stats, gamma});
-        }
+        if (training) ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
         return y;
     }
 
     static variable_list backward(AutogradContext* ctx, variable_list grads) {
         TORCH_CHECK(ctx->saved_data["training"].toBool(), "conv_bn_act: backward through inference-mode statistics is not supported");
-        const auto saved = ctx->get_saved_variables();
-        const Tensor &x = saved[0], &raw = saved[1], &y = saved[2], &stats = saved[3], &gamma = saved[4];
-        const bool relu = ctx->saved_data["relu"].toBool(), has_res = ctx->saved_data["has_res"].toBool();
-        BnGrads g = bn_backward(grads[0], raw, y, stats, gamma, ctx->saved_data["sums_ws"].toTensor(), ctx->saved_data["bwd_sums"].toTensor(),
-                                ctx->saved_data["flags"].toTensor(), relu, has_res);
-        const auto geom = ctx->saved_data["geom"].toIntVector();
-        const int K = (int)geom[0], S = (int)geom[1], P = (int)geom[2];
-        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)raw.size(1);
-        const int Ho = (int)raw.size(2), Wo = (int)raw.size(3);
-        Tensor dx, dw;
-        if (ctx->needs_input_grad(0)) {
-            TORCH_CHECK(ctx->saved_data.count("w_bwd"), "conv_bn_act: input gradient requested but no backward-data weight was prepared");
-            const Tensor wb = ctx->saved_data["w_bwd"].toTensor();
-            dx = at::empty_like(x);
-            Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
-            ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
-                              2.0 * ((double)x.numel() + (double)raw.numel() + (double)wb.numel()), current_stream(x));
-            check(epi_conv2d_bwd_data(g.dx.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P, ws.data_ptr(),
-                                      (size_t)ws.numel(), current_stream(x)),
-                  "epi_conv2d_bwd_data");
-        }
-        if (ctx->needs_input_grad(1)) {
-            const bool f32 = ctx->saved_data["w_f32"].toBool();
-            dw = at::empty_strided(ctx->saved_data["w_sizes"].toIntVector(), ctx->saved_data["w_strides"].toIntVector(),
-                                   x.options().dtype(f32 ? at::kFloat : at::kBFloat16));
-            Tensor& ws = workspace(epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K), x);
-            ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
-                              2.0 * ((double)x.numel() + (double)raw.numel() + (double)dw.numel()), current_stream(x));
-            check(epi_conv2d_bwd_weight(x.data_ptr(), g.dx.data_ptr(), dw.data_ptr(), f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, K, K, S, P,
-                                        ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
-                  "epi_conv2d_bwd_weight");
-        }
-        return {dx, dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+        auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
+        TORCH_CHECK(!holder->stages.empty(), "conv_bn_act: backward called twice (the fused nodes free their activations in backward)");
+        StageGrads g = stage_backward(grads[0], holder->stages[0], ctx->needs_input_grad(0), ctx->needs_input_grad(1), Tensor());
+        holder->stages.clear();                      // release the saved activations now, not when the graph is torn down
+        return {g.dx, g.dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
@@ -337,6 +376,79 @@ Tensor conv_bn_act(Tensor x, Tensor w, c10::optional<Tensor> w_bwd, int64_t stri
                    Tensor flags, bool training, double momentum, double eps, bool relu) {
     return ConvBnAct::apply(x, w, w_bwd, stride, pad, gamma, beta, residual, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags,
                             training, momentum, eps, relu);
+}
+
+// ---- A whole residual unit (BasicBlock / Bottleneck, pose3d_resnet.py:18-88) as ONE autograd node ------------------------------
+// tensors: STAGE_TENSORS per stage, main-path stages first, the downsample projection (if any) last; geometry: (stride, pad) per stage.
+// Every main-path stage has ReLU; the last one adds the shortcut before it; the projection has none.  In the backward pass the
+// gradient that reaches the unit input through the shortcut (identity: dres of the last stage; projection: its backward-data result)
+// is added in the epilogue of the first stage's backward-data GEMM -- autograd's separate accumulation launch per unit disappears.
+struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, at::TensorList tensors, std::vector<int64_t> geometry, bool has_downsample, bool training,
+                          double momentum, double eps) {
+        const int n_total = (int)(tensors.size() / STAGE_TENSORS), n_main = n_total - (has_downsample ? 1 : 0);
+        TORCH_CHECK((int)tensors.size() == n_total * STAGE_TENSORS && (int)geometry.size() == 2 * n_total && n_main >= 2, "residual_unit: arguments");
+        auto stage = [&](int i, bool relu) {
+            const at::Tensor* t = &tensors[i * STAGE_TENSORS];
+            return StageParams{t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], geometry[2 * i], geometry[2 * i + 1], relu};
+        };
+        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        auto holder = c10::make_intrusive<SavedHolder>();
+        holder->stages.resize(n_total);
+        holder->has_downsample = has_downsample;
+        holder->n_main = n_main;
+        const bool x_grad = x.requires_grad();
+        Tensor out = x;
+        for (int i = 0; i + 1 < n_main; ++i)
+            out = stage_forward(out, stage(i, true), Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i]);
+        Tensor shortcut = x;
+        if (has_downsample) shortcut = stage_forward(x, stage(n_total - 1, false), Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1]);
+        Tensor y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1]);
+        ctx->saved_data["training"] = training;
+        if (training) ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        TORCH_CHECK(ctx->saved_data["training"].toBool(), "residual_unit: backward through inference-mode statistics is not supported");
+        auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
+        TORCH_CHECK(!holder->stages.empty(), "residual_unit: backward called twice (the fused nodes free their activations in backward)");
+        const int n_total = (int)holder->stages.size(), n_main = holder->n_main;
+        const bool need_x = ctx->needs_input_grad(0);
+        std::vector<StageGrads> g(n_total);
+        // input slots: 0 = x, then STAGE_TENSORS per stage (w at +0, gamma at +2, beta at +3)
+        auto need_w = [&](int i) { return ctx->needs_input_grad(1 + i * STAGE_TENSORS); };
+        g[n_main - 1] = stage_backward(grads[0], holder->stages[n_main - 1], true, need_w(n_main - 1), Tensor());
+        Tensor shortcut_grad = g[n_main - 1].dres;                     // gradient of the shortcut input
+        if (holder->has_downsample) {
+            g[n_total - 1] = stage_backward(shortcut_grad, holder->stages[n_total - 1], need_x, need_w(n_total - 1), Tensor());
+            shortcut_grad = g[n_total - 1].dx;                          // undefined when x needs no gradient
+        }
+        Tensor flow = g[n_main - 1].dx;
+        for (int i = n_main - 2; i >= 1; --i) {
+            g[i] = stage_backward(flow, holder->stages[i], true, need_w(i), Tensor());
+            flow = g[i].dx;
+        }
+        g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor());
+        variable_list out;
+        out.reserve(1 + n_total * STAGE_TENSORS + 5);
+        out.push_back(g[0].dx);
+        for (int i = 0; i < n_total; ++i) {
+            out.push_back(g[i].dw);
+            out.push_back(Tensor());
+            out.push_back(g[i].dgamma);
+            out.push_back(g[i].dbeta);
+            for (int k = 4; k < STAGE_TENSORS; ++k) out.push_back(Tensor());
+        }
+        for (int k = 0; k < 5; ++k) out.push_back(Tensor());          // geometry, has_downsample, training, momentum, eps
+        holder->stages.clear();                                       // release the saved activations now
+        return out;
+    }
+};
+
+Tensor residual_unit(Tensor x, std::vector<Tensor> tensors, std::vector<int64_t> geometry, bool has_downsample, bool training, double momentum,
+                     double eps) {
+    return ResidualUnitFn::apply(x, at::TensorList(tensors), geometry, has_downsample, training, momentum, eps);
 }
 
 // ---- FusedAdam's per-step pointer table ----------------------------------------------------------------------------
@@ -386,6 +498,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "torch-autograd glue over the libepipolar_hip C ABI (no compute of its own)";
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
+    m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");
     m.def("timing_enable", &timing_enable, "record HIP events around every epi_* launch made by this extension");
     m.def("timing_collect", &timing_collect, "{name: (launches, total ms, algorithmic FLOPs, algorithmic bytes)}; clears the records");

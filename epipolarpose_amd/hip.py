@@ -53,14 +53,16 @@ _SIGNATURES = {
     "epi_conv2d_pack_row_bytes": (_sz, []),
     "epi_conv2d_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_conv2d_pack_weight_bwd_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
-    "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_pack_phase_cl": (_i, [_vp, _i, _i, _vp, _vp]),
+    "epi_deconv4x4s2_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
     "epi_adam_tensor_bytes": (_sz, []),
     "epi_adam_chunk_elems": (_i, []),
@@ -483,6 +485,26 @@ def deconv_pack_weight(weight, want_phase=True, want_bwd=True):
     return wp, wb
 
 
+def deconv_weight_forms(weight, w_phase=None):
+    """weight [Cin, Cout, 4, 4] -> (w_phase [4, Cout, 4*Cin] bf16, w_bwd [Cin, 16*Cout] bf16) WITHOUT re-laying the weight out: in
+    channels_last memory ([Cin][kh][kw][Cout], what ``model.to(memory_format=torch.channels_last)`` gives it) the bf16 weight is the
+    backward-data operand as it stands; only the forward operand is packed (skipped when the optimizer maintains ``w_phase``)."""
+    lib = load()
+    _dev(weight, name="weight")
+    cin, cout, kh, kw = weight.shape
+    if (kh, kw) != (4, 4):
+        raise ValueError("deconv head kernels cover kernel 4 / stride 2 / padding 1 only")
+    w = weight.detach()
+    if w.dtype != torch.bfloat16:
+        w = w.to(torch.bfloat16)
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    if w_phase is None:
+        w_phase = torch.empty((4, cout, 4 * cin), dtype=torch.bfloat16, device=w.device)
+        _check(lib.epi_deconv4x4s2_pack_phase_cl(_ptr(w), cin, cout, _ptr(w_phase), _stream()), "epi_deconv4x4s2_pack_phase_cl")
+    return w_phase, w            # w: logical [Cin, Cout, 4, 4], memory [Cin][16*Cout]
+
+
 def deconv4x4s2_fwd(x, w_phase):
     """x [B, Cin, H, W] channels_last bf16 -> y [B, Cout, 2H, 2W] channels_last bf16 (raw ConvTranspose2d output)."""
     lib = load()
@@ -561,20 +583,21 @@ def gemm_tn_bf16(a, b):
     return out
 
 
-def deconv4x4s2_bwd_weight(x, dy):
-    """x [B, Cin, H, W], dy [B, Cout, 2H, 2W] (channels_last bf16) -> dW [Cin, Cout, 4, 4] f32."""
+def deconv4x4s2_bwd_weight(x, dy, dtype=torch.float32):
+    """x [B, Cin, H, W], dy [B, Cout, 2H, 2W] (channels_last bf16) -> dW [Cin, Cout, 4, 4] (f32 or bf16) in channels_last memory
+    ([Cin][kh][kw][Cout]: the kernel's own output order, no permuting copy)."""
     lib = load()
     x, dy = _nhwc_bf16(x, "x"), _nhwc_bf16(dy, "dy")
     b, cin, h, w = x.shape
     cout = dy.shape[1]
-    taps = torch.empty((cin, 16, cout), dtype=torch.float32, device=x.device)
+    taps = torch.empty((cin, 16, cout), dtype=dtype, device=x.device)
     ws = _workspace(lib.epi_gemm_tn_workspace_bytes(b * h * w, cin, cout, 16), x.device)
     with _on(x.device):
         ev = timer.start("epi_deconv4x4s2_bwd_weight")
-        _check(lib.epi_deconv4x4s2_bwd_weight(_ptr(x), _ptr(dy), _ptr(taps), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
-               "epi_deconv4x4s2_bwd_weight")
+        _check(lib.epi_deconv4x4s2_bwd_weight(_ptr(x), _ptr(dy), _ptr(taps), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32, b, h, w, cin, cout,
+                                              _ptr(ws), ws.numel(), _stream()), "epi_deconv4x4s2_bwd_weight")
         timer.stop(ev)
-    return taps.reshape(cin, 4, 4, cout).permute(0, 3, 1, 2).contiguous()
+    return taps.view(cin, 4, 4, cout).permute(0, 3, 1, 2)
 
 
 def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
@@ -636,8 +659,9 @@ def conv2d_pack_weight_bwd(weight, stride=1, padding=0, out=None):
     return out
 
 
-def conv2d_bwd_data(dy, w_bwd, in_shape, kernel, stride=1, padding=0):
-    """dy [B, Cout, Ho, Wo] channels_last bf16, w_bwd from ``conv2d_pack_weight_bwd`` -> dx of shape ``in_shape`` = (B, Cin, H, W)."""
+def conv2d_bwd_data(dy, w_bwd, in_shape, kernel, stride=1, padding=0, addend=None):
+    """dy [B, Cout, Ho, Wo] channels_last bf16, w_bwd from ``conv2d_pack_weight_bwd`` -> dx of shape ``in_shape`` = (B, Cin, H, W);
+    ``addend`` (same shape as dx, channels_last bf16) is added in the epilogue (the other branch's gradient at a residual junction)."""
     lib = load()
     dy = _nhwc_bf16(dy, "dy")
     b, cin, h, wd = in_shape
@@ -646,8 +670,12 @@ def conv2d_bwd_data(dy, w_bwd, in_shape, kernel, stride=1, padding=0):
     dx = torch.empty((b, cin, h, wd), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     ws = _workspace(lib.epi_conv2d_workspace_bytes(b, h, wd, cin, cout, kh, kw, stride, padding), dy.device)
     ev = timer.start("epi_conv2d_bwd_data")
-    _check(lib.epi_conv2d_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(ws), ws.numel(),
-                                   _stream()), "epi_conv2d_bwd_data")
+    if addend is not None:
+        addend = _nhwc_bf16(addend, "addend")
+        if tuple(addend.shape) != tuple(dx.shape):
+            raise ValueError("addend must have the shape of dx")
+    _check(lib.epi_conv2d_bwd_data(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(addend), _ptr(ws),
+                                   ws.numel(), _stream()), "epi_conv2d_bwd_data")
     timer.stop(ev)
     return dx
 

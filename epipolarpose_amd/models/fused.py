@@ -100,6 +100,43 @@ class FusedConvBn:
                                       bn.training, bn.momentum, bn.eps, bn.relu)
 
 
+_EMPTY = {}
+
+
+def _empty_bf16(device):
+    t = _EMPTY.get(device)
+    if t is None:
+        t = _EMPTY[device] = torch.empty(0, dtype=torch.bfloat16, device=device)
+    return t
+
+
+class FusedResidualUnit:
+    """A whole BasicBlock / Bottleneck as ONE autograd node (``residual_unit`` of the C++ glue): every conv -> BatchNorm -> ReLU
+    stage, the shortcut (identity or 1x1 projection + BatchNorm) and the final add + ReLU forward; in the backward pass the
+    gradient arriving through the shortcut is added in the epilogue of the first stage's backward-data GEMM, so autograd's
+    separate accumulation launch per unit disappears.  ``stages``: FusedConvBn objects, main path first, the projection last."""
+
+    def __init__(self, stages, has_downsample):
+        self.stages, self.has_downsample = tuple(stages), has_downsample
+        self.geometry = [v for st in self.stages for v in (st.stride, st.pad)]
+
+    def __call__(self, x):
+        tensors = []
+        for st in self.stages:
+            conv, bn = st.conv, st.bn
+            if getattr(conv, "weight_lp", None) is not None:
+                w = sync_training_copy(conv)
+                wb = getattr(conv, "weight_bwd", None)
+            else:
+                w, wb = conv.weight, None
+            tensors.append(w)
+            tensors.append(wb if wb is not None else _empty_bf16(w.device))
+            tensors.extend(bn._tensors())
+            tensors.append(bn._flags)
+        bn0 = self.stages[0].bn
+        return hip.glue().residual_unit(x, tensors, self.geometry, self.has_downsample, bn0.training, bn0.momentum, bn0.eps)
+
+
 class PointwiseConv(nn.Module):
     """Bias-free 1x1 stride-1 convolution of an NHWC tensor as a plain library GEMM (hipBLASLt through ``F.linear`` on the
     zero-copy [B*H*W, Cin] view); weight [Cout, Cin, 1, 1] keeps the ``nn.Conv2d`` name and shape (bottleneck conv1 / conv3,
@@ -127,31 +164,46 @@ class PointwiseConv(nn.Module):
 
 class _DeconvFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
-        w_phase, w_bwd = hip.deconv_pack_weight(weight, want_phase=True, want_bwd=True)
-        ctx.save_for_backward(x, weight, w_bwd)
+    def forward(ctx, x, weight, w_phase):
+        # weight: the bf16 training copy (optimizer-maintained w_phase) or the fp32 master (converted and packed here)
+        w_phase, w16 = hip.deconv_weight_forms(weight, w_phase)
+        ctx.save_for_backward(x, w16)
+        ctx.grad_dtype = weight.dtype
         return hip.deconv4x4s2_fwd(x, w_phase)
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, w_bwd = ctx.saved_tensors
+        x, w16 = ctx.saved_tensors
         dy = _nhwc_bf16(dy)
-        dx = hip.deconv4x4s2_bwd_data(dy, w_bwd) if ctx.needs_input_grad[0] else None
-        dw = hip.deconv4x4s2_bwd_weight(x, dy).to(weight.dtype) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        cin, cout = w16.shape[0], w16.shape[1]
+        # channels_last memory of the [Cin, Cout, 4, 4] weight = [Cin][16*Cout] = the backward-data operand as it stands
+        dx = hip.deconv4x4s2_bwd_data(dy, torch.as_strided(w16, (cin, 16 * cout), (16 * cout, 1), w16.storage_offset())) if ctx.needs_input_grad[0] else None
+        dw = hip.deconv4x4s2_bwd_weight(x, dy, dtype=ctx.grad_dtype) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
 
 
 class Deconv4x4s2(nn.Module):
-    """ConvTranspose2d(kernel 4, stride 2, padding 1, no bias); weight [Cin, Cout, 4, 4] as in the reference."""
+    """ConvTranspose2d(kernel 4, stride 2, padding 1, no bias); weight [Cin, Cout, 4, 4] as in the reference.  In channels_last
+    memory (what ``PoseResNet.to(memory_format=torch.channels_last)`` gives every 4-D parameter) the weight is [Cin][kh][kw][Cout]:
+    the backward-data operand as it stands and the order the weight-gradient kernel writes; an optimizer that installs a bf16
+    training copy (optim.FusedAdam) also maintains the packed forward operand ``weight_phase``."""
+
+    supports_training_copy = True
+    epi_deconv = True
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.weight = nn.Parameter(torch.empty(in_channels, out_channels, 4, 4))
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.ConvTranspose2d default initialisation
+        self.register_parameter("bias", None)
 
     def forward(self, x):
-        return _DeconvFunction.apply(_nhwc_bf16(x), self.weight)
+        if getattr(self, "weight_lp", None) is not None:
+            w, wp = sync_training_copy(self), getattr(self, "weight_phase", None)
+        else:
+            w, wp = self.weight, None
+        return _DeconvFunction.apply(_nhwc_bf16(x), w, wp)
 
 
 class _Conv1x1Function(torch.autograd.Function):

@@ -18,7 +18,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, FusedConvBn, PointwiseConv, conv_is_fusable
+from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
 
 BN_MOMENTUM = 0.1
 # Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1).  Measured round 1 at B=32 (ms/step, whole training step):
@@ -67,6 +67,7 @@ class ResidualUnit(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, cin, kernel_size=1, stride=stride, bias=False),
                                             FusedBatchNormAct(cin, momentum=BN_MOMENTUM, relu=False))
 
+        self._unit = None
         self._fused = self._build_fused()
 
     def _build_fused(self):
@@ -76,11 +77,16 @@ class ResidualUnit(nn.Module):
             pairs.append((self.downsample[0], self.downsample[1]))
         if CONV_BACKEND != "hip" or not all(conv_is_fusable(c) for c, _ in pairs):
             return ()
-        return tuple(FusedConvBn(c, b) for c, b in pairs)
+        fused = tuple(FusedConvBn(c, b) for c, b in pairs)
+        # EPI_UNIT_NODE=0: one autograd node per conv/bn stage (A/B switch); default: one node per residual unit
+        self._unit = FusedResidualUnit(fused, self.downsample is not None) if os.environ.get("EPI_UNIT_NODE", "1") != "0" else None
+        return fused
 
     def forward(self, x):
         fused = self._fused
         if fused and x.is_cuda:
+            if self._unit is not None:
+                return self._unit(x)
             out = x
             for i in range(self.n_conv - 1):
                 out = fused[i](out)                                                      # conv -> BN -> ReLU: one node

@@ -31,6 +31,10 @@ def sync_training_copy(module):
             if wb is not None:                 # the packed backward-data operand follows the copy
                 _, stride, pad = module.epi_geometry
                 hip.conv2d_pack_weight_bwd(module.weight_lp, stride, pad, out=wb)
+            wp = getattr(module, "weight_phase", None)
+            if wp is not None:                 # deconvolution: the packed forward operand follows the copy
+                hip._check(hip.load().epi_deconv4x4s2_pack_phase_cl(module.weight_lp.data_ptr(), w.shape[0], w.shape[1], wp.data_ptr(),
+                                                                    hip._stream()), "epi_deconv4x4s2_pack_phase_cl")
         module._lp_version = w._version
     return module.weight_lp
 
@@ -120,29 +124,41 @@ class FusedAdam(torch.optim.Optimizer):
         convolution that runs on the implicit-GEMM kernels (modules carrying ``epi_geometry``, models/fused.py:FusedConvBn): one flat
         buffer, refreshed by ONE multi-layer pack launch after each Adam step."""
         lib = hip.load()
-        mods = [m for m in lp_modules if getattr(m, "epi_geometry", None) is not None]
+        convs = [m for m in lp_modules if getattr(m, "epi_geometry", None) is not None]
+        deconvs = [m for m in lp_modules if getattr(m, "epi_deconv", False) and m.weight.is_contiguous(memory_format=torch.channels_last)]
         self._pack_rows, self._pack_tiles, self._pack_table = 0, 0, None
-        if not mods:
+        if not convs and not deconvs:
             return
         import ctypes
-        total = sum(m.weight.numel() for m in mods)
+        total = sum(m.weight.numel() for m in convs) + sum(m.weight.numel() for m in deconvs)
         self._packed = torch.empty(total, dtype=torch.bfloat16, device=dev)
         row_bytes = lib.epi_conv2d_pack_row_bytes()
-        host = torch.zeros(len(mods) * row_bytes, dtype=torch.uint8)
-        off, tiles = 0, 0
-        for r, m in enumerate(mods):
+        host = torch.zeros((len(convs) + len(deconvs)) * row_bytes, dtype=torch.uint8)
+        off, tiles, r = 0, 0, 0
+        nt = ctypes.c_longlong(0)
+        for m in convs:
             n = m.weight.numel()
             wb = self._packed[off:off + n]
             off += n
             object.__setattr__(m, "weight_bwd", wb)
             k, stride, pad = m.epi_geometry
             cout, cin = m.weight.shape[0], m.weight.shape[1]
-            nt = ctypes.c_longlong(0)
             hip._check(lib.epi_conv2d_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), wb.data_ptr(), cout, cin, k, k,
                                                     stride, pad, tiles, ctypes.byref(nt)), "epi_conv2d_pack_fill_row")
             tiles += nt.value
+            r += 1
+        for m in deconvs:       # ConvTranspose2d(k4 s2 p1): the channels_last copy IS the backward-data operand; pack the forward one
+            cin, cout = m.weight.shape[0], m.weight.shape[1]
+            n = m.weight.numel()
+            wp = self._packed[off:off + n].view(4, cout, 4 * cin)
+            off += n
+            object.__setattr__(m, "weight_phase", wp)
+            hip._check(lib.epi_deconv4x4s2_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), wp.data_ptr(), cin, cout, tiles,
+                                                         ctypes.byref(nt)), "epi_deconv4x4s2_pack_fill_row")
+            tiles += nt.value
+            r += 1
         self._pack_table = host.to(dev)
-        self._pack_rows, self._pack_tiles = len(mods), tiles
+        self._pack_rows, self._pack_tiles = r, tiles
         self._pack_weights()
 
     def _pack_weights(self):

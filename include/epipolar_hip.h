@@ -176,6 +176,12 @@ int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int 
  *   w_bwd   [Cin][16*Cout]   : all 16 taps, for backward-data.                   Either may be NULL. */
 int epi_deconv4x4s2_pack_weight(const void* w_bf16, int Cin, int Cout, void* w_phase, void* w_bwd,
                                 epi_stream_t stream);
+/* The same for a weight kept in channels_last memory [Cin][kh][kw][Cout] (bf16): that memory IS w_bwd already, only w_phase is
+ * produced (32x32 tile transposes per tap).  _fill_row writes a row of the multi-layer table of epi_conv2d_pack_weight_bwd_multi,
+ * so that the deconvolution weights are re-packed by the same single launch after every optimizer step. */
+int epi_deconv4x4s2_pack_phase_cl(const void* w_cl, int Cin, int Cout, void* w_phase, epi_stream_t stream);
+int epi_deconv4x4s2_pack_fill_row(void* row_host, const void* w_cl, void* w_phase, int Cin, int Cout, long long tile_begin,
+                                  long long* ntiles);
 
 /* y [B][2H][2W][Cout] = ConvTranspose2d(x [B][H][W][Cin]) as 4 implicit (gather) GEMMs with K = 4*Cin.
  * Cin % 64 == 0, Cout % 4 == 0.  Raw output (BatchNorm + ReLU follow, pose3d_resnet.py:180-181).
@@ -248,8 +254,11 @@ size_t epi_conv2d_pack_row_bytes(void);
 int epi_conv2d_pack_fill_row(void* row_host, const void* w, void* w_bwd, int Cout, int Cin, int KH, int KW, int stride, int pad,
                              long long tile_begin, long long* ntiles);
 int epi_conv2d_pack_weight_bwd_multi(const void* rows, int nrows, long long total_tiles, epi_stream_t stream);
+/* addend [B][H][W][Cin] bf16 or NULL: dx = (backward-data result, rounded to bf16) + addend -- the gradient that reaches the same
+ * tensor through the other branch of a residual junction (`out += residual`, pose3d_resnet.py:44,85), added in the GEMM epilogue
+ * instead of a separate element-wise launch. */
 int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                        int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+                        int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
 /* Weight gradient of a Conv2d (groups 1, dilation 1) on NHWC bf16 tensors -- the backbone convolutions' backward-weight
  * (autograd of nn.Conv2d in lib/models/pose3d_resnet.py:21-88), which the reference leaves to cuDNN:
@@ -262,12 +271,13 @@ int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (J = columns per filter tap; ntap = 1 for epi_gemm_tn_bf16, 16 for the
  * deconvolution; may be 0: a reduction that needs no split writes its result directly).
  *   epi_gemm_tn_bf16:            C[I][J] = A[R][I]^T * B[R][J]  (final conv: A = dlogits, B = activations -> dW[Cout][Cin])
- *   epi_deconv4x4s2_bwd_weight:  dw_taps[Cin][16][Cout], tap = kh*4+kw, from x [B][H][W][Cin], dy [B][2H][2W][Cout]
+ *   epi_deconv4x4s2_bwd_weight:  dw_taps[Cin][16][Cout] (EPI_F32 | EPI_BF16), tap = kh*4+kw -- the memory order of a channels_last
+ *                                [Cin, Cout, 4, 4] weight -- from x [B][H][W][Cin], dy [B][2H][2W][Cout]
  *   epi_column_sums_bf16:        sums[2C] += per-column (sum, sum of squares) of x [R][C]  (bias gradient; zero it first) */
 size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap);
 int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J,
                      void* workspace, size_t workspace_bytes, epi_stream_t stream);
-int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, float* dw_taps, int B, int H, int W, int Cin, int Cout,
+int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, void* dw_taps, int dw_dtype, int B, int H, int W, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream);
 

@@ -227,3 +227,62 @@ def test_conv2d_fwd_fused_bn_statistics(geo):
         torch.testing.assert_close(sums[cout:], s2, rtol=2e-4, atol=1e-3)
     else:
         assert float(sums.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("geo", [(64, 64, 3, 1, 16, 3), (256, 64, 1, 1, 64, 8), (64, 256, 1, 1, 64, 8), (128, 128, 3, 2, 16, 3), (256, 512, 1, 2, 16, 3),
+                                 (512, 512, 3, 1, 8, 32), (2048, 512, 1, 1, 8, 32)],
+                         ids=lambda g: "%dto%d_k%ds%d_h%d_b%d" % g)
+def test_conv2d_bwd_data_epilogue_addend(geo):
+    """dx = bf16(backward-data) + addend in the GEMM epilogue (every kernel path: tall / small / A-stationary / split-K / phased)."""
+    from epipolarpose_amd import hip
+    cin, cout, k, stride, h, b = geo
+    pad = k // 2
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin + 5 * cout + k)
+    w = _rand((cout, cin, k, k), gen, scale=(2.0 / (cin * k * k)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    ho = (h + 2 * pad - k) // stride + 1
+    dy = _rand((b, cout, ho, ho), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    r = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    wb = hip.conv2d_pack_weight_bwd(w, stride, pad)
+    plain = hip.conv2d_bwd_data(dy, wb, (b, cin, h, h), k, stride, pad)
+    fused = hip.conv2d_bwd_data(dy, wb, (b, cin, h, h), k, stride, pad, addend=r)
+    assert torch.equal(fused, (plain.float() + r.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind", ["bottleneck_proj", "bottleneck_identity", "bottleneck_stride2", "basic_identity", "basic_stride2"])
+def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
+    """One autograd node per residual unit (shortcut gradient added in the first stage's dgrad epilogue) against one node per
+    conv/bn stage with autograd's own accumulation: same kernels, same roundings -> identical outputs and gradients."""
+    import copy
+    from epipolarpose_amd.models import pose3d_resnet as P
+    dev = torch.device("cuda:0")
+    plan, inpl, planes, stride = {"bottleneck_proj": (P._BOTTLENECK, 64, 64, 1), "bottleneck_identity": (P._BOTTLENECK, 256, 64, 1),
+                                  "bottleneck_stride2": (P._BOTTLENECK, 256, 128, 2), "basic_identity": (P._BASIC, 64, 64, 1),
+                                  "basic_stride2": (P._BASIC, 64, 128, 2)}[kind]
+    torch.manual_seed(3)
+    monkeypatch.setenv("EPI_UNIT_NODE", "1")
+    unit = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
+    assert unit._unit is not None
+    monkeypatch.setenv("EPI_UNIT_NODE", "0")
+    staged = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
+    assert staged._unit is None and staged._fused
+    staged.load_state_dict(copy.deepcopy(unit.state_dict()))
+    gen = torch.Generator().manual_seed(4)
+    x = _rand((4, inpl, 16, 16), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    pre = torch.nn.Conv2d(inpl, inpl, 1, bias=False).to(dev).to(torch.bfloat16)      # gives x a grad_fn: the unit must return dx
+    outs = []
+    for m in (unit, staged):
+        pre.zero_grad()
+        m.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        y = m(pre(xin).contiguous(memory_format=torch.channels_last))
+        dy = _rand(tuple(y.shape), torch.Generator().manual_seed(9)).to(dev).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        outs.append((y.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    # running statistics advanced identically
+    for (ka, va), (kb, vb) in zip(unit.state_dict().items(), staged.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka

@@ -213,3 +213,47 @@ def test_conv2d_bwd_weight_vs_torch(dev, b, h, w, cin, cout, k, stride, pad):
     got16 = hip.conv2d_bwd_weight(x, dy, k, stride, pad, dtype=torch.bfloat16)
     assert got16.dtype == torch.bfloat16
     close(got16, wt.grad, rel=1e-2)
+
+
+@pytest.mark.parametrize("cin,cout,h", [(128, 64, 8), (2048, 256, 4), (256, 256, 16)])
+def test_deconv_channels_last_weight_forms_and_module(dev, cin, cout, h):
+    """The channels_last weight memory [Cin][kh][kw][Cout] is the backward-data operand as it stands; the packed forward operand
+    equals the one produced from the contiguous layout; the module trains through a bf16 copy with a bf16 gradient in the weight's
+    own layout, and FusedAdam keeps ``weight_phase`` in step with the updated copy."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.models.fused import Deconv4x4s2
+    from epipolarpose_amd.optim import FusedAdam
+    wt = rnd((cin, cout, 4, 4), dev, 21, scale=(1.0 / cin) ** 0.5)
+    wp_ref, wb_ref = hip.deconv_pack_weight(wt)                                   # from the contiguous [Cin][Cout][4][4] layout
+    wp, w16 = hip.deconv_weight_forms(wt.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(wp, wp_ref)
+    assert torch.equal(torch.as_strided(w16, (cin, 16 * cout), (16 * cout, 1)), wb_ref)
+    mod = Deconv4x4s2(cin, cout).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        mod.weight.copy_(wt)
+    x = rnd((2, cin, h, h), dev, 22).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = rnd((2, cout, 2 * h, 2 * h), dev, 23).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_(True)
+    wr = wt.to(torch.bfloat16).float().requires_grad_(True)
+    ref = F.conv_transpose2d(xr, wr, None, stride=2, padding=1)
+    ref.backward(dy.float())
+    xg = x.clone().requires_grad_(True)
+    y = mod(xg)                                                                    # fp32 master path: converted + packed per call
+    close(y, ref)
+    y.backward(dy)
+    close(xg.grad, xr.grad)
+    assert mod.weight.grad.dtype == torch.float32 and mod.weight.grad.stride() == mod.weight.stride()
+    close(mod.weight.grad, wr.grad, rel=2e-3)
+    opt = FusedAdam(mod, lr=1e-3)                                                  # bf16 training copy + optimizer-maintained weight_phase
+    assert mod.weight_lp.dtype == torch.bfloat16 and mod.weight_phase.shape == (4, cout, 4 * cin)
+    assert torch.equal(mod.weight_phase, wp_ref)
+    xg2 = x.clone().requires_grad_(True)
+    y2 = mod(xg2)
+    close(y2, ref)
+    y2.backward(dy)
+    g = mod.weight_lp.grad
+    assert g.dtype == torch.bfloat16 and g.stride() == mod.weight.stride()
+    close(g, wr.grad, rel=1.5e-2)
+    opt.step()
+    assert torch.equal(mod.weight_lp.detach().float(), mod.weight.detach().to(torch.bfloat16).float())
+    assert torch.equal(mod.weight_phase, hip.deconv_pack_weight(mod.weight.detach())[0])
