@@ -356,6 +356,26 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         // read-back accumulates per-column sum and sum of squares of the bf16-ROUNDED outputs: 8 columns per lane over the
         // rows it copies, reduced over the 8 row lanes with three shuffles, one fp32 atomic per column and wave.
         char* mine = smem + wid * (TM * 32 * 128);
+        const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
+        // output row of read-back iteration `it` (rows it*8 + (lane >> 3) of the wave's sub-tile); -1: outside the matrix
+        auto out_row = [&](int it) -> long long {
+            const int m = m0 + wm * (TM * 32) + it * 8 + (lane >> 3);
+            if (m >= p.M || n >= p.N) return -1;
+            if (!p.sc.enabled) return m;
+            const int hw = p.sc.Hg * p.sc.Wg;
+            const int b = m / hw, rem = m - b * hw;
+            const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
+            return ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
+        };
+        // residual-junction addend: requested NOW, consumed after the LDS round trip below (its latency hides behind the park)
+        uint4v ad[TM * 4];
+        if (p.addend) {
+#pragma unroll
+            for (int it = 0; it < TM * 4; ++it) {
+                const long long orow = out_row(it);
+                ad[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
+            }
+        }
 #pragma unroll
         for (int ti = 0; ti < TM; ++ti) {
             const int row = ti * 32 + frow;
@@ -377,17 +397,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                     *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
                 }
         }
-        const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
         float ssum[8], ssq[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < TM * 4; ++it) {
             const int row = it * 8 + (lane >> 3), sw = row & 15;
             const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
             const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
-            const int m = m0 + wm * (TM * 32) + row;
-            if (m >= p.M || n >= p.N) continue;
+            const long long orow = out_row(it);
+            if (orow < 0) continue;
             if (p.stats) {
                 const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
@@ -397,15 +416,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                     ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
                 }
             }
-            long long orow = m;
-            if (p.sc.enabled) {
-                const int hw = p.sc.Hg * p.sc.Wg;
-                const int b = m / hw, rem = m - b * hw;
-                const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
-                orow = ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
-            }
             uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-            if (p.addend) o = add_bf16x8(o, *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n));
+            if (p.addend) o = add_bf16x8(o, ad[it]);
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
         }
         if (p.stats) {
@@ -567,6 +579,18 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
                 f[tj] = *reinterpret_cast<const uint4v*>(smem + off);
             }
         };
+        // residual-junction addend of this slice: requested before the MFMAs and consumed after the LDS round trip where the
+        // registers allow it (K <= 128: the stationary A fragments leave room); loaded at its use otherwise
+        uint4v ad[4];
+        auto load_addend = [&]() {
+            if (!p.addend) return;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = m0 + it * 8 + (lane >> 3), nn = nt * AS_BN + (lane & 7) * 8;
+                ad[it] = (m < p.M && nn < p.N) ? *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + nn) : uint4v{0u, 0u, 0u, 0u};
+            }
+        };
+        if (KSTEPS <= 8) load_addend();
         uint4v fb[3][2];
         read_b(0, fb[0]);
         if (KSTEPS > 1) read_b(1, fb[1]);
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
             const int m = m0 + row;
             if (m < p.M && n < p.N) {
                 uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-                if (p.addend) o = add_bf16x8(o, *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + n));
+                if (p.addend) o = add_bf16x8(o, KSTEPS <= 8 ? ad[it] : *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + n));
                 *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
                 if (p.stats) {      // BatchNorm statistics of the bf16-rounded outputs (see head_gemm_kernel's epilogue)
                     const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};

