@@ -42,8 +42,9 @@ __device__ __forceinline__ void slab_reduce_and_add(const float (&s)[8], const f
 }
 
 // sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)
+// (ncopies accumulator copies [ncopies][2C], row block b adds into copy b % ncopies: fewer atomics per 128-byte line; 1 = plain [2C])
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
-                                                              int rows_per_wg, float* __restrict__ sums) {
+                                                              int rows_per_wg, float* __restrict__ sums, int ncopies) {
     __shared__ float red[BN_RLANES * 128];
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
     const int ch0 = slab * BN_SLAB + g * 8;
@@ -76,14 +77,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned sho
             for (int k = 0; k < 8; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
         }
     }
-    slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
+    slab_reduce_and_add(s, q, g, rl, slab, C, sums + (long long)(blockIdx.y % ncopies) * 2 * C, red);
 }
 
 // Per-channel affine of one BatchNorm call, derived inside the apply kernel.
 // Training (sums != nullptr): mean / rstd from the batch sums (float64: E[x^2] - m^2 cancels), running statistics
 // (momentum, unbiased variance) and num_batches_tracked updated by workgroup 0.  Inference: running statistics.
 struct BnAffine {
-    const float* sums;            // [2C] batch sums (sum x | sum x^2) or nullptr
+    const float* sums;            // [ncopies][2C] partial batch sums (sum x | sum x^2), added up here, or nullptr
+    int ncopies;
     long long R;
     double inv_r;                 // 1 / R (host-computed: no float64 divide on the device)
     const float *gamma, *beta;
@@ -106,8 +108,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned sho
         // float32) and float32 for the rest -- no float64 divide / sqrt
         double m, var;
         if (a.sums) {
-            m = (double)a.sums[c] * inv_r;
-            var = fma(-m, m, (double)a.sums[C + c] * inv_r);
+            float s1 = a.sums[c], s2 = a.sums[C + c];
+            for (int k = 1; k < a.ncopies; ++k) { s1 += a.sums[2 * k * C + c]; s2 += a.sums[(2 * k + 1) * C + c]; }
+            m = (double)s1 * inv_r;
+            var = fma(-m, m, (double)s2 * inv_r);
             if (var < 0) var = 0;
         } else {
             m = a.running_mean[c];
@@ -214,10 +218,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ sums,
                                                                   unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
-                                                                  float* __restrict__ fwd_sums_clear, float* __restrict__ param_grads) {
+                                                                  float* __restrict__ fwd_sums_clear, int fwd_sums_copies,
+                                                                  float* __restrict__ param_grads) {
     if (blockIdx.x == 0) {
         if (fwd_sums_clear)                        // the forward statistics accumulator of this layer's NEXT forward pass
-            for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
+            for (int c = threadIdx.x; c < 2 * C * fwd_sums_copies; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
         if (param_grads)                           // (dbeta | dgamma) handed to the caller in memory the accumulator protocol never touches
             for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) param_grads[c] = sums[c];
     }
@@ -268,6 +273,11 @@ static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* g
 
 using namespace epi;
 
+// The forward statistics accumulator sums_ws is [epi_bn_sum_copies(C)][2C]: producers (the statistics kernel's row blocks, a
+// convolution epilogue's M tiles) spread their atomics over the copies; the apply kernel adds the copies up.  One copy for wide
+// layers (few rows, so few producers -- and every apply workgroup reads all of them).
+extern "C" int epi_bn_sum_copies(int C) { return C <= 512 ? 4 : 1; }
+
 extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                               float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
                               long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
@@ -282,7 +292,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
         int rpw = 0;
         dim3 rgrid;
         reduce_blocking(R, C, &rpw, &rgrid);
-        hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws);
+        hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws, epi_bn_sum_copies(C));
         EPI_CHECK_LAUNCH();
     }
     const long long nvec = R * (C >> 3);
@@ -290,7 +300,7 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     const size_t lds = (size_t)2 * C * sizeof(float);
     if (lds > 65536) return EPI_ERR_UNSUPPORTED;
     BnAffine a;
-    a.sums = training ? sums_ws : nullptr; a.R = R; a.inv_r = 1.0 / (double)R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
+    a.sums = training ? sums_ws : nullptr; a.ncopies = epi_bn_sum_copies(C); a.R = R; a.inv_r = 1.0 / (double)R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
     a.running_mean = running_mean; a.running_var = running_var; a.num_batches = num_batches_tracked;
     a.mean = mean; a.rstd = rstd; a.scale = scale_shift; a.shift = scale_shift + C; a.bwd_sums = bwd_sums;
     const unsigned short* xs = (const unsigned short*)x;
@@ -326,7 +336,7 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     const long long nvec = R * (C >> 3);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, param_grads)
+#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, epi_bn_sum_copies(C), param_grads)
     if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
     else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }
     else { if (dres) EPI_BN_APP(BN_MASK_FROM_Y, true); else EPI_BN_APP(BN_MASK_FROM_Y, false); }
@@ -344,7 +354,7 @@ extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* su
     int rpw = 0;
     dim3 rgrid;
     reduce_blocking(R, C, &rpw, &rgrid);
-    hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums, 1);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

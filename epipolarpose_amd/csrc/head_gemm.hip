@@ -82,7 +82,8 @@ struct GemmArgs {
     int k_per_split;       // split-K: blockIdx.y handles K range [y*k_per_split, ...) and writes an fp32 slab (plain rows)
     float* slabs;          // [nsplit][nphase][M][N] when gridDim.y > 1
     const unsigned short* addend;   // bf16 [same rows / stride as C] or null: C = A*B + addend (the other branch's gradient at a residual junction)
-    float* stats;          // [2N] or null: += per-column (sum, sum of squares) of the bf16 result (unsplit bf16 launches only)
+    float* stats;          // [stats_copies][2N] or null: += per-column (sum, sum of squares) of the bf16 result (unsplit bf16 launches only);
+    int stats_copies;      //   M tile t adds into copy t % stats_copies
     int coalesce;          // bf16 result with N % 8 == 0, ldc % 8 == 0: LDS-staged 128-byte row segments
 };
 
@@ -421,17 +422,29 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
         }
         if (p.stats) {
+            // reduce over the 8 row lanes, combine the workgroup's WM wave rows through LDS (a region behind the park slices), then
+            // ONE contiguous fp32 atomic per column and workgroup: what serialises in L2 is the number of (instruction, 128-byte
+            // line) pairs per line -- M-tiles x 1 this way, against M-tiles x WM x 16 with per-wave strided atomics (measured: 9 ns each)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
                 for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
             }
-            if (lane < 8 && n < p.N) {
+            float* st = reinterpret_cast<float*>(smem + Cfg::WM * Cfg::WN * (TM * 32 * 128));    // [WM][sum | sq][GBN]
+            if (lane < 8) {
+                float* row = st + wm * (2 * GBN) + wn * 64 + c8 * 8;
+                *reinterpret_cast<float4v*>(row) = float4v{ssum[0], ssum[1], ssum[2], ssum[3]};
+                *reinterpret_cast<float4v*>(row + 4) = float4v{ssum[4], ssum[5], ssum[6], ssum[7]};
+                *reinterpret_cast<float4v*>(row + GBN) = float4v{ssq[0], ssq[1], ssq[2], ssq[3]};
+                *reinterpret_cast<float4v*>(row + GBN + 4) = float4v{ssq[4], ssq[5], ssq[6], ssq[7]};
+            }
+            __syncthreads();
+            for (int t = tid; t < 2 * GBN; t += Cfg::THREADS) {
+                float v = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    atomicAdd(p.stats + n + k, ssum[k]);
-                    atomicAdd(p.stats + p.N + n + k, ssq[k]);
-                }
+                for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
+                const int which = t / GBN, col = n0 + (t % GBN);
+                if (col < p.N) atomicAdd(p.stats + (long long)((m0 / GBM) % p.stats_copies) * 2 * p.N + which * p.N + col, v);
             }
         }
         return;
@@ -663,9 +676,10 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
     }
     if (p.stats) {              // every wave's LDS atomics are in: one global atomic per column and workgroup
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* dst = p.stats + (long long)(blockIdx.x % p.stats_copies) * 2 * p.N;
         for (int n = tid; n < p.N; n += 64 * AS_WAVES) {
-            atomicAdd(p.stats + n, stats_s[n]);
-            atomicAdd(p.stats + p.N + n, stats_s[n_tiles * AS_BN + n]);
+            atomicAdd(dst + n, stats_s[n]);
+            atomicAdd(dst + p.N + n, stats_s[n_tiles * AS_BN + n]);
         }
     }
 }
@@ -802,7 +816,9 @@ extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
 
 template <bool OUT_F32, typename Cfg, int MODE>
 static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
-    const size_t lds = (size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES;
+    // staging ring; the epilogue reuses it for the waves' output slices and, behind them, the BatchNorm-statistics combine area
+    const size_t lds = std::max((size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES,
+                                (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
     if (lds > 65536) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -826,10 +842,12 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (stats_done) *stats_done = 0;
     if (a.addend && (out_f32 || (reinterpret_cast<uintptr_t>(a.addend) & 15u))) return EPI_ERR_UNSUPPORTED;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
-    // BatchNorm statistics from the GEMM epilogue are OFF by default (EPI_FUSE_BN_STATS=1 enables them): measured on MI355X the
-    // per-channel fp32 atomics of 512 .. 2048 workgroups on the same 64 .. 256 addresses serialise in L2 at ~200 ns each -- the
-    // 64-channel layer-1 convolutions went from 26 us to 230 .. 430 us (profiles/r02_*, DESIGN.md "measured and rejected")
-    static const bool fuse_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS"); return e && e[0] == '1'; }();
+    // BatchNorm statistics from the GEMM epilogue (on; EPI_FUSE_BN_STATS=0 keeps the separate statistics pass: 8.46 vs 8.49 ms/step,
+    // 471 vs 507 launches, profiles/r02_fs_steady_state_d_*).  First version, measured and rejected: per-WAVE
+    // atomics, 8 lanes x 8 strided columns per instruction -- 16 (instruction, line) pairs per wave and line, which L2 serialises at
+    // ~9 ns each (layer-1 convolutions 26 us -> 230 .. 430 us, profiles/r02_fs_steady_state_x_*).  Now: one contiguous atomic
+    // instruction per workgroup after an LDS combine (as the standalone statistics kernel does).
+    static const bool fuse_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS"); return !(e && e[0] == '0'); }();
     float* const want_stats = fuse_stats ? a.stats : nullptr;
     a.stats = nullptr;
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
@@ -1569,6 +1587,7 @@ extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int 
         if ((long long)B * H * W * Cin >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;      // 32-bit element offsets in the gather
     }
     a.stats = bn_sums;
+    a.stats_copies = epi_bn_sum_copies(Cout);
     return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
 }
 

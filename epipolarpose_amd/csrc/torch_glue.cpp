@@ -118,6 +118,7 @@ Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, b
     if (has_res) TORCH_CHECK(nhwc_bf16(residual) && residual.sizes() == x.sizes(), "FusedBatchNormAct: residual layout");
     const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
     TORCH_CHECK(b.weight.numel() == C, "FusedBatchNormAct: channel count mismatch");
+    TORCH_CHECK(!training || b.sums_ws.numel() == 2 * C * epi_bn_sum_copies((int)C), "FusedBatchNormAct: sums_ws must be [epi_bn_sum_copies(C)][2C]");
     int* fl = b.flags.data_ptr<int>();
     Tensor sums_ws = b.sums_ws;
     if (training && !sums_ready) {
@@ -254,6 +255,7 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
     Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
     int sums_done = 0;
     Tensor sums_ws = sp.sums_ws;
+    TORCH_CHECK(!training || sums_ws.numel() == 2 * (int64_t)Cout * epi_bn_sum_copies(Cout), "conv_bn_act: sums_ws must be [epi_bn_sum_copies(C)][2C]");
     if (training) {             // the accumulator hand-over of bn_forward, done here because the GEMM epilogue may fill sums_ws
         int* fl = sp.flags.data_ptr<int>();
         if (fl[0]) sums_ws.zero_();

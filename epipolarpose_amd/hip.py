@@ -55,6 +55,7 @@ _SIGNATURES = {
     "epi_conv2d_pack_weight_bwd_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
     "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
+    "epi_bn_sum_copies": (_i, [_i]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -628,9 +629,14 @@ def _cl_weight_bf16(weight):
     return w if w.is_contiguous(memory_format=torch.channels_last) else w.contiguous(memory_format=torch.channels_last)
 
 
+def bn_sum_copies(channels):
+    """Accumulator copies of a BatchNorm layer's forward statistics buffer (``sums_ws`` is [copies][2C] f32, epipolar_hip.h)."""
+    return 4 if channels <= 512 else 1
+
+
 def conv2d_fwd(x, weight, stride=1, padding=0, bn_sums=None):
     """x [B, Cin, H, W] channels_last bf16, weight [Cout, Cin, KH, KW] (channels_last memory) -> y [B, Cout, Ho, Wo]
-    channels_last bf16.  Reference: the nn.Conv2d calls of pose3d_resnet.py:21-88.  ``bn_sums`` (zeroed f32 [2*Cout]): asks for
+    channels_last bf16.  Reference: the nn.Conv2d calls of pose3d_resnet.py:21-88.  ``bn_sums`` (zeroed f32 [bn_sum_copies(Cout) * 2*Cout]): asks for
     the per-channel (sum, sum of squares) of the result from the GEMM epilogue; returns (y, done) then."""
     lib = load()
     x = _nhwc_bf16(x, "x")

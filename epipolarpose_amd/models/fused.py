@@ -31,7 +31,8 @@ class FusedBatchNormAct(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
-        self.register_buffer("sums_ws", torch.zeros(2 * num_features), persistent=False)   # kernel accumulator, kept zero
+        # kernel accumulator [copies][2C], kept zero
+        self.register_buffer("sums_ws", torch.zeros(hip.bn_sum_copies(num_features) * 2 * num_features), persistent=False)
         self.register_buffer("bwd_sums", torch.zeros(2 * num_features), persistent=False)  # (dbeta | dgamma) accumulator
         # accumulator hand-over state shared with the C++ autograd glue (csrc/torch_glue.cpp): [0] sums_ws holds a forward's
         # sums that no backward has cleared yet, [1] bwd_sums holds a backward's sums that no forward has cleared yet

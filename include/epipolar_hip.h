@@ -199,7 +199,9 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  * (+ `out += residual`) of lib/models/pose3d_resnet.py:31-47,68-88,158-183,186-188.
  *   x, residual, y : [R][C] bf16 (R = B*H*W, C % 8 == 0);  gamma, beta, running_mean, running_var, mean, rstd : [C] f32
  *   scale_shift    : [2C] f32 out (scale = gamma*rstd, shift = beta - mean*scale), reused by the backward
- *   sums_ws        : [2C] f32 accumulator (training) that must be ZERO on entry; on return it holds the batch sums.
+ *   sums_ws        : [epi_bn_sum_copies(C)][2C] f32 accumulator (training) that must be ZERO on entry; on return its copies add
+ *                    up to the batch sums (the producers -- row blocks of the statistics kernel, M tiles of a convolution
+ *                    epilogue -- spread their fp32 atomics over the copies; what serialises in L2 is atomics per 128-byte line).
  *                    Keep one per layer and hand it to the layer's backward call as `fwd_sums_clear`, which zeroes
  *                    it again (steady-state training and graph replays then need no memset); a caller that runs a
  *                    training-mode forward without the backward clears it itself before the next forward.
@@ -210,11 +212,12 @@ int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B,
  *                    layer's next backward pass without a separate memset
  * Backward (training):  dbeta_dgamma [2C] f32, ZERO on entry, out = (sum dz, sum dz*xhat);  dx [R][C];  dres [R][C] or NULL
  *   = gradient of the residual input;  y = saved forward output, required when relu && dres;
- *   fwd_sums_clear [2C] f32 or NULL: zeroed (the forward accumulator above).
+ *   fwd_sums_clear [epi_bn_sum_copies(C)][2C] f32 or NULL: zeroed (the forward accumulator above).
  *   param_grads [2C] f32 or NULL: a COPY of (dbeta | dgamma) in caller-owned memory outside the accumulator protocol -- hand
  *   THIS to the optimizer / autograd, never dbeta_dgamma itself: the layer's next forward clears that accumulator, which would
  *   wipe a gradient that is still waiting (gradient accumulation, a forward between backward and optimizer.step).
  * ------------------------------------------------------------------------------------------------ */
+int epi_bn_sum_copies(int C);       /* accumulator copies of a C-channel layer (4 for C <= 512, else 1) */
 int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                    float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
                    long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
@@ -238,7 +241,7 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
  * workspace: epi_conv2d_workspace_bytes(...) covers forward and backward-data of one layer.
  * ------------------------------------------------------------------------------------------------ */
 size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
-/* bn_sums [2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
+/* bn_sums [epi_bn_sum_copies(Cout)][2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
  * the launch can do it (unsplit result), the GEMM epilogue adds the per-channel (sum, sum of squares) of the bf16 outputs and sets
  * *bn_sums_done = 1 -- pass training = 2 to epi_bn_act_fwd then (its statistics pass is skipped); otherwise *bn_sums_done = 0 and
  * bn_sums is untouched. */

@@ -39,6 +39,8 @@ def test_host_only_entry_points(lib):
     assert lib.epi_softargmax3d_workspace_bytes(32, 17, 64, 64, 64) == 32 * 17 * 64 * 32
     assert lib.epi_softargmax3d_workspace_bytes(0, 17, 64, 64, 64) == 0
     assert lib.epi_argmax_workspace_bytes(4, 100) == 4 * 16
+    from epipolarpose_amd import hip
+    assert all(lib.epi_bn_sum_copies(c) == hip.bn_sum_copies(c) for c in (8, 64, 256, 512, 1024, 2048))
     # argument validation happens before any device work
     assert lib.epi_softargmax3d_fwd(None, 0, 0, 1, 1, 1, 1, 1, None, None, None, None, 0, None) == 1
     assert lib.epi_joint_loss(None, None, None, 1, 3, 0, 0, 1, None, None, None) == 1

@@ -216,8 +216,9 @@ def test_conv2d_fwd_fused_bn_statistics(geo):
     gen = torch.Generator().manual_seed(cin + cout + k + h)
     x = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
     w = _rand((cout, cin, k, k), gen, scale=(2.0 / (cin * k * k)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
-    sums = torch.zeros(2 * cout, dtype=torch.float32, device=dev)
+    sums = torch.zeros(hip.bn_sum_copies(cout) * 2 * cout, dtype=torch.float32, device=dev)
     y, done = hip.conv2d_fwd(x, w, stride, pad, bn_sums=sums)
+    sums = sums.view(-1, 2 * cout).sum(0)                 # the M tiles spread their atomics over the copies
     ref = hip.conv2d_fwd(x, w, stride, pad)
     assert torch.equal(y, ref)
     if done:
@@ -279,11 +280,17 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
         dy = _rand(tuple(y.shape), torch.Generator().manual_seed(9)).to(dev).contiguous(memory_format=torch.channels_last)
         y.backward(dy)
         outs.append((y.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
-    # same kernels and roundings; the BatchNorm sums are accumulated with fp32 atomics (order varies run to run), so "identical" means
-    # within a couple of bf16 units in the last place of the largest value
+    # same kernels and roundings, but the BatchNorm sums are accumulated with fp32 atomics whose order varies run to run
+    # and a sum that differs in its last bit can flip a bf16 rounding; one ReLU mask flipped at an activation next to zero then moves
+    # a handful of gradient elements by O(dy * w).  Measured on MI355X (two runs of the SAME path against each other, 4 x 16 x 16
+    # inputs): up to 0.5 % of the gradient elements beyond a couple of bf16 units of the largest value, up to 1.5 % in the L2 norm.
+    # A wrong or missing term (shortcut gradient, a stage's dgrad) is O(1) in both measures.
     def near(a, b, what):
-        tol = 2 ** -6 * max(float(b.float().abs().max()), 1e-6)
-        assert float((a.float() - b.float()).abs().max()) <= tol, what
+        a, b = a.float(), b.float()
+        tol = 2 ** -6 * max(float(b.abs().max()), 1e-6)
+        d = (a - b).abs()
+        assert float((d > tol).float().mean()) <= 2e-2, (what, float(d.max()), tol)
+        assert float(d.norm()) <= 4e-2 * max(float(b.norm()), 1e-6), (what, float(d.norm()), float(b.norm()))
     near(outs[0][0], outs[1][0], "output")
     near(outs[0][1], outs[1][1], "input gradient")
     for k in outs[0][2]:

@@ -139,7 +139,7 @@ def bench_bn():
         f32 = lambda n, v=0.0: torch.full((n,), v, dtype=torch.float32, device=DEV)  # noqa: E731
         gamma, beta, rm, rv = f32(c, 1.0), f32(c), f32(c), f32(c, 1.0)
         nbt = torch.zeros((), dtype=torch.long, device=DEV)
-        stats, sums, bsums = f32(4 * c), f32(2 * c), f32(2 * c)
+        stats, sums, bsums = f32(4 * c), f32(2 * c * hip.bn_sum_copies(c)), f32(2 * c)
         sp, st = stats.data_ptr(), torch.cuda.current_stream().cuda_stream
         R = b * h * w
 
