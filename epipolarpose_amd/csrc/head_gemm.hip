@@ -85,6 +85,8 @@ struct GemmArgs {
     float* stats;          // [stats_copies][2N] or null: += per-column (sum, sum of squares) of the bf16 result (unsplit bf16 launches only);
     int stats_copies;      //   M tile t adds into copy t % stats_copies
     int coalesce;          // bf16 result with N % 8 == 0, ldc % 8 == 0: LDS-staged 128-byte row segments
+    int patch_px;          // conv_patch_kernel: pixels of the staged patch (256 + 2W + 2, rounded up to 8)
+    int chunks_per_split;  // conv_patch_kernel: 64-channel chunks per blockIdx.y
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -684,6 +686,297 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 / pad-1 convolutions (forward, and backward-data = the same convolution with the taps mirrored): patch-stationary
+// implicit GEMM.  The generic gather kernel stages a fresh 256 x 64 A tile for EVERY filter tap -- nine L2 -> LDS fills of (almost)
+// the same pixels per 64-channel chunk.  PMC on MI355X (profiles/r02_pmc_l2_conv_gemms.txt): L2 hit rate 0.77 .. 0.84, fabric
+// reads ~ the algorithmic bytes, yet only ~9 TB/s of L2 -> LDS fill for 15 % MFMA utilisation -- the K loop waits for the slowest
+// line of each tile, and the bytes in flight are capped by the LDS that receives them.  So: fewer bytes per MFMA.
+//   * rows of the GEMM are consecutive NHWC pixels, so tap (dy, dx) of output pixel m is input pixel m + dy*W + dx of the SAME
+//     linear pixel array: a workgroup stages the pixels [m0 - W - 1, m0 + 256 + W + 1) of one 64-channel chunk ONCE (the "patch",
+//     128 bytes per pixel) and runs all nine taps from it with a row shift; taps that cross an image border are masked per
+//     (row, tap) by pointing the lane at a 128-byte block of zeros in LDS (one v_cndmask on the address, not four on the data)
+//   * the weights stream through a ring of [BN][64] tiles, one per tap, three deep where LDS allows
+//   * A traffic per chunk: one patch (256 + 2W + 2 pixels) instead of 9 x 256 pixels; with the B tiles 193 KB instead of 432 KB
+//     per 256 x 128 x 576 MACs.
+// DMA schedule: every step (tap) issues exactly BP + 1 instructions per wave -- the B tile two steps ahead and one piece of the
+// NEXT chunk's patch (a dummy piece when there is none), so one counted `s_waitcnt vmcnt(BP + 1)` + barrier per step retires
+// everything but the group just issued.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TM_, int WM_, int WN_> struct PatchCfg {
+    static constexpr int TM = TM_, WM = WM_, WN = WN_, NW = WM_ * WN_, THREADS = 64 * NW;
+    static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * 64, B_BYTES = BN * 128, BP = BN / 8 / NW;
+    static_assert(NW == 8 && BP >= 1, "8 waves");
+};
+typedef PatchCfg<2, 4, 2> PatchWide;      // 256 x 128
+typedef PatchCfg<1, 8, 1> PatchNarrow;    // 256 x 64 (the 64-channel layers)
+typedef PatchCfg<1, 4, 2> PatchHalf;      // 128 x 128 (mid layers: enough tiles to fill the chip without a channel split)
+constexpr int PATCH_TAPS = 9, PATCH_APW = 8;     // patch pieces (8 pixels, 1 KiB) per wave: one per tap step, the ninth step issues a dummy
+
+// -DEPI_PATCH_TRACE (tools/patch_trace.cpp only): s_memtime stamps of every 16th workgroup's wave 0 -- start, prologue issued,
+// prologue landed, after every step's barrier, loop drained, results stored
+#ifdef EPI_PATCH_TRACE
+__device__ unsigned long long epi_patch_trace[64 * 96];
+#define PATCH_STAMP(i)                                                                                                   \
+    do {                                                                                                                 \
+        const int wg_ = blockIdx.x + gridDim.x * blockIdx.y;                                                             \
+        if (lane == 0 && wid == 0 && wg_ % 16 == 0 && wg_ / 16 < 64 && (i) < 96) epi_patch_trace[(wg_ / 16) * 96 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PATCH_STAMP(i) do {} while (0)
+#endif
+
+template <typename Cfg, int NB>
+__global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p) {
+    constexpr int TM = Cfg::TM, GBN = Cfg::BN, BP = Cfg::BP, NW = Cfg::NW, BB = Cfg::B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 patches][NB weight tiles][1 KiB dummy][128 B zeros]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
+    const int tiles_n = (p.N + GBN - 1) / GBN;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    const int tile_id = lid % (int)gridDim.x, split_id = lid / (int)gridDim.x;
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    const int m0 = tile_m * Cfg::BM, n0 = tile_n * GBN;
+    const int W = p.ga.Wg, H = p.ga.Hg, Cs = p.ga.Cs;
+    const int c_begin = split_id * p.chunks_per_split, c_end = min(Cs / GBK, c_begin + p.chunks_per_split);
+    const int PB = p.patch_px * 128;
+    const int ring_off = 2 * PB, dummy_off = ring_off + NB * BB, zero_off = dummy_off + 1024;
+    PATCH_STAMP(0);
+    if (tid < 32) reinterpret_cast<float*>(smem + zero_off)[tid] = 0.f;
+    const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
+
+    // ---- staging roles: wave w owns patch pieces q = j*8 + w (patch pixels 8q .. 8q+7) and weight-tile pieces w*BP + ps ----
+    // patch piece j of this wave: source element offset of the lane's 16 bytes (chunk c adds c*64), or -1 outside the pixel array
+    auto a_off = [&](int j) -> int {
+        const int prow = (j * NW + wid) * 8 + (lane >> 3);
+        const long long pin = (long long)m0 - (W + 1) + prow;           // linear input pixel behind patch pixel prow
+        const bool ok = prow < p.patch_px && pin >= 0 && pin < p.M;
+        return ok ? (int)pin * Cs + (((lane & 7) ^ ((prow >> 1) & 7)) << 3) : -1;
+    };
+    const unsigned short* b_ptr[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int ps = 0; ps < BP; ++ps) {
+        const int trow = (wid * BP + ps) * 8 + (lane >> 3);
+        const int n = n0 + trow;
+        b_ok[ps] = n < p.N;
+        b_ptr[ps] = p.Bt + (long long)(b_ok[ps] ? n : 0) * p.ldb + (((lane & 7) ^ ((trow >> 1) & 7)) << 3);
+    }
+    auto issue_a = [&](int j, int c, int buf) {
+        const bool real = j < PATCH_APW && (j * NW + wid) * 8 < p.patch_px && c < c_end;
+        char* dst = real ? smem + buf * PB + (j * NW + wid) * 1024 : smem + dummy_off;
+        const int off = a_off(j);
+        glds16((real && off >= 0) ? reinterpret_cast<const void*>(p.A + off + c * GBK) : reinterpret_cast<const void*>(zero_src), dst);
+    };
+    auto issue_b = [&](int t, int c, int slot, bool real) {
+#pragma unroll
+        for (int ps = 0; ps < BP; ++ps) {
+            char* dst = real ? smem + ring_off + slot * BB + (wid * BP + ps) * 1024 : smem + dummy_off;
+            const void* src = (real && b_ok[ps]) ? reinterpret_cast<const void*>(b_ptr[ps] + t * Cs + c * GBK) : reinterpret_cast<const void*>(zero_src);
+            glds16(src, dst);
+        }
+    };
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    const int b_frag = ring_off + lds_off(wn * 64 + frow, fhalf);
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: the first chunk's whole patch and the first NB - 1 weight tiles ----
+    const int nsteps = (c_end - c_begin) * PATCH_TAPS;
+    if (nsteps > 0) {
+#pragma unroll
+        for (int j = 0; j < PATCH_APW; ++j) issue_a(j, c_begin, 0);
+        issue_b(0, c_begin, 0, true);
+        if (NB > 2) issue_b(1, c_begin, 1, true);
+    }
+    __builtin_amdgcn_sched_barrier(0);             // the index math below runs behind the DMA, not in front of it
+    // ---- per (row, tap) validity: the tap must stay inside the row's own image (computed while the prologue's DMA is in flight) ----
+    int amask[TM], arow[TM];
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+        const int r = wm * (TM * 32) + ti * 32 + frow, m = m0 + r;
+        arow[ti] = r;
+        const int j = m % W, i = (m / W) % H;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < PATCH_TAPS; ++t) {
+            const int y = i + p.ga.dy[t], x = j + p.ga.dx[t];
+            if (m < p.M && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) mask |= 1 << t;
+        }
+        amask[ti] = mask;
+    }
+    PATCH_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PATCH_STAMP(2);
+    int step_no = 0;
+
+    int slot = 0;                                                         // ring slot of the current step
+    for (int c = c_begin; c < c_end; ++c) {
+        const int pbuf = (c - c_begin) & 1;
+#pragma unroll
+        for (int t = 0; t < PATCH_TAPS; ++t) {
+            // -- this step's DMA group: weight tile NB - 1 steps ahead, one piece of the next chunk's patch --
+            {
+                int ta = t + NB - 1, ca = c;
+                if (ta >= PATCH_TAPS) { ta -= PATCH_TAPS; ca += 1; }
+                int sa = slot + NB - 1; if (sa >= NB) sa -= NB;
+                issue_b(ta, ca, sa, ca < c_end);
+                issue_a(t, c + 1, pbuf ^ 1);
+            }
+            // -- MFMAs of tap t from the resident patch --
+            const int sh = (p.ga.dy[t] + 1) * W + p.ga.dx[t] + 1;
+            int a_addr[TM];
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti) {
+                const int pr = arow[ti] + sh;
+                const int in = pbuf * PB + pr * 128 + ((fhalf ^ ((pr >> 1) & 7)) << 4);
+                a_addr[ti] = ((amask[ti] >> t) & 1) ? in : zero_off;
+            }
+            const int b_addr = b_frag + slot * BB;
+            bf16x8 af[2][TM], bfr[2][2];
+            auto read_frags = [&](int ks, bf16x8 (&a)[TM], bf16x8 (&b)[2]) {
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti) a[ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(smem + (a_addr[ti] ^ (ks << 5))));
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) b[tj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(smem + ((b_addr ^ (ks << 5)) + tj * 4096)));
+            };
+            read_frags(0, af[0], bfr[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) read_frags(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][tj], af[ks & 1][ti], acc[ti][tj], 0, 0, 0);
+            }
+            // -- everything but the group just issued has landed (next step's weight tile; at t = 8 the next patch) --
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * (BP + 1)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == NB ? 0 : slot + 1;
+            PATCH_STAMP(3 + step_no);
+            ++step_no;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // dummy pieces and fragment reads are done: the epilogue reuses the LDS
+    PATCH_STAMP(3 + step_no);
+
+    // ---- epilogue: lane holds, for tile (ti, tj): row wm*TM*32 + ti*32 + (lane & 31), columns wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e ----
+    if (gridDim.y > 1) {        // split over channel chunks: fp32 partials, finished by splitk_finish_kernel
+        float* slab = p.slabs + (long long)split_id * p.M * p.N;
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti) {
+            const int m = m0 + arow[ti];
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + tj * 32 + 8 * q + 4 * fhalf;
+                    if (n + 3 < p.N) {
+                        float4v t; t.x = acc[ti][tj][4 * q]; t.y = acc[ti][tj][4 * q + 1]; t.z = acc[ti][tj][4 * q + 2]; t.w = acc[ti][tj][4 * q + 3];
+                        *reinterpret_cast<float4v*>(slab + (long long)m * p.N + n) = t;
+                    }
+                }
+        }
+#ifdef EPI_PATCH_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PATCH_STAMP(4 + step_no);
+#endif
+        return;
+    }
+    // bf16 result through the wave's own LDS slice as whole 128-byte row segments; residual addend and BatchNorm statistics as in
+    // head_gemm_kernel's coalesced epilogue
+    char* mine = smem + wid * (TM * 32 * 128);
+    const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
+    auto out_row = [&](int it) -> long long {
+        const int m = m0 + wm * (TM * 32) + it * 8 + (lane >> 3);
+        return (m >= p.M || n >= p.N) ? -1 : m;
+    };
+    uint4v ad[TM * 4];
+    if (p.addend) {
+#pragma unroll
+        for (int it = 0; it < TM * 4; ++it) {
+            const long long orow = out_row(it);
+            ad[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti) {
+        const int row = ti * 32 + frow;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 t;
+                t.x = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
+                t.y = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
+                const int unit = tj * 8 + 2 * q + fhalf;
+                *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
+            }
+    }
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < TM * 4; ++it) {
+        const int row = it * 8 + (lane >> 3), sw = row & 15;
+        const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
+        const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
+        const long long orow = out_row(it);
+        if (orow < 0) continue;
+        if (p.stats) {
+            const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
+                ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
+                ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
+            }
+        }
+        uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+        if (p.addend) o = add_bf16x8(o, ad[it]);
+        *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
+        }
+        float* st = reinterpret_cast<float*>(smem + NW * (TM * 32 * 128));    // [WM][sum | sq][GBN], behind the waves' slices
+        if (lane < 8) {
+            float* row = st + wm * (2 * GBN) + wn * 64 + c8 * 8;
+            *reinterpret_cast<float4v*>(row) = float4v{ssum[0], ssum[1], ssum[2], ssum[3]};
+            *reinterpret_cast<float4v*>(row + 4) = float4v{ssum[4], ssum[5], ssum[6], ssum[7]};
+            *reinterpret_cast<float4v*>(row + GBN) = float4v{ssq[0], ssq[1], ssq[2], ssq[3]};
+            *reinterpret_cast<float4v*>(row + GBN + 4) = float4v{ssq[4], ssq[5], ssq[6], ssq[7]};
+        }
+        __syncthreads();
+        for (int t = tid; t < 2 * GBN; t += Cfg::THREADS) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
+            const int which = t / GBN, col = n0 + (t % GBN);
+            if (col < p.N) atomicAdd(p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N + which * p.N + col, v);
+        }
+    }
+#ifdef EPI_PATCH_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PATCH_STAMP(4 + step_no);
+#endif
+}
+
 // sum the split-K slabs, add the bias, convert and write through the row scatter (N % 4 == 0)
 template <bool OUT_F32>
 __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit, int nphase, GemmArgs p) {
@@ -836,6 +1129,77 @@ static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hi
     return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN>(a, pl, nphase, st);
 }
 
+#ifdef EPI_PATCH_TRACE
+extern "C" int epi_patch_trace_read(unsigned long long* out, int clear) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(epi::epi_patch_trace), sizeof(unsigned long long) * 64 * 96) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zeros[64 * 96];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(epi::epi_patch_trace), zeros, sizeof(zeros)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
+// ---- conv_patch_kernel: eligibility, plan, launch ----
+enum { PATCH_WIDE = 0, PATCH_NARROW = 1, PATCH_HALF = 2 };
+struct PatchPlan { bool ok; int cfg, nb, patch_px, nsplit, cps; long long tiles; size_t lds; };
+// EPI_CONV3X3_PATCH: 0 never (the generic gather kernel), 1 (default) where the tiles fill the chip without a channel split, 2 always
+static int g_patch_mode = -1;
+static int patch_mode() {
+    if (g_patch_mode < 0) { const char* e = getenv("EPI_CONV3X3_PATCH"); g_patch_mode = e ? atoi(e) : 1; }
+    return g_patch_mode;
+}
+// tuning / test hook: set the mode (0 .. 2; anything else only queries); returns the mode in force before the call
+extern "C" int epi_conv3x3_patch_mode(int mode) {
+    const int before = patch_mode();
+    if (mode >= 0 && mode <= 2) g_patch_mode = mode;
+    return before;
+}
+static PatchPlan patch_plan(int M, int N, int Cs, int W, size_t workspace_bytes) {
+    PatchPlan pl = {};
+    const int nchunks = Cs / GBK;
+    // tile: 256 x 64 for the 64-channel layers; 256 x 128 when that already fills the chip, else 128 x 128 (twice the tiles)
+    pl.cfg = N <= 64 ? PATCH_NARROW : PATCH_WIDE;
+    if (pl.cfg == PATCH_WIDE && (long long)((M + 255) / 256) * ((N + 127) / 128) < 200) pl.cfg = PATCH_HALF;
+    const int bm = pl.cfg == PATCH_HALF ? 128 : 256, bn = pl.cfg == PATCH_NARROW ? 64 : 128;
+    const int tm = pl.cfg == PATCH_WIDE ? 2 : 1, wmv = pl.cfg == PATCH_NARROW ? 8 : 4;
+    pl.patch_px = (bm + 2 * W + 2 + 7) / 8 * 8;
+    if (pl.patch_px > 8 * 8 * PATCH_APW) return pl;                 // one patch piece per wave and tap step
+    const size_t epi = (size_t)8 * tm * 32 * 128 + (size_t)wmv * 2 * bn * sizeof(float);
+    for (pl.nb = 3; pl.nb >= 2; --pl.nb) {
+        pl.lds = std::max((size_t)2 * pl.patch_px * 128 + (size_t)pl.nb * bn * 128 + 1024 + 128, epi);
+        if (pl.lds <= 160 * 1024) break;
+    }
+    if (pl.nb < 2) return pl;
+    pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    pl.nsplit = 1;
+    if (pl.tiles < 120) {                                           // (measured: 128 unsplit workgroups of 36 steps beat 4 splits + finish)
+        if (patch_mode() < 2) return pl;                            // would need a channel split: left to the generic kernel
+        pl.nsplit = (int)std::min<long long>(nchunks, std::max<long long>(1, 256 / pl.tiles));
+    }
+    while (pl.nsplit > 1 && (size_t)pl.nsplit * M * N * sizeof(float) > workspace_bytes) --pl.nsplit;
+    pl.cps = (nchunks + pl.nsplit - 1) / pl.nsplit;
+    pl.nsplit = (nchunks + pl.cps - 1) / pl.cps;
+    pl.ok = pl.tiles <= 0x7fffffffLL;
+    return pl;
+}
+static bool patch_eligible(const GemmArgs& a, bool out_f32, int nphase) {
+    if (patch_mode() == 0 || out_f32 || nphase != 1 || !a.ga.enabled || a.ph.enabled || a.sc.enabled || a.bias || !a.coalesce) return false;
+    if (a.ga.stride != 1 || a.ga.Hg != a.ga.Hs || a.ga.Wg != a.ga.Ws || a.ga.Cs % GBK || a.K != PATCH_TAPS * a.ga.Cs) return false;
+    for (int t = 0; t < PATCH_TAPS; ++t)
+        if (a.ga.dy[t] < -1 || a.ga.dy[t] > 1 || a.ga.dx[t] < -1 || a.ga.dx[t] > 1) return false;
+    return (long long)a.M * a.ga.Cs < (1LL << 31) && gemm_tile_override() == 0;
+}
+template <typename Cfg, int NB>
+static int launch_patch(const GemmArgs& a, const PatchPlan& pl, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Cfg, NB>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return EPI_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_patch_kernel<Cfg, NB>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), pl.lds, st, a);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
 // stats_done (may be null): set to 1 when a.stats was accumulated by the GEMM launch itself (unsplit bf16 result), else 0 --
 // the caller then computes the statistics with its own pass
 static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr) {
@@ -873,6 +1237,26 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
 #undef EPI_ASTAT
         EPI_CHECK_LAUNCH();
         return EPI_OK;
+    }
+    if (patch_eligible(a, out_f32, nphase)) {           // 3x3 / stride 1: the patch-stationary kernel
+        const PatchPlan pp = patch_plan(a.M, a.N, a.ga.Cs, a.ga.Wg, workspace ? workspace_bytes : 0);
+        if (pp.ok) {
+            a.patch_px = pp.patch_px;
+            a.chunks_per_split = pp.cps;
+            if (pp.nsplit > 1) a.slabs = (float*)workspace;
+            else if (want_stats) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
+            int rc;
+            if (pp.cfg == PATCH_NARROW) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3>(a, pp, st) : launch_patch<PatchNarrow, 2>(a, pp, st);
+            else if (pp.cfg == PATCH_HALF) rc = pp.nb == 3 ? launch_patch<PatchHalf, 3>(a, pp, st) : launch_patch<PatchHalf, 2>(a, pp, st);
+            else rc = pp.nb == 3 ? launch_patch<PatchWide, 3>(a, pp, st) : launch_patch<PatchWide, 2>(a, pp, st);
+            if (rc != EPI_OK) return rc;
+            if (pp.nsplit > 1) {
+                const long long n = (long long)a.M * (a.N >> 2);
+                hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.slabs, pp.nsplit, 1, a);
+                EPI_CHECK_LAUNCH();
+            }
+            return EPI_OK;
+        }
     }
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
     if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
@@ -1560,6 +1944,11 @@ extern "C" size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int C
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
     if (Ho <= 0 || Wo <= 0) return 0;
     size_t need = epi_gemm_workspace_bytes(B * Ho * Wo, Cout, KH * KW * Cin, 1);                       // forward
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && Cin % GBK == 0 && Cout % GBK == 0) {          // patch kernel: split over channel chunks
+        const PatchPlan pf = patch_plan(B * H * W, Cout, Cin, W, (size_t)-1), pb = patch_plan(B * H * W, Cin, Cout, W, (size_t)-1);
+        if (pf.ok && pf.nsplit > 1) need = std::max(need, (size_t)pf.nsplit * B * H * W * Cout * sizeof(float));
+        if (pb.ok && pb.nsplit > 1) need = std::max(need, (size_t)pb.nsplit * B * H * W * Cin * sizeof(float));
+    }
     if (stride == 1) need = std::max(need, epi_gemm_workspace_bytes(B * H * W, Cin, KH * KW * Cout, 1));   // backward-data
     else need = std::max(need, epi_gemm_workspace_bytes(B * ((H + 1) / 2) * ((W + 1) / 2), Cin, 4 * Cout, 4));
     return need;

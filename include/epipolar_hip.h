@@ -241,6 +241,11 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
  * workspace: epi_conv2d_workspace_bytes(...) covers forward and backward-data of one layer.
  * ------------------------------------------------------------------------------------------------ */
 size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+/* 3x3 / stride 1 / pad 1 forward and backward-data have a second kernel that stages each pixel patch once for all nine taps
+ * (csrc/head_gemm.hip, conv_patch_kernel).  mode 0: never; 1 (default, or EPI_CONV3X3_PATCH): where its tiles fill the chip without a
+ * split over channel chunks; 2: always.  Sets the mode (other values only query) and returns the previous one.  Same results
+ * either way (fp32 accumulation over the same products; the summation order differs). */
+int epi_conv3x3_patch_mode(int mode);
 /* bn_sums [epi_bn_sum_copies(Cout)][2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
  * the launch can do it (unsplit result), the GEMM epilogue adds the per-channel (sum, sum of squares) of the bf16 outputs and sets
  * *bn_sums_done = 1 -- pass training = 2 to epi_bn_act_fwd then (its statistics pass is skipped); otherwise *bn_sums_done = 0 and

@@ -75,6 +75,56 @@ def test_conv2d_full_size_bench_shapes_spot_check():
         assert (dw - refdw).abs().max().item() <= 3e-3 * refdw.abs().max().item() + 1e-5
 
 
+# (Cin, Cout, B, H, W): the patch-stationary 3x3 kernel -- narrow (Cout 64) / wide tiles, unsplit (many tiles) / split over channel
+# chunks (few tiles), ragged last tile (B*H*W % 256 != 0), several images per tile (small H*W), H != W, a three-deep and (W = 96)
+# a two-deep weight ring, Cout that does not fill the last 128-wide tile
+PATCH_CASES = [(64, 64, 32, 64, 64), (64, 64, 3, 10, 10), (128, 128, 32, 32, 32), (128, 192, 5, 12, 20), (256, 256, 7, 16, 16), (512, 512, 9, 8, 8),
+               (64, 128, 2, 96, 96), (256, 64, 3, 6, 4), (128, 128, 1, 3, 3)]
+
+
+@pytest.fixture
+def patch_kernel_always():
+    from epipolarpose_amd import hip
+    before = hip.conv3x3_patch_mode(2)
+    yield
+    hip.conv3x3_patch_mode(before)
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "%dto%d_b%d_%dx%d" % c)
+def test_conv3x3_patch_kernel_vs_torch_fp32(case, patch_kernel_always):
+    """3x3 / stride 1 / pad 1 forward and backward-data (the patch-stationary kernel: every filter tap from one staged pixel patch,
+    border taps masked per row) against fp32 F.conv2d on the same bf16 operands -- every image border, image-to-image transitions
+    inside one tile and the zero tail of the last tile included."""
+    from epipolarpose_amd import hip
+    cin, cout, b, h, w_ = case
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin + cout + b + h * w_)
+    x = _rand((b, cin, h, w_), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    w = _rand((cout, cin, 3, 3), gen, scale=(2.0 / (cin * 9)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    sl = slice(0, b, max(1, b // 3))                        # a few images in fp32 (first, middle, last third)
+    y = hip.conv2d_fwd(x, w, 1, 1)
+    ref = F.conv2d(x[sl].float(), w.float(), padding=1)
+    assert (y[sl].float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    dy = _rand(tuple(y.shape), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    r = _rand(tuple(x.shape), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    wb = hip.conv2d_pack_weight_bwd(w, 1, 1)
+    dx = hip.conv2d_bwd_data(dy, wb, tuple(x.shape), 3, 1, 1)
+    n = len(range(*sl.indices(b)))
+    refdx = torch.nn.grad.conv2d_input((n, cin, h, w_), w.float(), dy[sl].float(), padding=1)
+    assert (dx[sl].float() - refdx).abs().max().item() <= 2 ** -7 * refdx.abs().max().item() + 1e-6
+    fused = hip.conv2d_bwd_data(dy, wb, tuple(x.shape), 3, 1, 1, addend=r)
+    assert torch.equal(fused, (dx.float() + r.float()).to(torch.bfloat16))
+    # BatchNorm statistics from the epilogue (unsplit launches) are the column sums of what was written
+    sums = torch.zeros(hip.bn_sum_copies(cout) * 2 * cout, dtype=torch.float32, device=dev)
+    y2, done = hip.conv2d_fwd(x, w, 1, 1, bn_sums=sums)
+    assert torch.equal(y2, y)
+    if done:
+        yf = y.float()
+        got = sums.view(-1, 2 * cout).sum(0)
+        torch.testing.assert_close(got[:cout], yf.sum(dim=(0, 2, 3)), rtol=2e-4, atol=2e-3 * float(yf.abs().max()) * (yf.numel() / cout) ** 0.5)
+        torch.testing.assert_close(got[cout:], (yf * yf).sum(dim=(0, 2, 3)), rtol=2e-4, atol=1e-3)
+
+
 def test_conv2d_unsupported_geometry_is_refused():
     from epipolarpose_amd import hip
     dev = torch.device("cuda:0")
