@@ -726,9 +726,12 @@ __device__ unsigned long long epi_patch_trace[64 * 96];
 #define PATCH_STAMP(i) do {} while (0)
 #endif
 
-template <typename Cfg, int NB>
-__global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p) {
+// SINGLE: the workgroup covers ONE 64-channel chunk (64-channel layers, or one chunk per split) -- no second patch buffer, no
+// patch pieces in the per-step DMA group, and (narrow tiles) two workgroups per CU: one's prologue / epilogue under the other's loop
+template <typename Cfg, int NB, bool SINGLE>
+__global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kernel(GemmArgs p) {      // (waves per SIMD)
     constexpr int TM = Cfg::TM, GBN = Cfg::BN, BP = Cfg::BP, NW = Cfg::NW, BB = Cfg::B_BYTES;
+    constexpr int NPATCH = SINGLE ? 1 : 2, GROUP = BP + (SINGLE ? 0 : 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 patches][NB weight tiles][1 KiB dummy][128 B zeros]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p)
     const int W = p.ga.Wg, H = p.ga.Hg, Cs = p.ga.Cs;
     const int c_begin = split_id * p.chunks_per_split, c_end = min(Cs / GBK, c_begin + p.chunks_per_split);
     const int PB = p.patch_px * 128;
-    const int ring_off = 2 * PB, dummy_off = ring_off + NB * BB, zero_off = dummy_off + 1024;
+    const int ring_off = NPATCH * PB, dummy_off = ring_off + NB * BB, zero_off = dummy_off + 1024;
     PATCH_STAMP(0);
     if (tid < 32) reinterpret_cast<float*>(smem + zero_off)[tid] = 0.f;
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p)
 
     int slot = 0;                                                         // ring slot of the current step
     for (int c = c_begin; c < c_end; ++c) {
-        const int pbuf = (c - c_begin) & 1;
+        const int pbuf = SINGLE ? 0 : (c - c_begin) & 1;
 #pragma unroll
         for (int t = 0; t < PATCH_TAPS; ++t) {
             // -- this step's DMA group: weight tile NB - 1 steps ahead, one piece of the next chunk's patch --
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p)
                 if (ta >= PATCH_TAPS) { ta -= PATCH_TAPS; ca += 1; }
                 int sa = slot + NB - 1; if (sa >= NB) sa -= NB;
                 issue_b(ta, ca, sa, ca < c_end);
-                issue_a(t, c + 1, pbuf ^ 1);
+                if (!SINGLE) issue_a(t, c + 1, pbuf ^ 1);
             }
             // -- MFMAs of tap t from the resident patch --
             const int sh = (p.ga.dy[t] + 1) * W + p.ga.dx[t] + 1;
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 1) void conv_patch_kernel(GemmArgs p)
                         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][tj], af[ks & 1][ti], acc[ti][tj], 0, 0, 0);
             }
             // -- everything but the group just issued has landed (next step's weight tile; at t = 8 the next patch) --
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * (BP + 1)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * GROUP) : "memory");
             __builtin_amdgcn_s_barrier();
             slot = slot + 1 == NB ? 0 : slot + 1;
             PATCH_STAMP(3 + step_no);
@@ -1050,9 +1053,12 @@ static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pip
     pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long long wgs = pl.tiles * nphase;
     const bool one_per_cu = cfg == CFG_BIG || pipe;
-    // no split once (nearly) every CU has a workgroup: measured per layer (tools/bench_conv.py), an unsplit 256-workgroup launch of
+    // no split once about half the CUs have a workgroup: measured per layer (tools/bench_conv.py), an unsplit 256-workgroup launch of
     // 16 K tiles beats two splits + the finish kernel (ResNet-50 layer4.conv1: 16 us vs 27 us)
-    const long long enough = 200, target = one_per_cu ? 256 : 512;
+    // (EPI_GEMM_ENOUGH: measurement switch.  120 vs 200 on MI355X, profiles/r02_conv_layers_e_*: the 128-tile layers -- ResNet-50
+    // layer3 1x1 at batch 32 -- run unsplit in 14.6 us instead of 21.9 us with four splits + finish; 60 loses again)
+    static const long long enough_env = [] { const char* e = getenv("EPI_GEMM_ENOUGH"); return e ? atoll(e) : 120LL; }();
+    const long long enough = enough_env, target = one_per_cu ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
         nsplit = (int)(target / wgs);               // floor: one workgroup over the resident capacity costs a whole extra round
@@ -1142,11 +1148,11 @@ extern "C" int epi_patch_trace_read(unsigned long long* out, int clear) {
 
 // ---- conv_patch_kernel: eligibility, plan, launch ----
 enum { PATCH_WIDE = 0, PATCH_NARROW = 1, PATCH_HALF = 2 };
-struct PatchPlan { bool ok; int cfg, nb, patch_px, nsplit, cps; long long tiles; size_t lds; };
-// EPI_CONV3X3_PATCH: 0 never (the generic gather kernel), 1 (default) where the tiles fill the chip without a channel split, 2 always
+struct PatchPlan { bool ok; int cfg, nb, patch_px, nsplit, cps; long long tiles; size_t lds; bool single; };
+// EPI_CONV3X3_PATCH: 0 never (the generic gather kernel), 1 only where the tiles fill the chip without a channel split, 2 (default) always
 static int g_patch_mode = -1;
 static int patch_mode() {
-    if (g_patch_mode < 0) { const char* e = getenv("EPI_CONV3X3_PATCH"); g_patch_mode = e ? atoi(e) : 1; }
+    if (g_patch_mode < 0) { const char* e = getenv("EPI_CONV3X3_PATCH"); g_patch_mode = e ? atoi(e) : 2; }
     return g_patch_mode;
 }
 // tuning / test hook: set the mode (0 .. 2; anything else only queries); returns the mode in force before the call
@@ -1166,8 +1172,9 @@ static PatchPlan patch_plan(int M, int N, int Cs, int W, size_t workspace_bytes)
     pl.patch_px = (bm + 2 * W + 2 + 7) / 8 * 8;
     if (pl.patch_px > 8 * 8 * PATCH_APW) return pl;                 // one patch piece per wave and tap step
     const size_t epi = (size_t)8 * tm * 32 * 128 + (size_t)wmv * 2 * bn * sizeof(float);
+    pl.single = pl.cfg == PATCH_NARROW && nchunks == 1;             // (a wide tile's registers do not allow two workgroups per CU)
     for (pl.nb = 3; pl.nb >= 2; --pl.nb) {
-        pl.lds = std::max((size_t)2 * pl.patch_px * 128 + (size_t)pl.nb * bn * 128 + 1024 + 128, epi);
+        pl.lds = std::max((size_t)(pl.single ? 1 : 2) * pl.patch_px * 128 + (size_t)pl.nb * bn * 128 + 1024 + 128, epi);
         if (pl.lds <= 160 * 1024) break;
     }
     if (pl.nb < 2) return pl;
@@ -1190,12 +1197,12 @@ static bool patch_eligible(const GemmArgs& a, bool out_f32, int nphase) {
         if (a.ga.dy[t] < -1 || a.ga.dy[t] > 1 || a.ga.dx[t] < -1 || a.ga.dx[t] > 1) return false;
     return (long long)a.M * a.ga.Cs < (1LL << 31) && gemm_tile_override() == 0;
 }
-template <typename Cfg, int NB>
+template <typename Cfg, int NB, bool SINGLE = false>
 static int launch_patch(const GemmArgs& a, const PatchPlan& pl, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Cfg, NB>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Cfg, NB, SINGLE>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return EPI_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv_patch_kernel<Cfg, NB>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), pl.lds, st, a);
+    hipLaunchKernelGGL((conv_patch_kernel<Cfg, NB, SINGLE>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), pl.lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
@@ -1246,7 +1253,8 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             if (pp.nsplit > 1) a.slabs = (float*)workspace;
             else if (want_stats) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
             int rc;
-            if (pp.cfg == PATCH_NARROW) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3>(a, pp, st) : launch_patch<PatchNarrow, 2>(a, pp, st);
+            if (pp.cfg == PATCH_NARROW && pp.single) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3, true>(a, pp, st) : launch_patch<PatchNarrow, 2, true>(a, pp, st);
+            else if (pp.cfg == PATCH_NARROW) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3>(a, pp, st) : launch_patch<PatchNarrow, 2>(a, pp, st);
             else if (pp.cfg == PATCH_HALF) rc = pp.nb == 3 ? launch_patch<PatchHalf, 3>(a, pp, st) : launch_patch<PatchHalf, 2>(a, pp, st);
             else rc = pp.nb == 3 ? launch_patch<PatchWide, 3>(a, pp, st) : launch_patch<PatchWide, 2>(a, pp, st);
             if (rc != EPI_OK) return rc;
@@ -1617,6 +1625,33 @@ __global__ void slab_reduce_few_kernel(const float* __restrict__ slabs, int nspl
     else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + e) = o; }
 }
 
+// MANY pending reductions in one launch (every split weight gradient of a backward pass): blockIdx.x = chunk of 512 elements; the
+// row (result tensor) a chunk belongs to is found by bisection over the rows' first chunks
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const EpiSlabReduce* __restrict__ rows, int nrows) {
+    int lo = 0, hi = nrows - 1;
+    while (lo < hi) {                                   // last row with chunk_begin <= blockIdx.x (uniform: scalar loads)
+        const int mid = (lo + hi + 1) >> 1;
+        if (rows[mid].chunk_begin <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const EpiSlabReduce r = rows[lo];
+    const long long e = (((long long)blockIdx.x - r.chunk_begin) * 256 + threadIdx.x) * 2;
+    if (e >= r.n) return;
+    float s0 = 0.f, s1 = 0.f;
+    const float* src = r.slabs + e;
+    int k = 0;
+    for (; k + 3 < r.nsplit; k += 4) {                  // four slabs in flight
+        const float2 a = *reinterpret_cast<const float2*>(src + (long long)k * r.n), b = *reinterpret_cast<const float2*>(src + (long long)(k + 1) * r.n);
+        const float2 c = *reinterpret_cast<const float2*>(src + (long long)(k + 2) * r.n), d = *reinterpret_cast<const float2*>(src + (long long)(k + 3) * r.n);
+        s0 += (a.x + b.x) + (c.x + d.x); s1 += (a.y + b.y) + (c.y + d.y);
+    }
+    for (; k < r.nsplit; ++k) {
+        const float2 v = *reinterpret_cast<const float2*>(src + (long long)k * r.n);
+        s0 += v.x; s1 += v.y;
+    }
+    if (r.out_bf16) reinterpret_cast<unsigned int*>(r.out)[e >> 1] = pack_bf16x2(s0, s1);
+    else { float2 o; o.x = s0; o.y = s1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(r.out) + e) = o; }
+}
+
 }  // namespace epi
 
 struct TnPlan { int cfg; long long tiles; int nsplit, rps; };      // cfg: 0 small, 1 narrow, 2 big
@@ -1664,7 +1699,10 @@ static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, hipStream_t st) 
     return EPI_OK;
 }
 
-static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size_t slab_bytes, hipStream_t st) {
+// defer (may be null): when the reduction is split, leave the slabs in slab_ws and describe the pending reduce instead of launching it
+// (nsplit = 0 in *defer: nothing pending, `out` is complete)
+static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size_t slab_bytes, hipStream_t st, EpiSlabReduce* defer = nullptr) {
+    if (defer) { *defer = EpiSlabReduce(); }
     if (!a.A || !a.B || !out || a.R <= 0 || a.I <= 0 || a.J <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8 || (a.gather && a.Cs % 8)) return EPI_ERR_UNSUPPORTED;
     if (a.gather && (long long)((a.R + a.Hg * a.Wg - 1) / (a.Hg * a.Wg)) * a.Hs * a.Ws * a.ldb >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;
@@ -1685,6 +1723,10 @@ static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size
     else if (pl.cfg == 1) rc = a.gather ? launch_tn_cfg<TnNarrow, true>(a, pl, st) : launch_tn_cfg<TnNarrow, false>(a, pl, st);
     else rc = a.gather ? launch_tn_cfg<TnSmall, true>(a, pl, st) : launch_tn_cfg<TnSmall, false>(a, pl, st);
     if (rc != EPI_OK) return rc;
+    if (pl.nsplit > 1 && defer) {
+        defer->slabs = slab_ws; defer->out = out; defer->n = n; defer->nsplit = pl.nsplit; defer->out_bf16 = out_bf16;
+        return EPI_OK;
+    }
     if (pl.nsplit > 1) {
         if (pl.nsplit >= 16 && n / 2 < 262144)       // many slabs of a small result: spread the split dimension over the threads
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n / 2 + 7) / 8)), dim3(256), 0, st, slab_ws, pl.nsplit, n, out, out_bf16);
@@ -1727,8 +1769,10 @@ extern "C" int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, void* d
 //   dW[co][kh][kw][ci] = sum over (n, oh, ow) of dy[n][oh][ow][co] * x[n][oh*stride + kh - pad][ow*stride + kw - pad][ci]
 // = the TN GEMM with A = dy (plain rows) and B = x gathered per tap along the columns.  Replaces MIOpen's split-K wrw kernels
 // and the memset / zero-fill / cast launches around them.  workspace: epi_gemm_tn_workspace_bytes(B*Ho*Wo, Cout, Cin, KH*KW).
-extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
-                                     int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+extern "C" int epi_conv2d_bwd_weight_deferred(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
+                                              int KW, int stride, int pad, void* workspace, size_t workspace_bytes, EpiSlabReduce* pending,
+                                              epi_stream_t stream) {
+    if (pending) *pending = EpiSlabReduce();
     if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return EPI_ERR_INVALID_ARGUMENT;
     if (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16) return EPI_ERR_UNSUPPORTED;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -1738,7 +1782,21 @@ extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, in
     if (!(KH == 1 && KW == 1 && stride == 1 && pad == 0)) {
         a.gather = 1; a.Hg = Ho; a.Wg = Wo; a.Hs = H; a.Ws = W; a.Cs = Cin; a.stride = stride; a.pad = pad; a.KW = KW;
     }
-    return launch_tn(a, dw, dw_dtype == EPI_BF16, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_tn(a, dw, dw_dtype == EPI_BF16, (float*)workspace, workspace_bytes, (hipStream_t)stream, pending);
+}
+
+extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
+                                     int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return epi_conv2d_bwd_weight_deferred(x, dy, dw, dw_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" long long epi_slab_reduce_chunks(long long n) { return n > 0 ? (n / 2 + 255) / 256 : 0; }
+
+extern "C" int epi_slab_reduce_multi(const EpiSlabReduce* rows_dev, int nrows, long long total_chunks, epi_stream_t stream) {
+    if (!rows_dev || nrows <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL) return EPI_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(epi::slab_reduce_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, rows_dev, nrows);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

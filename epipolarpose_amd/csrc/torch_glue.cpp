@@ -12,11 +12,13 @@
 //   adam_prepare  the per-step pointer table of FusedAdam (170 parameters) without a Python loop
 #include <torch/extension.h>
 #include <torch/custom_class.h>
+#include <torch/csrc/autograd/engine.h>
 #include <c10/hip/HIPStream.h>
 
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -101,6 +103,135 @@ Tensor& workspace(size_t bytes, const Tensor& like) {
     if (!ws.defined() || (size_t)ws.numel() < bytes)
         ws = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 16)}, like.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
     return ws;
+}
+
+// ---- deferred weight-gradient reductions ---------------------------------------------------------------------------
+// A split weight gradient leaves fp32 slabs that one more launch per layer would sum (55 launches per ResNet-50 backward, 4 .. 10 us
+// each and mostly latency).  Instead every backward-weight launch of a backward pass parks its slabs in ONE arena and registers the
+// outstanding sum; a final callback of the autograd engine (it runs on the caller's stream once the whole graph task is done,
+// before backward() returns) sums them all with a single epi_slab_reduce_multi launch.  Anything that consumes a gradient earlier --
+// the bucketed all-reduce hooks -- calls flush_pending_reduces() first.  EPI_DEFER_WGRAD_REDUCE=0 restores one reduce per layer.
+struct PendingReduces {
+    Tensor arena;                    // bytes; slabs of the current backward pass, bump-allocated
+    size_t used = 0, wanted = 0;     // wanted: what this pass would have needed (the arena grows after the flush)
+    size_t target = (size_t)64 << 20;   // capacity of the next allocation: the largest `wanted` seen so far
+    std::vector<EpiSlabReduce> rows;
+    // the gradients the rows point to, held WEAKLY through their storage: a strong reference would keep AccumulateGrad from adopting
+    // the tensor as .grad (it would clone the not-yet-reduced memory instead); a storage that died before the flush is skipped
+    std::vector<c10::weak_intrusive_ptr<c10::StorageImpl>> keep;
+    c10::Device dev = c10::Device(c10::kCPU);
+    Tensor table_dev, table_host;    // device copy of rows / pinned staging
+    std::vector<EpiSlabReduce> uploaded;
+    hipEvent_t upload_done = nullptr;
+    int device = -1;
+};
+PendingReduces g_pend;
+int g_defer = -1;
+bool defer_enabled() {
+    if (g_defer < 0) { const char* e = getenv("EPI_DEFER_WGRAD_REDUCE"); g_defer = (e && e[0] == '0') ? 0 : 1; }
+    return g_defer != 0;
+}
+// test / measurement hook: returns the previous setting
+bool defer_wgrad_reduce(bool on) {
+    const bool before = defer_enabled();
+    g_defer = on ? 1 : 0;
+    return before;
+}
+
+void flush_pending_reduces() {
+    PendingReduces& P = g_pend;
+    if (!P.rows.empty()) {
+        const int nrows = (int)P.rows.size();
+        long long chunks = 0;
+        std::vector<c10::intrusive_ptr<c10::StorageImpl>> alive(P.keep.size());
+        for (size_t i = 0; i < P.rows.size(); ++i) {
+            alive[i] = P.keep[i].lock();
+            if (!alive[i]) { P.rows[i].n = 0; P.rows[i].nsplit = 0; }                    // nobody holds this gradient any more
+        }
+        for (auto& r : P.rows) { r.chunk_begin = chunks; chunks += epi_slab_reduce_chunks(r.n); }
+        const size_t bytes = sizeof(EpiSlabReduce) * (size_t)nrows;
+        auto stream = c10::hip::getCurrentHIPStream(P.dev.index());
+        const auto byte_opts = at::TensorOptions().dtype(at::kByte).device(P.dev);
+        // the table is the same from step to step (same layers, same arena offsets, gradients from the caching allocator usually at
+        // the same addresses): upload only when it changed
+        const bool same = P.uploaded.size() == P.rows.size() && std::memcmp(P.uploaded.data(), P.rows.data(), bytes) == 0;
+        if (!same) {
+            if (!P.table_dev.defined() || (size_t)P.table_dev.numel() < bytes) {
+                P.table_dev = at::empty({(int64_t)std::max<size_t>(bytes, 8192)}, byte_opts);
+                P.table_host = at::empty({P.table_dev.numel()}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+            }
+            if (P.upload_done) {                             // the previous copy must have read the staging buffer
+                TORCH_CHECK(hipEventSynchronize(P.upload_done) == hipSuccess, "deferred reduce: event");
+            } else {
+                TORCH_CHECK(hipEventCreateWithFlags(&P.upload_done, hipEventDisableTiming) == hipSuccess, "deferred reduce: event");
+            }
+            std::memcpy(P.table_host.data_ptr(), P.rows.data(), bytes);
+            TORCH_CHECK(hipMemcpyAsync(P.table_dev.data_ptr(), P.table_host.data_ptr(), bytes, hipMemcpyHostToDevice, stream.stream()) == hipSuccess,
+                        "deferred reduce: table upload");
+            TORCH_CHECK(hipEventRecord(P.upload_done, stream.stream()) == hipSuccess, "deferred reduce: event");
+            P.uploaded = P.rows;
+        }
+        if (chunks > 0) {
+            ScopedTimer timer("conv_bwd_weight", 0.0, 0.0, reinterpret_cast<epi_stream_t>(stream.stream()));    // (the reduce belongs to the family's time)
+            check(epi_slab_reduce_multi(reinterpret_cast<const EpiSlabReduce*>(P.table_dev.data_ptr()), nrows, chunks,
+                                        reinterpret_cast<epi_stream_t>(stream.stream())), "epi_slab_reduce_multi");
+        }
+        P.rows.clear();
+        P.keep.clear();
+    }
+    P.target = std::max(P.target, P.wanted);
+    if (P.arena.defined() && P.target > (size_t)P.arena.numel()) P.arena = Tensor();            // regrown by the next pass (stream-ordered free)
+    P.used = 0;
+    P.wanted = 0;
+}
+
+// slab memory for one backward-weight launch of `bytes`, or nullptr when the arena is full (the caller then reduces at once)
+void* pending_slab_alloc(size_t bytes, const Tensor& like) {
+    PendingReduces& P = g_pend;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (P.device != like.device().index()) {            // one process drives one GPU; a device change starts over
+        TORCH_CHECK(P.rows.empty(), "deferred reduce: pending work on another device");
+        P.arena = Tensor(); P.table_dev = Tensor(); P.uploaded.clear(); P.device = like.device().index();
+    }
+    P.wanted += bytes;
+    if (!P.arena.defined()) {
+        if (P.used != 0) return nullptr;                 // dropped mid-pass: wait for the next pass
+        const size_t cap = std::max(P.wanted, P.target);
+        P.arena = at::empty({(int64_t)cap}, like.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+    }
+    if (P.used + bytes > (size_t)P.arena.numel()) return nullptr;
+    void* p = static_cast<char*>(P.arena.data_ptr()) + P.used;
+    P.used += bytes;
+    return p;
+}
+
+// May the gradient of weight `w` stay unreduced until the end of the backward pass?  Only when nothing looks at it earlier: `w` is a
+// leaf (no upstream node reads the gradient), has no gradient yet (AccumulateGrad will adopt the tensor, not add to it), and carries
+// no tensor hooks / post-accumulate hooks (those run inside the pass; the bucketed all-reduce, which hooks the LAST gradient of each
+// bucket, flushes explicitly for the others).
+bool gradient_consumed_after_backward(const Tensor& w) {
+    if (!w.defined() || !w.is_leaf() || w.grad().defined()) return false;
+    if (torch::autograd::impl::post_acc_grad_hooks(w) != nullptr) return false;
+    if (!torch::autograd::impl::hooks(w).empty()) return false;
+    auto acc = torch::autograd::impl::try_get_grad_accumulator(w);
+    if (acc && (!acc->tensor_pre_hooks().empty() || !acc->pre_hooks().empty() || !acc->retains_grad_hooks().empty())) return false;
+    return true;
+}
+
+void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
+    PendingReduces& P = g_pend;
+    P.rows.push_back(r);
+    P.keep.push_back(grad.storage().getWeakStorageImpl());
+    P.dev = grad.device();
+    // inside a backward pass: sum everything when the pass ends (one callback per registration -- the first one to run does the
+    // work, the rest find nothing; a flag instead would be left stale by a pass that aborts); outside a pass: at once
+    bool queued = false;
+    try {
+        torch::autograd::Engine::get_default_engine().queue_callback([] { flush_pending_reduces(); });
+        queued = true;
+    } catch (const c10::Error&) {
+    }
+    if (!queued) flush_pending_reduces();
 }
 
 // ---- BatchNorm halves shared by bn_act and conv_bn_act ------------------------------------------------------------
@@ -237,6 +368,7 @@ struct StageSaved {       // what a stage's backward needs
     std::vector<int64_t> w_sizes, w_strides;
     int K, S, P;
     bool relu, has_res, w_f32, need_dx;
+    Tensor w;                           // the weight itself (a parameter or its training copy): consulted by the deferred-reduce rule
 };
 
 Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& residual, bool training, double momentum, double eps, bool need_dx,
@@ -299,6 +431,7 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
         save->w_sizes = w.sizes().vec();
         save->w_strides = (w.is_contiguous(at::MemoryFormat::ChannelsLast) || (K == 1 && w.is_contiguous())) ? w.strides().vec() : w16.strides().vec();
         save->K = K; save->S = S; save->P = P; save->relu = sp.relu; save->has_res = has_res; save->w_f32 = w.scalar_type() != at::kBFloat16;
+        save->w = w;
         save->need_dx = need_dx;
     }
     return y;
@@ -328,12 +461,21 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
     }
     if (need_dw) {
         out.dw = at::empty_strided(sv.w_sizes, sv.w_strides, x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
-        Tensor& ws = workspace(epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K), x);
-        ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
-                          2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), current_stream(x));
-        check(epi_conv2d_bwd_weight(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, K, K, S,
-                                    P, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
-              "epi_conv2d_bwd_weight");
+        const size_t slab_bytes = epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K);
+        const bool may_defer = slab_bytes && defer_enabled() && gradient_consumed_after_backward(sv.w);
+        if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();      // e.g. a second use of a shared weight adds to the first
+        void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
+        EpiSlabReduce pend = {};
+        Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x);
+        {
+            ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
+                              2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), current_stream(x));
+            check(epi_conv2d_bwd_weight_deferred(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
+                                                 K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
+                                                 slabs ? &pend : nullptr, current_stream(x)),
+                  "epi_conv2d_bwd_weight");
+        }
+        if (pend.nsplit > 0) pending_register(pend, out.dw);
     }
     return out;
 }
@@ -494,6 +636,12 @@ std::tuple<bool, std::vector<Tensor>> adam_prepare(const std::vector<Tensor>& pa
     return std::make_tuple(changed, keep);
 }
 
+// optimizer.zero_grad(set_to_none=True) for a parameter list without a Python loop (~170 parameters + their bf16 training copies)
+void clear_grads(const std::vector<Tensor>& tensors) {
+    for (const Tensor& t : tensors)
+        if (t.defined()) t.mutable_grad().reset();
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -501,6 +649,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
+    m.def("flush_pending_reduces", &flush_pending_reduces,
+          "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
+    m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");
+    m.def("clear_grads", &clear_grads, "drop the .grad of every tensor in the list (zero_grad(set_to_none=True))");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");
     m.def("timing_enable", &timing_enable, "record HIP events around every epi_* launch made by this extension");
     m.def("timing_collect", &timing_collect, "{name: (launches, total ms, algorithmic FLOPs, algorithmic bytes)}; clears the records");

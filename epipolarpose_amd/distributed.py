@@ -135,6 +135,11 @@ class BucketedGradSync:
 
     def _launch(self, bi):
         flat, plist, views = self.buckets[bi]
+        if flat.is_cuda:
+            # split weight gradients are summed by ONE launch at the end of backward (csrc/torch_glue.cpp); a bucket that leaves
+            # earlier needs the sums of what has been computed so far now
+            from . import hip
+            hip.glue().flush_pending_reduces()
         if BUCKET_PACK == "cat" and self._pack_cat(flat, plist, views):
             self._finish_launch(bi, flat, plist, views)
             return

@@ -55,6 +55,9 @@ _SIGNATURES = {
     "epi_conv2d_pack_weight_bwd_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
     "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
+    "epi_conv2d_bwd_weight_deferred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp, _vp]),
+    "epi_slab_reduce_chunks": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "epi_slab_reduce_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
     "epi_bn_sum_copies": (_i, [_i]),
     "epi_conv3x3_patch_mode": (_i, [_i]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
@@ -632,7 +635,7 @@ def _cl_weight_bf16(weight):
 
 def conv3x3_patch_mode(mode=-1):
     """Kernel choice for 3x3 / stride-1 convolutions (0 generic gather kernel, 1 patch kernel where it needs no channel split, 2 patch
-    kernel always); sets ``mode`` when 0 .. 2 and returns the previous mode (epipolar_hip.h)."""
+    kernel always -- the default); sets ``mode`` when 0 .. 2 and returns the previous mode (epipolar_hip.h)."""
     return int(load().epi_conv3x3_patch_mode(int(mode)))
 
 

@@ -85,6 +85,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if lp_modules else None
         self._lp_of = {}
+        self._clear_list = None
         self._lp_modules = lp_modules
         self._offs = offs
         for m in lp_modules:
@@ -184,11 +185,14 @@ class FusedAdam(torch.optim.Optimizer):
         return dict(self._lp_of)
 
     def zero_grad(self, set_to_none=True):
-        super().zero_grad(set_to_none=set_to_none)
+        if set_to_none:                      # one C++ call for the ~170 parameters and their bf16 training copies
+            if self._clear_list is None:
+                self._clear_list = list(self._params) + list(self._lp_of.values())
+            hip.glue().clear_grads(self._clear_list)
+            return
+        super().zero_grad(set_to_none=False)
         for lp in self._lp_of.values():
-            if set_to_none:
-                lp.grad = None
-            elif lp.grad is not None:
+            if lp.grad is not None:
                 lp.grad.zero_()
 
     @torch.no_grad()

@@ -242,8 +242,8 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
  * ------------------------------------------------------------------------------------------------ */
 size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 /* 3x3 / stride 1 / pad 1 forward and backward-data have a second kernel that stages each pixel patch once for all nine taps
- * (csrc/head_gemm.hip, conv_patch_kernel).  mode 0: never; 1 (default, or EPI_CONV3X3_PATCH): where its tiles fill the chip without a
- * split over channel chunks; 2: always.  Sets the mode (other values only query) and returns the previous one.  Same results
+ * (csrc/head_gemm.hip, conv_patch_kernel).  mode 0: never; 1: only where its tiles fill the chip without a split over channel
+ * chunks; 2 (default; EPI_CONV3X3_PATCH overrides): always.  Sets the mode (other values only query) and returns the previous one.  Same results
  * either way (fp32 accumulation over the same products; the summation order differs). */
 int epi_conv3x3_patch_mode(int mode);
 /* bn_sums [epi_bn_sum_copies(Cout)][2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
@@ -274,6 +274,25 @@ int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int 
  *   KH*KW <= 16, Cin % 8 == 0, Cout % 8 == 0.  workspace: epi_gemm_tn_workspace_bytes(B*Ho*Wo, Cout, Cin, KH*KW). */
 int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout,
                           int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+/* Deferred reduction.  A weight gradient whose reduction over batch*pixels was split leaves one fp32 slab per split in the
+ * workspace; summing them is a separate small launch per layer (55 per ResNet-50 backward).  The _deferred entry point runs the
+ * GEMM only: the slabs stay in `workspace` -- memory the caller must then leave untouched until the reduce has run -- and
+ * *pending describes the outstanding sum (pending->nsplit == 0: nothing outstanding, dw is complete).  epi_slab_reduce_multi
+ * performs MANY of them in one launch: rows_dev = a device array of the descriptors with chunk_begin filled in (row r starts at
+ * chunk  sum over the rows before it of epi_slab_reduce_chunks(n)), total_chunks = the sum over all rows.  pending == NULL
+ * behaves like epi_conv2d_bwd_weight. */
+typedef struct EpiSlabReduce {
+    const float* slabs;     /* [nsplit][n] fp32 partial results */
+    void* out;              /* n elements, f32 or bf16 */
+    long long n;
+    long long chunk_begin;  /* filled by the caller: first 512-element chunk of this row in the multi launch */
+    int nsplit, out_bf16;
+} EpiSlabReduce;
+int epi_conv2d_bwd_weight_deferred(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout,
+                                   int KH, int KW, int stride, int pad, void* workspace, size_t workspace_bytes,
+                                   EpiSlabReduce* pending, epi_stream_t stream);
+long long epi_slab_reduce_chunks(long long n);
+int epi_slab_reduce_multi(const EpiSlabReduce* rows_dev, int nrows, long long total_chunks, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (J = columns per filter tap; ntap = 1 for epi_gemm_tn_bf16, 16 for the

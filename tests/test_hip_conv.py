@@ -348,3 +348,59 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
     for (ka, va), (kb, vb) in zip(unit.state_dict().items(), staged.state_dict().items()):      # running statistics advanced alike
         assert ka == kb
         near(va, vb, ka)
+
+
+def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
+    """Split weight gradients summed by one launch at the end of backward() (the autograd engine's final callback) against one
+    reduce per layer: the same slabs, fp32 sums in a different order; also when backward() runs twice in a row, when a gradient is
+    consumed from a hook in the middle of the pass (flush_pending_reduces, the bucketed all-reduce path) and for a bare call
+    outside any backward pass."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.models import pose3d_resnet as P
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(P.ResidualUnit(64, 64, P._BOTTLENECK, 1), P.ResidualUnit(256, 128, P._BOTTLENECK, 2),
+                              P.ResidualUnit(512, 128, P._BOTTLENECK, 1)).to(dev).to(memory_format=torch.channels_last)
+    x = _rand((8, 64, 32, 32), torch.Generator().manual_seed(6)).to(dev).contiguous(memory_format=torch.channels_last)
+    pre = torch.nn.Conv2d(64, 64, 1, bias=False).to(dev).to(torch.bfloat16)
+
+    def grads(hooked=False):
+        net.zero_grad()
+        seen = {}
+        handles = []
+        if hooked:                                       # read one gradient in the middle of backward, as a bucket hook would
+            name, prm = list(net.named_parameters())[-4]
+            def hook(p_):
+                hip.glue().flush_pending_reduces()
+                seen[name] = p_.grad.detach().float().clone()
+            handles.append(prm.register_post_accumulate_grad_hook(hook))
+        y = net(pre(x).contiguous(memory_format=torch.channels_last))
+        y.float().square().mean().backward()
+        for h in handles:
+            h.remove()
+        out = {k: p_.grad.detach().float().clone() for k, p_ in net.named_parameters()}
+        for k, v in seen.items():
+            assert torch.equal(v, out[k]), k             # what the hook saw is the finished gradient
+        return out
+
+    before = hip.glue().defer_wgrad_reduce(False)
+    try:
+        ref = grads()
+        hip.glue().defer_wgrad_reduce(True)
+        for hooked in (False, False, True):
+            got = grads(hooked)
+            for k in ref:
+                scale = float(ref[k].abs().max()) + 1e-12
+                # run-to-run noise of this network (BatchNorm sums by atomics, bf16 activations: see the unit-node test) is ~4 % of the
+                # largest element; a reduce that did not run leaves O(1) garbage
+                assert float((got[k] - ref[k]).abs().max()) <= 1e-1 * scale, k
+                assert float((got[k] - ref[k]).norm()) <= 5e-2 * float(ref[k].norm()) + 1e-12, k
+    finally:
+        hip.glue().defer_wgrad_reduce(before)
+    # outside a backward pass the reduce runs at once
+    w = _rand((64, 64, 3, 3), torch.Generator().manual_seed(7)).to(dev).contiguous(memory_format=torch.channels_last)
+    xx = _rand((32, 64, 32, 32), torch.Generator().manual_seed(8)).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = _rand((32, 64, 32, 32), torch.Generator().manual_seed(9)).to(dev).contiguous(memory_format=torch.channels_last)
+    dw = hip.conv2d_bwd_weight(xx, dy, 3, 1, 1, dtype=torch.float32)
+    refdw = torch.nn.grad.conv2d_weight(xx.float(), tuple(w.shape), dy.float(), padding=1)
+    assert (dw - refdw).abs().max().item() <= 3e-3 * refdw.abs().max().item() + 1e-5
