@@ -97,12 +97,84 @@ std::map<std::string, std::tuple<int64_t, double, double, double>> timing_collec
 
 // split-K / slab scratch shared by every GEMM-type launch of this process (one process per GPU; launches on one stream are
 // ordered, so consecutive kernels may reuse it); grown on demand, never shrunk
-Tensor& workspace(size_t bytes, const Tensor& like) {
-    static std::vector<Tensor> per_device(64);
-    Tensor& ws = per_device[like.device().index()];
+Tensor& workspace(size_t bytes, const Tensor& like, int slot = 0) {      // slot 1: launches on the weight-gradient stream
+    static std::vector<Tensor> per_device(128);
+    Tensor& ws = per_device[2 * like.device().index() + slot];
     if (!ws.defined() || (size_t)ws.numel() < bytes)
         ws = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 16)}, like.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
     return ws;
+}
+
+// ---- weight gradients on a second stream ---------------------------------------------------------------------------
+// Nothing inside the backward pass waits for a weight gradient: the chain is BatchNorm backward -> backward-data -> the next layer's
+// BatchNorm backward, and the weight-gradient GEMMs (1.7 of the 8 ms step on ResNet-50 / batch 32, each one under-filling the chip)
+// only have to be complete when the optimizer runs.  With EPI_WGRAD_STREAM != 0 they are launched on a second HIP stream: fork = an
+// event recorded on the main stream after the layer's BatchNorm backward, join = the main stream waits once, at the end of the pass
+// (the engine's final callback, together with the deferred slab sums) or earlier when somebody consumes a gradient inside the pass.
+// The operands (x, dy) are kept alive until the join instead of being registered with the caching allocator's per-stream use list
+// (recordStream costs an event per tensor when it is freed; holding ~2x the activations for one backward pass costs nothing at 288 GB).
+struct SideStream {
+    int mode = -1;                   // 0 off, 1 same priority as the main stream, 2 lowest priority
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> fork;    // ring of events recorded on the main stream
+    size_t next = 0;
+    hipEvent_t joined = nullptr;
+    hipStream_t main_stream = nullptr;
+    bool dirty = false, low_priority = false;
+    std::vector<Tensor> keep;
+};
+SideStream g_side;
+int side_mode() {
+    if (g_side.mode < 0) { const char* e = getenv("EPI_WGRAD_STREAM"); g_side.mode = e ? atoi(e) : 1; }
+    return g_side.mode;
+}
+int wgrad_stream_mode(int mode) {             // test / measurement hook: returns the previous setting
+    const int before = side_mode();
+    g_side.mode = mode;
+    return before;
+}
+
+// the main stream waits for everything launched on the weight-gradient stream so far
+void side_join() {
+    SideStream& S = g_side;
+    if (!S.dirty) return;
+    TORCH_CHECK(hipEventRecord(S.joined, S.stream) == hipSuccess, "weight-gradient stream: join event");
+    hipStream_t main_stream = c10::hip::getCurrentHIPStream(S.device).stream();
+    TORCH_CHECK(hipStreamWaitEvent(main_stream, S.joined, 0) == hipSuccess, "weight-gradient stream: join");
+    if (S.main_stream != main_stream)         // forked from another stream than the one that joins: that one has to wait as well
+        TORCH_CHECK(hipStreamWaitEvent(S.main_stream, S.joined, 0) == hipSuccess, "weight-gradient stream: join");
+    S.keep.clear();
+    S.dirty = false;
+}
+
+// returns the weight-gradient stream, ordered behind everything enqueued on `main_stream` so far
+hipStream_t side_fork(const Tensor& like, hipStream_t main_stream) {
+    SideStream& S = g_side;
+    const int dev = like.device().index();
+    const bool low = S.mode == 2;
+    if (S.stream == nullptr || S.device != dev || S.low_priority != low) {
+        if (S.stream != nullptr && S.device == dev) side_join();           // priority class changed: drain, then replace the stream
+        TORCH_CHECK(!S.dirty, "weight-gradient stream: pending work on another device");
+        if (S.stream != nullptr) (void)hipStreamDestroy(S.stream);        // (destruction waits for the stream's work)
+        int least = 0, greatest = 0;
+        TORCH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess, "weight-gradient stream: priority range");
+        TORCH_CHECK(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, low ? least : 0) == hipSuccess,
+                    "weight-gradient stream: create");
+        if (S.fork.empty()) {
+            S.fork.resize(256);
+            for (auto& e : S.fork) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "weight-gradient stream: event");
+            TORCH_CHECK(hipEventCreateWithFlags(&S.joined, hipEventDisableTiming) == hipSuccess, "weight-gradient stream: event");
+        }
+        S.device = dev;
+        S.low_priority = low;
+    }
+    hipEvent_t e = S.fork[S.next++ % S.fork.size()];
+    TORCH_CHECK(hipEventRecord(e, main_stream) == hipSuccess, "weight-gradient stream: fork event");
+    TORCH_CHECK(hipStreamWaitEvent(S.stream, e, 0) == hipSuccess, "weight-gradient stream: fork");
+    S.main_stream = main_stream;
+    S.dirty = true;
+    return S.stream;
 }
 
 // ---- deferred weight-gradient reductions ---------------------------------------------------------------------------
@@ -140,6 +212,7 @@ bool defer_wgrad_reduce(bool on) {
 
 void flush_pending_reduces() {
     PendingReduces& P = g_pend;
+    side_join();                     // the slabs (and the unsplit gradients) may still be in flight on the weight-gradient stream
     if (!P.rows.empty()) {
         const int nrows = (int)P.rows.size();
         long long chunks = 0;
@@ -218,13 +291,10 @@ bool gradient_consumed_after_backward(const Tensor& w) {
     return true;
 }
 
-void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
-    PendingReduces& P = g_pend;
-    P.rows.push_back(r);
-    P.keep.push_back(grad.storage().getWeakStorageImpl());
-    P.dev = grad.device();
-    // inside a backward pass: sum everything when the pass ends (one callback per registration -- the first one to run does the
-    // work, the rest find nothing; a flag instead would be left stale by a pass that aborts); outside a pass: at once
+// inside a backward pass: sum everything (and join the weight-gradient stream) when the pass ends -- one callback per registration,
+// the first one to run does the work, the rest find nothing (a flag instead would be left stale by a pass that aborts); outside a
+// pass: at once
+void end_of_pass_callback() {
     bool queued = false;
     try {
         torch::autograd::Engine::get_default_engine().queue_callback([] { flush_pending_reduces(); });
@@ -232,6 +302,14 @@ void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
     } catch (const c10::Error&) {
     }
     if (!queued) flush_pending_reduces();
+}
+
+void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
+    PendingReduces& P = g_pend;
+    P.rows.push_back(r);
+    P.keep.push_back(grad.storage().getWeakStorageImpl());
+    P.dev = grad.device();
+    end_of_pass_callback();
 }
 
 // ---- BatchNorm halves shared by bn_act and conv_bn_act ------------------------------------------------------------
@@ -462,20 +540,30 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
     if (need_dw) {
         out.dw = at::empty_strided(sv.w_sizes, sv.w_strides, x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
         const size_t slab_bytes = epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K);
-        const bool may_defer = slab_bytes && defer_enabled() && gradient_consumed_after_backward(sv.w);
+        const bool after_pass = gradient_consumed_after_backward(sv.w);        // nobody reads this gradient before backward() returns
+        const bool may_defer = slab_bytes && defer_enabled() && after_pass;
         if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();      // e.g. a second use of a shared weight adds to the first
         void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
+        // second stream: only a launch whose result is complete by the end-of-pass join (an arena-less split would reduce right away)
+        const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
+        const epi_stream_t main_stream = current_stream(x);
+        const epi_stream_t st = on_side ? reinterpret_cast<epi_stream_t>(side_fork(x, reinterpret_cast<hipStream_t>(main_stream))) : main_stream;
         EpiSlabReduce pend = {};
-        Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x);
+        Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x, on_side ? 1 : 0);
         {
             ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
-                              2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), current_stream(x));
+                              2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), st);
             check(epi_conv2d_bwd_weight_deferred(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
                                                  K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
-                                                 slabs ? &pend : nullptr, current_stream(x)),
+                                                 slabs ? &pend : nullptr, st),
                   "epi_conv2d_bwd_weight");
         }
+        if (on_side) {
+            g_side.keep.push_back(x);
+            g_side.keep.push_back(g.dx);
+        }
         if (pend.nsplit > 0) pending_register(pend, out.dw);
+        else if (on_side) end_of_pass_callback();
     }
     return out;
 }
@@ -651,6 +739,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
     m.def("flush_pending_reduces", &flush_pending_reduces,
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
+    m.def("wgrad_stream_mode", &wgrad_stream_mode,
+          "weight gradients on a second HIP stream: 0 off, 1 on, 2 on with the lowest stream priority; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");
     m.def("clear_grads", &clear_grads, "drop the .grad of every tensor in the list (zero_grad(set_to_none=True))");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");

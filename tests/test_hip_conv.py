@@ -384,19 +384,24 @@ def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
         return out
 
     before = hip.glue().defer_wgrad_reduce(False)
+    stream_before = hip.glue().wgrad_stream_mode(0)
     try:
         ref = grads()
-        hip.glue().defer_wgrad_reduce(True)
-        for hooked in (False, False, True):
+        # (deferred reduce, weight gradients on the second stream [0 off / 1 on / 2 on, lowest priority], gradient read from a hook)
+        for defer, side, hooked in ((True, 0, False), (True, 0, False), (True, 0, True), (False, 1, False), (True, 1, False),
+                                    (True, 1, True), (True, 2, False), (True, 1, False)):
+            hip.glue().defer_wgrad_reduce(defer)
+            hip.glue().wgrad_stream_mode(side)
             got = grads(hooked)
             for k in ref:
                 scale = float(ref[k].abs().max()) + 1e-12
-                # run-to-run noise of this network (BatchNorm sums by atomics, bf16 activations: see the unit-node test) is ~4 % of the
-                # largest element; a reduce that did not run leaves O(1) garbage
-                assert float((got[k] - ref[k]).abs().max()) <= 1e-1 * scale, k
-                assert float((got[k] - ref[k]).norm()) <= 5e-2 * float(ref[k].norm()) + 1e-12, k
+                # run-to-run noise of this network (BatchNorm sums by atomics, bf16 activations: see the unit-node test) is ~5 % of the
+                # largest element / of the norm; a reduce that did not run, or a gradient read before its launch finished, leaves O(1) garbage
+                assert float((got[k] - ref[k]).abs().max()) <= 2e-1 * scale, (k, defer, side, hooked)
+                assert float((got[k] - ref[k]).norm()) <= 1e-1 * float(ref[k].norm()) + 1e-12, (k, defer, side, hooked)
     finally:
         hip.glue().defer_wgrad_reduce(before)
+        hip.glue().wgrad_stream_mode(stream_before)
     # outside a backward pass the reduce runs at once
     w = _rand((64, 64, 3, 3), torch.Generator().manual_seed(7)).to(dev).contiguous(memory_format=torch.channels_last)
     xx = _rand((32, 64, 32, 32), torch.Generator().manual_seed(8)).to(dev).contiguous(memory_format=torch.channels_last)
