@@ -41,6 +41,13 @@ template <int TM_, int WM_, int WN_, int MIN_WAVES_, int NSTAGE_> struct GemmCfg
 typedef GemmCfg<2, 2, 2, 2, 2> CfgSmall;
 typedef GemmCfg<2, 4, 1, 2, 2> CfgTall;
 typedef GemmCfg<4, 2, 4, 1, 2> CfgBig;
+// Under-filled launches (the deep layers at batch 32: 8192 or 2048 rows, 64 .. 512 tiles of 128 x 128): a workgroup that owns a CU alone
+// fills LDS at ~30 B/clk (tools/probe_fill.hip: 4 waves issuing 1 KiB loads), two per CU at ~51 B/clk, and a CU without a workgroup at
+// nothing -- so the same problem cut into twice or four times as many, smaller tiles finishes sooner although it stages more bytes.
+//   half:    64 x 128, 4 waves (2 x 2, one MFMA tile row each), 48 KiB LDS (3 workgroups / CU)
+//   quarter: 64 x  64, 2 waves (2 x 1),                         32 KiB LDS (5 workgroups / CU)
+typedef GemmCfg<1, 2, 2, 3, 2> CfgHalf;
+typedef GemmCfg<1, 2, 1, 3, 2> CfgQuarter;
 // Pipelined variants: a ring of 4 (3) LDS stages owned by ONE workgroup per CU; the DMA of K tile kt+3 (kt+2) is issued while tile
 // kt computes and is waited for with a COUNTED vmcnt, so a load has three (two) tile times to land instead of one.  For the
 // convolution GEMMs of this network (a few hundred workgroups, 9 .. 72 K tiles each) the 2-stage loop spends most of every K
@@ -1022,7 +1029,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
 
 using namespace epi;
 
-enum { CFG_SMALL = 0, CFG_TALL = 1, CFG_BIG = 2 };
+enum { CFG_SMALL = 0, CFG_TALL = 1, CFG_BIG = 2, CFG_HALF = 3, CFG_QUARTER = 4 };
 struct GemmPlan { int cfg; int nsplit, kps; long long tiles; int pipe; };
 
 // EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
@@ -1049,7 +1056,8 @@ static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pip
     GemmPlan pl;
     pl.cfg = cfg;
     pl.pipe = pipe ? 1 : 0;
-    const int bm = cfg == CFG_SMALL ? 128 : 256, bn = cfg == CFG_BIG ? 256 : (cfg == CFG_TALL ? 64 : 128);
+    const int bm = cfg == CFG_SMALL ? 128 : (cfg == CFG_HALF || cfg == CFG_QUARTER ? 64 : 256);
+    const int bn = cfg == CFG_BIG ? 256 : (cfg == CFG_TALL || cfg == CFG_QUARTER ? 64 : 128);
     pl.tiles = (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const long long wgs = pl.tiles * nphase;
     const bool one_per_cu = cfg == CFG_BIG || pipe;
@@ -1091,8 +1099,16 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         const bool deep = pb.nsplit == 1 ? (K >= 512 && pb.tiles * nphase >= 200) : pb.kps >= 1024;
         if (ov == 2 || (fills && deep)) return pb;
     }
-    const int cfg = (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) ? CFG_TALL : CFG_SMALL;
-    const int pm = out_f32 ? 0 : gemm_pipe_mode();
+    int cfg = (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) ? CFG_TALL : CFG_SMALL;
+    // smaller tiles while the launch leaves CUs without two workgroups (EPI_GEMM_FILL: the workgroup count below which the next
+    // smaller tile is taken; 0 = never)
+    static const long long fill_env = [] { const char* e = getenv("EPI_GEMM_FILL"); return e ? atoll(e) : 384LL; }();
+    if (cfg == CFG_SMALL && ov == 0 && !out_f32 && fill_env > 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase;
+        const long long t64x128 = (long long)((M + 63) / 64) * ((N + 127) / 128) * nphase;
+        if (t128 < fill_env) cfg = t64x128 < fill_env ? CFG_QUARTER : CFG_HALF;
+    }
+    const int pm = out_f32 || cfg == CFG_HALF || cfg == CFG_QUARTER ? 0 : gemm_pipe_mode();
     if (pm) {       // pipelined ring (one workgroup per CU): pays when every workgroup still has a K loop of >= 6 tiles
         const GemmPlan pp = gemm_plan_cfg(cfg, M, N, K, nphase, true);
         if (pm == 2 || pp.kps >= 6 * GBK) return pp;
@@ -1277,6 +1293,8 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     int rc;
     if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
+    else if (pl.cfg == CFG_HALF) rc = launch_gemm_cfg<false, CfgHalf>(a, pl, nphase, st);
+    else if (pl.cfg == CFG_QUARTER) rc = launch_gemm_cfg<false, CfgQuarter>(a, pl, nphase, st);
     else if (pl.cfg == CFG_TALL) rc = pl.pipe ? launch_gemm_cfg<false, CfgTallP>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgTall>(a, pl, nphase, st);
     else rc = pl.pipe ? launch_gemm_cfg<false, CfgSmallP>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall>(a, pl, nphase, st);
     if (rc != EPI_OK) return rc;
@@ -1665,6 +1683,9 @@ static TnPlan tn_plan(int R, int I, int J) {
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     auto fills = [](int n) { const int t = (n + 255) / 256; return n >= 192 && t * 256 <= n + n / 4; };
     const int ov = gemm_tile_override();
+    // EPI_TN_SLOTS=<percent>: plan as if the chip held that share of its workgroup slots (measurement switch: a smaller footprint
+    // for weight-gradient launches that run beside the critical path on the second stream)
+    static const int slot_percent = [] { const char* e = getenv("EPI_TN_SLOTS"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
     TnPlan best = {0, 0, 1, 0};
     double best_t = 1e30;
     for (const Cfg& c : cfgs) {
@@ -1677,7 +1698,8 @@ static TnPlan tn_plan(int R, int I, int J) {
             if (ns > 1 && (long long)ns * 128 > R) break;
             int rps = ((R + ns - 1) / ns + GBK - 1) / GBK * GBK;
             const int nsplit = (R + rps - 1) / rps;
-            const double rounds = (double)((tiles * nsplit + c.slots - 1) / c.slots);
+            const long long slots = (long long)c.slots * slot_percent / 100;
+            const double rounds = (double)((tiles * nsplit + slots - 1) / slots);
             const double t_main = rounds * ((rps / GBK) * c.t_tile + c.t_fixed);
             const double t_slab = nsplit > 1 ? (double)nsplit * I * J * 8.0 / 3.0e6 + 3.0 : 0.0;
             if (t_main + t_slab < best_t) { best_t = t_main + t_slab; best = {c.id, tiles, nsplit, rps}; }

@@ -123,6 +123,18 @@ struct SideStream {
     hipStream_t main_stream = nullptr;
     bool dirty = false, low_priority = false;
     std::vector<Tensor> keep;
+    // weight-gradient launches of the residual unit whose backward is being enqueued: they go out together behind ONE fork event when
+    // the unit is done (an event recorded on the main stream costs it a ~6 us bubble -- measured launch by launch with
+    // tools/trace_step_sequence.py --, 52 of them per step ate half of what the second stream gained)
+    struct Job {
+        Tensor x, dy, dw, w;
+        int B, H, W, Cin, Cout, K, S, P;
+        bool w_f32;
+        void* slabs;
+        size_t slab_bytes;
+        double flops, bytes;
+    };
+    std::vector<Job> jobs;
 };
 SideStream g_side;
 int side_mode() {
@@ -159,6 +171,8 @@ hipStream_t side_fork(const Tensor& like, hipStream_t main_stream) {
         if (S.stream != nullptr) (void)hipStreamDestroy(S.stream);        // (destruction waits for the stream's work)
         int least = 0, greatest = 0;
         TORCH_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess, "weight-gradient stream: priority range");
+        // (a CU-masked stream -- hipExtStreamCreateWithCUMask, 25 .. 75 % of the units -- was measured at 12.8 .. 15.9 ms/step against 7.56:
+        // rejected)
         TORCH_CHECK(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, low ? least : 0) == hipSuccess,
                     "weight-gradient stream: create");
         if (S.fork.empty()) {
@@ -310,6 +324,32 @@ void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
     P.keep.push_back(grad.storage().getWeakStorageImpl());
     P.dev = grad.device();
     end_of_pass_callback();
+}
+
+// the queued weight-gradient launches of one autograd node, on the second stream behind one fork event
+void side_run_jobs() {
+    SideStream& S = g_side;
+    if (S.jobs.empty()) return;
+    const Tensor& first = S.jobs.front().x;
+    const epi_stream_t st = reinterpret_cast<epi_stream_t>(side_fork(first, reinterpret_cast<hipStream_t>(current_stream(first))));
+    bool unsplit = false;
+    for (SideStream::Job& j : S.jobs) {
+        EpiSlabReduce pend = {};
+        Tensor* ws = j.slabs ? nullptr : &workspace(j.slab_bytes, j.x, 1);
+        {
+            ScopedTimer timer("conv_bwd_weight", j.flops, j.bytes, st);
+            check(epi_conv2d_bwd_weight_deferred(j.x.data_ptr(), j.dy.data_ptr(), j.dw.data_ptr(), j.w_f32 ? EPI_F32 : EPI_BF16, j.B, j.H, j.W, j.Cin,
+                                                 j.Cout, j.K, j.K, j.S, j.P, j.slabs ? j.slabs : ws->data_ptr(),
+                                                 j.slabs ? j.slab_bytes : (size_t)ws->numel(), j.slabs ? &pend : nullptr, st),
+                  "epi_conv2d_bwd_weight");
+        }
+        S.keep.push_back(std::move(j.x));
+        S.keep.push_back(std::move(j.dy));
+        if (pend.nsplit > 0) pending_register(pend, j.dw);
+        else unsplit = true;
+    }
+    S.jobs.clear();                 // (drops the strong references to the gradients before autograd sees them)
+    if (unsplit) end_of_pass_callback();
 }
 
 // ---- BatchNorm halves shared by bn_act and conv_bn_act ------------------------------------------------------------
@@ -546,24 +586,22 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
         void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
         // second stream: only a launch whose result is complete by the end-of-pass join (an arena-less split would reduce right away)
         const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
-        const epi_stream_t main_stream = current_stream(x);
-        const epi_stream_t st = on_side ? reinterpret_cast<epi_stream_t>(side_fork(x, reinterpret_cast<hipStream_t>(main_stream))) : main_stream;
-        EpiSlabReduce pend = {};
-        Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x, on_side ? 1 : 0);
-        {
-            ScopedTimer timer("conv_bwd_weight", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
-                              2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), st);
-            check(epi_conv2d_bwd_weight_deferred(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
-                                                 K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
-                                                 slabs ? &pend : nullptr, st),
-                  "epi_conv2d_bwd_weight");
+        const double wflops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
+        const double wbytes = 2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel());
+        if (on_side) {           // launched by side_run_jobs() when the node's main-stream work has been enqueued
+            g_side.jobs.push_back(SideStream::Job{x, g.dx, out.dw, sv.w, B, H, W, Cin, Cout, K, S, P, sv.w_f32, slabs, slab_bytes, wflops, wbytes});
+        } else {
+            EpiSlabReduce pend = {};
+            Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x);
+            {
+                ScopedTimer timer("conv_bwd_weight", wflops, wbytes, current_stream(x));
+                check(epi_conv2d_bwd_weight_deferred(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
+                                                     K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
+                                                     slabs ? &pend : nullptr, current_stream(x)),
+                      "epi_conv2d_bwd_weight");
+            }
+            if (pend.nsplit > 0) pending_register(pend, out.dw);
         }
-        if (on_side) {
-            g_side.keep.push_back(x);
-            g_side.keep.push_back(g.dx);
-        }
-        if (pend.nsplit > 0) pending_register(pend, out.dw);
-        else if (on_side) end_of_pass_callback();
     }
     return out;
 }
@@ -596,7 +634,9 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
         TORCH_CHECK(ctx->saved_data["training"].toBool(), "conv_bn_act: backward through inference-mode statistics is not supported");
         auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
         TORCH_CHECK(!holder->stages.empty(), "conv_bn_act: backward called twice (the fused nodes free their activations in backward)");
+        g_side.jobs.clear();                         // (left-overs of a pass that aborted inside a node)
         StageGrads g = stage_backward(grads[0], holder->stages[0], ctx->needs_input_grad(0), ctx->needs_input_grad(1), Tensor());
+        side_run_jobs();
         holder->stages.clear();                      // release the saved activations now, not when the graph is torn down
         return {g.dx, g.dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor(), Tensor(), Tensor(), Tensor()};
@@ -645,6 +685,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         TORCH_CHECK(ctx->saved_data["training"].toBool(), "residual_unit: backward through inference-mode statistics is not supported");
         auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
         TORCH_CHECK(!holder->stages.empty(), "residual_unit: backward called twice (the fused nodes free their activations in backward)");
+        g_side.jobs.clear();                         // (left-overs of a pass that aborted inside a node)
         const int n_total = (int)holder->stages.size(), n_main = holder->n_main;
         const bool need_x = ctx->needs_input_grad(0);
         std::vector<StageGrads> g(n_total);
@@ -662,6 +703,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
             flow = g[i].dx;
         }
         g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor());
+        side_run_jobs();                                              // the unit's weight gradients: second stream, one fork event
         variable_list out;
         out.reserve(1 + n_total * STAGE_TENSORS + 5);
         out.push_back(g[0].dx);

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--image", type=int, default=256)
+    ap.add_argument("--no-miopen", action="store_true", help="skip the library timings (quick A/B of our kernels)")
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = True
     dev = torch.device("cuda:0")
@@ -70,7 +71,7 @@ def main():
         ours = [timeit(lambda: hip.conv2d_fwd(x, w, s, pad), args.iters),
                 timeit(lambda: hip.conv2d_bwd_data(dy, wb, tuple(x.shape), k, s, pad), args.iters),
                 timeit(lambda: hip.conv2d_bwd_weight(x, dy, k, s, pad, dtype=torch.bfloat16), args.iters)]
-        mi = [timeit(lambda: F.conv2d(x, w, stride=s, padding=pad), args.iters),
+        mi = [0.0, 0.0, 0.0] if args.no_miopen else [timeit(lambda: F.conv2d(x, w, stride=s, padding=pad), args.iters),
               timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (pad, pad), (1, 1), False, (0, 0), 1, (True, False, False)), args.iters),
               timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (pad, pad), (1, 1), False, (0, 0), 1, (False, True, False)), args.iters)]
         cells = ["%6.1f/%6.1f/%5.1f" % (ours[i], mi[i], bound) for i in range(3)]
