@@ -161,9 +161,8 @@ void side_join() {
 }
 
 // returns the weight-gradient stream, ordered behind everything enqueued on `main_stream` so far
-hipStream_t side_fork(const Tensor& like, hipStream_t main_stream) {
+hipStream_t side_fork(int dev, hipStream_t main_stream) {
     SideStream& S = g_side;
-    const int dev = like.device().index();
     const bool low = S.mode == 2;
     if (S.stream == nullptr || S.device != dev || S.low_priority != low) {
         if (S.stream != nullptr && S.device == dev) side_join();           // priority class changed: drain, then replace the stream
@@ -226,7 +225,6 @@ bool defer_wgrad_reduce(bool on) {
 
 void flush_pending_reduces() {
     PendingReduces& P = g_pend;
-    side_join();                     // the slabs (and the unsplit gradients) may still be in flight on the weight-gradient stream
     if (!P.rows.empty()) {
         const int nrows = (int)P.rows.size();
         long long chunks = 0;
@@ -237,7 +235,12 @@ void flush_pending_reduces() {
         }
         for (auto& r : P.rows) { r.chunk_begin = chunks; chunks += epi_slab_reduce_chunks(r.n); }
         const size_t bytes = sizeof(EpiSlabReduce) * (size_t)nrows;
-        auto stream = c10::hip::getCurrentHIPStream(P.dev.index());
+        // Which stream?  With weight gradients in flight on the second stream the sum runs THERE, behind them (and behind the main
+        // stream's own split launches: one more fork event), so that it overlaps whatever the main stream still has to do -- at the end
+        // of a ResNet backward the stem's max-pool / BatchNorm / convolution backward, ~0.3 ms against ~0.18 ms of reduce.
+        hipStream_t stream = c10::hip::getCurrentHIPStream(P.dev.index()).stream();
+        static const bool reduce_on_side = [] { const char* e = getenv("EPI_REDUCE_STREAM"); return !(e && e[0] == '0'); }();      // A/B switch
+        if (reduce_on_side && g_side.dirty && g_side.device == P.dev.index()) stream = side_fork(P.dev.index(), stream);
         const auto byte_opts = at::TensorOptions().dtype(at::kByte).device(P.dev);
         // the table is the same from step to step (same layers, same arena offsets, gradients from the caching allocator usually at
         // the same addresses): upload only when it changed
@@ -253,19 +256,20 @@ void flush_pending_reduces() {
                 TORCH_CHECK(hipEventCreateWithFlags(&P.upload_done, hipEventDisableTiming) == hipSuccess, "deferred reduce: event");
             }
             std::memcpy(P.table_host.data_ptr(), P.rows.data(), bytes);
-            TORCH_CHECK(hipMemcpyAsync(P.table_dev.data_ptr(), P.table_host.data_ptr(), bytes, hipMemcpyHostToDevice, stream.stream()) == hipSuccess,
+            TORCH_CHECK(hipMemcpyAsync(P.table_dev.data_ptr(), P.table_host.data_ptr(), bytes, hipMemcpyHostToDevice, stream) == hipSuccess,
                         "deferred reduce: table upload");
-            TORCH_CHECK(hipEventRecord(P.upload_done, stream.stream()) == hipSuccess, "deferred reduce: event");
+            TORCH_CHECK(hipEventRecord(P.upload_done, stream) == hipSuccess, "deferred reduce: event");
             P.uploaded = P.rows;
         }
         if (chunks > 0) {
-            ScopedTimer timer("conv_bwd_weight", 0.0, 0.0, reinterpret_cast<epi_stream_t>(stream.stream()));    // (the reduce belongs to the family's time)
+            ScopedTimer timer("conv_bwd_weight", 0.0, 0.0, reinterpret_cast<epi_stream_t>(stream));    // (the reduce belongs to the family's time)
             check(epi_slab_reduce_multi(reinterpret_cast<const EpiSlabReduce*>(P.table_dev.data_ptr()), nrows, chunks,
-                                        reinterpret_cast<epi_stream_t>(stream.stream())), "epi_slab_reduce_multi");
+                                        reinterpret_cast<epi_stream_t>(stream)), "epi_slab_reduce_multi");
         }
         P.rows.clear();
         P.keep.clear();
     }
+    side_join();                     // the main stream waits for everything on the weight-gradient stream: unsplit gradients, slabs, the sum
     P.target = std::max(P.target, P.wanted);
     if (P.arena.defined() && P.target > (size_t)P.arena.numel()) P.arena = Tensor();            // regrown by the next pass (stream-ordered free)
     P.used = 0;
@@ -331,7 +335,7 @@ void side_run_jobs() {
     SideStream& S = g_side;
     if (S.jobs.empty()) return;
     const Tensor& first = S.jobs.front().x;
-    const epi_stream_t st = reinterpret_cast<epi_stream_t>(side_fork(first, reinterpret_cast<hipStream_t>(current_stream(first))));
+    const epi_stream_t st = reinterpret_cast<epi_stream_t>(side_fork(first.device().index(), reinterpret_cast<hipStream_t>(current_stream(first))));
     bool unsplit = false;
     for (SideStream::Job& j : S.jobs) {
         EpiSlabReduce pend = {};
@@ -725,6 +729,37 @@ Tensor residual_unit(Tensor x, std::vector<Tensor> tensors, std::vector<int64_t>
     return ResidualUnitFn::apply(x, at::TensorList(tensors), geometry, has_downsample, training, momentum, eps);
 }
 
+// ---- MaxPool2d(3, 2, 1) of the stem (pose3d_resnet.py:104,186) on epi_maxpool3x3s2_* --------------------------------------------
+struct MaxPool3x3s2 : public torch::autograd::Function<MaxPool3x3s2> {
+    static Tensor forward(AutogradContext* ctx, Tensor x) {
+        TORCH_CHECK(x.is_cuda(), "maxpool3x3s2: input must live on the GPU (no CPU fallback in epipolarpose_amd)");
+        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+        const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+        Tensor y = at::empty({B, C, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+        Tensor pos = at::empty({B, Ho, Wo, C}, x.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+        {
+            ScopedTimer timer("maxpool_fwd", 0.0, 2.0 * (double)x.numel() + 3.0 * (double)y.numel(), current_stream(x));
+            check(epi_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), pos.data_ptr(), (int)B, (int)H, (int)W, (int)C, current_stream(x)), "epi_maxpool3x3s2_fwd");
+        }
+        ctx->saved_data["H"] = H;
+        ctx->saved_data["W"] = W;
+        ctx->save_for_backward({pos});
+        return y;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const Tensor pos = ctx->get_saved_variables()[0];
+        Tensor dy = grads[0];
+        if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        const int64_t B = dy.size(0), C = dy.size(1), H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+        Tensor dx = at::empty({B, C, H, W}, dy.options().memory_format(at::MemoryFormat::ChannelsLast));
+        ScopedTimer timer("maxpool_bwd", 0.0, 3.0 * (double)dy.numel() + 2.0 * (double)dx.numel(), current_stream(dy));
+        check(epi_maxpool3x3s2_bwd(dy.data_ptr(), pos.data_ptr(), dx.data_ptr(), (int)B, (int)H, (int)W, (int)C, current_stream(dy)), "epi_maxpool3x3s2_bwd");
+        return {dx};
+    }
+};
+Tensor maxpool3x3s2(Tensor x) { return MaxPool3x3s2::apply(x); }
+
 // ---- FusedAdam's per-step pointer table ----------------------------------------------------------------------------
 // Row layout (int64 slots): p, g, m, v, shadow, n, flags (bit 0: gradient is bf16).  For every parameter: take the gradient of its
 // bf16 training copy (when it has one) or its own, check dtype and memory order against the parameter (same strides on every
@@ -778,6 +813,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "torch-autograd glue over the libepipolar_hip C ABI (no compute of its own)";
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
+    m.def("maxpool3x3s2", &maxpool3x3s2, "MaxPool2d(kernel 3, stride 2, padding 1), NHWC bf16, autograd-aware");
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
     m.def("flush_pending_reduces", &flush_pending_reduces,
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");

@@ -75,6 +75,8 @@ _SIGNATURES = {
     "epi_adam_step_clipped": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong,
                                    ctypes.c_float, _vp, _vp]),
     "epi_dropout_bf16": (_i, [_vp, _vp, ctypes.c_longlong, ctypes.c_float, ctypes.c_ulonglong, _vp]),
+    "epi_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "epi_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "epi_crop_patches": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i, _i, _i, _vp,
                               _i, _i, _vp]),
     "epi_evaluate_poses": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -731,6 +733,33 @@ def dropout_bf16(x, p, seed, out=None):
     out = torch.empty_like(x) if out is None else out
     _check(lib.epi_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()), "epi_dropout_bf16")
     return out
+
+
+def maxpool3x3s2_fwd(x):
+    """nn.MaxPool2d(3, 2, 1) of a channels_last bf16 tensor [B, C, H, W] -> (y [B, C, Ho, Wo] channels_last bf16, pos uint8 [B, Ho, Wo, C]:
+    the window position every output element came from -- what ``maxpool3x3s2_bwd`` needs).  Reference: pose3d_resnet.py:104,186."""
+    lib = load()
+    x = _nhwc_bf16(x, "x")
+    b, c, h, w = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((b, c, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    pos = torch.empty((b, ho, wo, c), dtype=torch.uint8, device=x.device)
+    with _on(x.device):
+        _check(lib.epi_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(pos), b, h, w, c, _stream()), "epi_maxpool3x3s2_fwd")
+    return y, pos
+
+
+def maxpool3x3s2_bwd(dy, pos, in_hw):
+    """dy [B, C, Ho, Wo] channels_last bf16, pos from the forward pass -> dx [B, C, H, W] channels_last bf16."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    _dev(pos, torch.uint8, "pos")
+    b, c = dy.shape[0], dy.shape[1]
+    h, w = in_hw
+    dx = torch.empty((b, c, h, w), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    with _on(dy.device):
+        _check(lib.epi_maxpool3x3s2_bwd(_ptr(dy), _ptr(pos), _ptr(dx), b, h, w, c, _stream()), "epi_maxpool3x3s2_bwd")
+    return dx
 
 
 def evaluate_poses(pred_img, gt_img, pelvis_z, fl, c_p, root, j14):

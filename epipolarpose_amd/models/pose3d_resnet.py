@@ -18,6 +18,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .. import hip
 from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
 
 BN_MOMENTUM = 0.1
@@ -30,6 +31,7 @@ POINTWISE_BACKEND = os.environ.get("EPI_1X1", "miopen")
 # conv -> BatchNorm (+ residual) (+ ReLU) stage one C++ autograd node (models/fused.py:FusedConvBn); "miopen" = nn.Conv2d through
 # MIOpen followed by the fused BatchNorm module (the round-1 path, kept for A/B measurements).
 CONV_BACKEND = os.environ.get("EPI_CONV", "hip")
+MAXPOOL_BACKEND = os.environ.get("EPI_MAXPOOL", "hip")       # "torch": the library max-pool (A/B switch)
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -161,7 +163,11 @@ class PoseResNet(nn.Module):
         self.to(memory_format=torch.channels_last)
 
     def features(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x)))
+        x = self.bn1(self.conv1(x))
+        if x.is_cuda and x.shape[1] % 8 == 0 and MAXPOOL_BACKEND == "hip":      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
+            x = hip.glue().maxpool3x3s2(x)
+        else:
+            x = self.maxpool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

@@ -331,6 +331,13 @@ int epi_adam_step_clipped(const void* table, const void* chunks, int nchunks, fl
  * (seed, i); calling it on the output gradient with the same seed IS the backward pass.  y may alias x. */
 int epi_dropout_bf16(const void* x, void* y, long long n, float p, unsigned long long seed, epi_stream_t stream);
 
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem (lib/models/pose3d_resnet.py:104,186), NHWC bf16, C % 8 == 0.
+ *   x [B][H][W][C] -> y [B][Ho][Wo][C], Ho = (H - 1) / 2 + 1;  pos [B][Ho][Wo][C] uint8: the window position (kh*3 + kw) each output
+ *   element was taken from -- the library's selection rule (first of equal maxima in scan order, a NaN sticks) -- which is all the
+ *   backward pass needs: dx [B][H][W][C] gathers dy from the <= 4 windows that selected the pixel (no atomics, no zero fill). */
+int epi_maxpool3x3s2_fwd(const void* x, void* y, void* pos, int B, int H, int W, int C, epi_stream_t stream);
+int epi_maxpool3x3s2_bwd(const void* dy, const void* pos, void* dx, int B, int H, int W, int C, epi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Input pipeline -- replaces, per batch instead of per sample on the host, generate_patch_image_cv
  * (lib/utils/img_utils.py:114-127: cv2.warpAffine, INTER_LINEAR, constant border) and the colour / normalisation stage of

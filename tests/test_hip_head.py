@@ -257,3 +257,37 @@ def test_deconv_channels_last_weight_forms_and_module(dev, cin, cout, h):
     opt.step()
     assert torch.equal(mod.weight_lp.detach().float(), mod.weight.detach().to(torch.bfloat16).float())
     assert torch.equal(mod.weight_phase, hip.deconv_pack_weight(mod.weight.detach())[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 64, 32, 32), (3, 8, 17, 23), (1, 64, 128, 128), (2, 16, 9, 8)])
+def test_maxpool3x3s2_matches_torch(shape):
+    """epi_maxpool3x3s2_fwd / _bwd against nn.MaxPool2d(3, 2, 1) (pose3d_resnet.py:104) in fp32: the selected values are exact, the
+    gradient goes to the library's arg-max (first of equal maxima in scan order -- post-ReLU inputs are full of ties) and a pixel
+    selected by several windows gets their fp32 sum rounded once.  Odd sizes, a NaN and a window of -inf included."""
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=gen).clamp_min(0.0)              # ReLU output: ~half the entries are exact zeros
+    x[0, 0, 0, 0] = float("nan")
+    x[-1, :, -3:, -3:] = float("-inf")
+    x = x.to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    dy_shape = (shape[0], shape[1], (shape[2] - 1) // 2 + 1, (shape[3] - 1) // 2 + 1)
+    dy = torch.randn(dy_shape, generator=gen).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    y, pos = hip.maxpool3x3s2_fwd(x)
+    dx = hip.maxpool3x3s2_bwd(dy, pos, shape[2:])
+    # reference on an NCHW-contiguous tensor: the library's channels_last kernel leaves the gradient of an all -inf window at pixel
+    # (0, 0) of the image (its index buffer starts at 0), its NCHW kernel at the window's first pixel inside the image, as here
+    xr = x.float().contiguous().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 3, 2, 1)
+    yr.backward(dy.float().contiguous())
+    assert y.shape == yr.shape and dx.shape == xr.shape
+    assert torch.equal(torch.nan_to_num(y.float(), nan=12345.0), torch.nan_to_num(yr.detach(), nan=12345.0))
+    ref_dx = xr.grad.to(torch.bfloat16).float()
+    bad = (dx.float() != ref_dx).nonzero()
+    assert bad.numel() == 0, (bad[:8].tolist(), dx.float()[tuple(bad[0])].item(), ref_dx[tuple(bad[0])].item())
+    # through the autograd node of the C++ glue
+    xg = x.clone().requires_grad_(True)
+    yg = hip.glue().maxpool3x3s2(xg)
+    yg.backward(dy)
+    assert torch.equal(torch.nan_to_num(yg.float(), nan=12345.0), torch.nan_to_num(y.float(), nan=12345.0)) and torch.equal(xg.grad, dx)
