@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -127,23 +128,34 @@ struct SideStream {
     // the unit is done (an event recorded on the main stream costs it a ~6 us bubble -- measured launch by launch with
     // tools/trace_step_sequence.py --, 52 of them per step ate half of what the second stream gained)
     struct Job {
-        Tensor x, dy, dw, w;
-        int B, H, W, Cin, Cout, K, S, P;
-        bool w_f32;
-        void* slabs;
-        size_t slab_bytes;
+        Tensor x, dy, dw;                // operands (kept alive until the join) and the gradient (released before autograd sees it)
+        // launches the weight-gradient kernel(s) on the given stream; returns the pending slab sum (nsplit == 0: `dw` is complete)
+        std::function<EpiSlabReduce(epi_stream_t)> launch;
+        const char* name;
         double flops, bytes;
     };
     std::vector<Job> jobs;
 };
 SideStream g_side;
+// scratch of the launches on the weight-gradient stream.  Grown on demand like workspace(); the outgrown buffer may still be in use by
+// a launch in flight on that stream while the caching allocator would hand it to the main stream at once -- it is parked until the join.
+Tensor& side_workspace(size_t bytes, const Tensor& like) {
+    static std::vector<Tensor> per_device(64);
+    Tensor& ws = per_device[like.device().index()];
+    if (!ws.defined() || (size_t)ws.numel() < bytes) {
+        if (ws.defined()) g_side.keep.push_back(ws);
+        ws = at::empty({(int64_t)std::max<size_t>(bytes, (size_t)1 << 16)}, like.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+    }
+    return ws;
+}
+
 int side_mode() {
     if (g_side.mode < 0) { const char* e = getenv("EPI_WGRAD_STREAM"); g_side.mode = e ? atoi(e) : 1; }
     return g_side.mode;
 }
-int wgrad_stream_mode(int mode) {             // test / measurement hook: returns the previous setting
+int wgrad_stream_mode(int mode) {             // test / measurement hook: returns the previous setting; a negative mode only queries
     const int before = side_mode();
-    g_side.mode = mode;
+    if (mode >= 0) g_side.mode = mode;
     return before;
 }
 
@@ -339,13 +351,9 @@ void side_run_jobs() {
     bool unsplit = false;
     for (SideStream::Job& j : S.jobs) {
         EpiSlabReduce pend = {};
-        Tensor* ws = j.slabs ? nullptr : &workspace(j.slab_bytes, j.x, 1);
         {
-            ScopedTimer timer("conv_bwd_weight", j.flops, j.bytes, st);
-            check(epi_conv2d_bwd_weight_deferred(j.x.data_ptr(), j.dy.data_ptr(), j.dw.data_ptr(), j.w_f32 ? EPI_F32 : EPI_BF16, j.B, j.H, j.W, j.Cin,
-                                                 j.Cout, j.K, j.K, j.S, j.P, j.slabs ? j.slabs : ws->data_ptr(),
-                                                 j.slabs ? j.slab_bytes : (size_t)ws->numel(), j.slabs ? &pend : nullptr, st),
-                  "epi_conv2d_bwd_weight");
+            ScopedTimer timer(j.name, j.flops, j.bytes, st);
+            pend = j.launch(st);
         }
         S.keep.push_back(std::move(j.x));
         S.keep.push_back(std::move(j.dy));
@@ -593,7 +601,17 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
         const double wflops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
         const double wbytes = 2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel());
         if (on_side) {           // launched by side_run_jobs() when the node's main-stream work has been enqueued
-            g_side.jobs.push_back(SideStream::Job{x, g.dx, out.dw, sv.w, B, H, W, Cin, Cout, K, S, P, sv.w_f32, slabs, slab_bytes, wflops, wbytes});
+            const Tensor xin = x, dyin = g.dx, dwout = out.dw;
+            const bool w_f32 = sv.w_f32;
+            g_side.jobs.push_back(SideStream::Job{x, g.dx, out.dw, [=](epi_stream_t st) {
+                EpiSlabReduce pend = {};
+                Tensor* ws = slabs ? nullptr : &side_workspace(slab_bytes, xin);
+                check(epi_conv2d_bwd_weight_deferred(xin.data_ptr(), dyin.data_ptr(), dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
+                                                     K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
+                                                     slabs ? &pend : nullptr, st),
+                      "epi_conv2d_bwd_weight");
+                return pend;
+            }, "conv_bwd_weight", wflops, wbytes});
         } else {
             EpiSlabReduce pend = {};
             Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x);
@@ -729,6 +747,190 @@ Tensor residual_unit(Tensor x, std::vector<Tensor> tensors, std::vector<int64_t>
     return ResidualUnitFn::apply(x, at::TensorList(tensors), geometry, has_downsample, training, momentum, eps);
 }
 
+// ---- Deconvolution head (pose3d_resnet.py:158-183, 116-122) ---------------------------------------------------------------------
+// ConvTranspose2d(k4, s2, p1, no bias) -> BatchNorm -> ReLU as ONE autograd node, and the final 1x1 convolution (+ bias) as one node.
+// Same kernels as the Python autograd.Functions they replace (models/fused.py round 1): what changes is the host cost per call and
+// that their weight gradients -- the largest of the network: 0.35 ms per step -- join the backbone's on the second stream.
+// w: [Cin, Cout, 4, 4] bf16 training copy or fp32 master, channels_last memory ([Cin][kh][kw][Cout] = the backward-data operand as it
+// stands); w_phase: the packed forward operand [4][Cout][4 Cin] kept by the optimizer, or undefined / empty -> packed here.
+struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, c10::optional<Tensor> w_phase_opt, Tensor gamma, Tensor beta, Tensor running_mean,
+                          Tensor running_var, Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum,
+                          double eps, bool relu) {
+        TORCH_CHECK(x.is_cuda() && w.is_cuda(), "deconv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
+        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        TORCH_CHECK(w.dim() == 4 && w.size(0) == x.size(1) && w.size(2) == 4 && w.size(3) == 4, "deconv_bn_act: weight must be [Cin, Cout, 4, 4]");
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)w.size(1);
+        Tensor w16 = w.detach();
+        if (w16.scalar_type() != at::kBFloat16) w16 = w16.to(at::kBFloat16);
+        if (!w16.is_contiguous(at::MemoryFormat::ChannelsLast)) w16 = w16.contiguous(at::MemoryFormat::ChannelsLast);
+        Tensor w_phase = (w_phase_opt.has_value() && w_phase_opt->defined() && w_phase_opt->numel() == w.numel()) ? *w_phase_opt : Tensor();
+        if (!w_phase.defined()) {
+            w_phase = at::empty({4, Cout, 4 * Cin}, w16.options().memory_format(at::MemoryFormat::Contiguous));
+            check(epi_deconv4x4s2_pack_phase_cl(w16.data_ptr(), Cin, Cout, w_phase.data_ptr(), current_stream(x)), "epi_deconv4x4s2_pack_phase_cl");
+        }
+        Tensor raw = at::empty({B, Cout, 2 * H, 2 * W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+        const double flops = 2.0 * B * H * W * 16.0 * Cin * Cout;
+        {
+            Tensor& ws = workspace(epi_gemm_workspace_bytes(B * H * W, Cout, 4 * Cin, 4), x);
+            ScopedTimer timer("head_deconv4x4s2_fwd", flops, 0.0, current_stream(x));
+            check(epi_deconv4x4s2_fwd(x.data_ptr(), w_phase.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(), (size_t)ws.numel(),
+                                      current_stream(x)), "epi_deconv4x4s2_fwd");
+        }
+        BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
+        Tensor stats;
+        Tensor y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats);
+        ctx->saved_data["training"] = training;
+        if (training) {
+            auto holder = c10::make_intrusive<SavedHolder>();
+            holder->stages.resize(1);
+            StageSaved& sv = holder->stages[0];
+            sv.x = x; sv.raw = raw; sv.stats = stats; sv.gamma = gamma; sv.wb = w16; sv.sums_ws = sums_ws; sv.bwd_sums = bwd_sums; sv.flags = flags;
+            sv.relu = relu; sv.has_res = false; sv.w_f32 = w.scalar_type() != at::kBFloat16; sv.w = w; sv.need_dx = x.requires_grad();
+            ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        TORCH_CHECK(ctx->saved_data["training"].toBool(), "deconv_bn_act: backward through inference-mode statistics is not supported");
+        auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
+        TORCH_CHECK(!holder->stages.empty(), "deconv_bn_act: backward called twice (the fused nodes free their activations in backward)");
+        g_side.jobs.clear();
+        const StageSaved& sv = holder->stages[0];
+        BnGrads g = bn_backward(grads[0], sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false);
+        const Tensor& x = sv.x;
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)sv.raw.size(1);
+        const double flops = 2.0 * B * H * W * 16.0 * Cin * Cout;
+        Tensor dx, dw;
+        if (ctx->needs_input_grad(0)) {
+            dx = at::empty_like(x);
+            Tensor& ws = workspace(epi_gemm_workspace_bytes(B * H * W, Cin, 16 * Cout, 1), x);
+            ScopedTimer timer("head_deconv4x4s2_bwd_data", flops, 0.0, current_stream(x));
+            check(epi_deconv4x4s2_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(), (size_t)ws.numel(),
+                                           current_stream(x)), "epi_deconv4x4s2_bwd_data");
+        }
+        if (ctx->needs_input_grad(1)) {
+            // [Cin, Cout, 4, 4] in channels_last strides = memory [Cin][16 taps][Cout]: the kernel's own output order
+            dw = at::empty_strided({Cin, Cout, 4, 4}, {16 * (int64_t)Cout, 1, 4 * (int64_t)Cout, (int64_t)Cout},
+                                   x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
+            const size_t slab_bytes = epi_gemm_tn_workspace_bytes(B * H * W, Cin, Cout, 16);
+            const bool on_side = side_mode() != 0 && gradient_consumed_after_backward(sv.w);
+            const Tensor xin = x, dyin = g.dx, dwout = dw;
+            const bool w_f32 = sv.w_f32;
+            auto launch = [=](epi_stream_t st, Tensor& ws) {
+                check(epi_deconv4x4s2_bwd_weight(xin.data_ptr(), dyin.data_ptr(), dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
+                                                 ws.data_ptr(), (size_t)ws.numel(), st), "epi_deconv4x4s2_bwd_weight");
+            };
+            if (on_side) {
+                g_side.jobs.push_back(SideStream::Job{x, g.dx, dw, [=](epi_stream_t st) {
+                    launch(st, side_workspace(slab_bytes, xin));
+                    return EpiSlabReduce();
+                }, "head_deconv4x4s2_bwd_weight", flops, 0.0});
+            } else {
+                ScopedTimer timer("head_deconv4x4s2_bwd_weight", flops, 0.0, current_stream(x));
+                launch(current_stream(x), workspace(slab_bytes, x));
+            }
+        }
+        side_run_jobs();
+        holder->stages.clear();
+        return {dx, dw, Tensor(), g.dgamma, g.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor deconv_bn_act(Tensor x, Tensor w, c10::optional<Tensor> w_phase, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var,
+                     Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
+    return DeconvBnAct::apply(x, w, w_phase, gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags, training, momentum, eps, relu);
+}
+
+// Final 1x1 convolution with bias: y[m][co] = sum_ci x[m][ci] w[co][ci] + b[co] on the [B*H*W, C] views of the NHWC tensors.
+// w: [Cout, Cin, 1, 1] bf16 training copy or fp32 master; bias fp32 or undefined.
+struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, c10::optional<Tensor> bias_opt) {
+        TORCH_CHECK(x.is_cuda() && w.is_cuda(), "conv1x1: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
+        if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        TORCH_CHECK(w.dim() == 4 && w.size(1) == x.size(1) && w.size(2) == 1 && w.size(3) == 1, "conv1x1: weight must be [Cout, Cin, 1, 1]");
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)w.size(0);
+        const int M = B * H * W;
+        Tensor w16 = w.detach().reshape({Cout, Cin});
+        if (w16.scalar_type() != at::kBFloat16) w16 = w16.to(at::kBFloat16);
+        if (!w16.is_contiguous()) w16 = w16.contiguous();
+        const bool has_bias = bias_opt.has_value() && bias_opt->defined();
+        Tensor bias;
+        if (has_bias) bias = bias_opt->detach().to(at::kFloat).contiguous();
+        Tensor y = at::empty({B, Cout, H, W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+        {
+            Tensor& ws = workspace(epi_gemm_workspace_bytes(M, Cout, Cin, 1), x);
+            ScopedTimer timer("head_gemm_bf16", 2.0 * M * (double)Cout * Cin, 0.0, current_stream(x));
+            check(epi_gemm_bf16(x.data_ptr(), Cin, w16.data_ptr(), Cin, y.data_ptr(), Cout, EPI_BF16, M, Cout, Cin, has_bias ? bias.data_ptr<float>() : nullptr,
+                                ws.data_ptr(), (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16");
+        }
+        ctx->saved_data["has_bias"] = has_bias;
+        ctx->saved_data["w_f32"] = w.scalar_type() != at::kBFloat16;
+        ctx->save_for_backward({x, w16, w});
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor x = saved[0], w16 = saved[1], w = saved[2];
+        Tensor dy = grads[0];
+        if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+        const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)w16.size(0);
+        const int M = B * H * W;
+        const bool w_f32 = ctx->saved_data["w_f32"].toBool();
+        const double flops = 2.0 * M * (double)Cout * Cin;
+        g_side.jobs.clear();
+        Tensor dx, dw, db;
+        if (ctx->needs_input_grad(0)) {
+            const Tensor wt = w16.t().contiguous();                  // [Cin][Cout]: the backward-data operand (0.5 MB)
+            dx = at::empty_like(x);
+            Tensor& ws = workspace(epi_gemm_workspace_bytes(M, Cin, Cout, 1), x);
+            ScopedTimer timer("head_gemm_bf16", flops, 0.0, current_stream(x));
+            check(epi_gemm_bf16(dy.data_ptr(), Cout, wt.data_ptr(), Cout, dx.data_ptr(), Cin, EPI_BF16, M, Cin, Cout, nullptr, ws.data_ptr(),
+                                (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16");
+        }
+        if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) {
+            Tensor sums = at::zeros({2 * (int64_t)Cout}, x.options().dtype(at::kFloat));
+            check(epi_column_sums_bf16(dy.data_ptr(), (long long)M, Cout, sums.data_ptr<float>(), current_stream(x)), "epi_column_sums_bf16");
+            db = sums.slice(0, 0, Cout);
+        }
+        if (ctx->needs_input_grad(1)) {
+            // the weight gradient of a 1x1 convolution: dW[co][ci] = sum_m dy[m][co] x[m][ci] (bf16 or fp32 result, split sums deferrable)
+            dw = at::empty({Cout, Cin, 1, 1}, x.options().dtype(w_f32 ? at::kFloat : at::kBFloat16).memory_format(at::MemoryFormat::Contiguous));
+            const size_t slab_bytes = epi_gemm_tn_workspace_bytes(M, Cout, Cin, 1);
+            const bool after_pass = gradient_consumed_after_backward(w);
+            const bool may_defer = slab_bytes && defer_enabled() && after_pass;
+            if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();
+            void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
+            const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
+            const Tensor xin = x, dyin = dy, dwout = dw;
+            auto launch = [=](epi_stream_t st, Tensor* ws) {
+                EpiSlabReduce pend = {};
+                check(epi_conv2d_bwd_weight_deferred(xin.data_ptr(), dyin.data_ptr(), dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout, 1, 1, 1, 0,
+                                                     slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(), slabs ? &pend : nullptr, st),
+                      "epi_conv2d_bwd_weight");
+                return pend;
+            };
+            if (on_side) {
+                g_side.jobs.push_back(SideStream::Job{x, dy, dw, [=](epi_stream_t st) { return launch(st, slabs ? nullptr : &side_workspace(slab_bytes, xin)); },
+                                                      "head_gemm_tn_bf16", flops, 0.0});
+            } else {
+                EpiSlabReduce pend = {};
+                {
+                    ScopedTimer timer("head_gemm_tn_bf16", flops, 0.0, current_stream(x));
+                    pend = launch(current_stream(x), slabs ? nullptr : &workspace(slab_bytes, x));
+                }
+                if (pend.nsplit > 0) pending_register(pend, dw);
+            }
+        }
+        side_run_jobs();
+        return {dx, dw, db};
+    }
+};
+
+Tensor conv1x1_bias(Tensor x, Tensor w, c10::optional<Tensor> bias) { return Conv1x1Bias::apply(x, w, bias); }
+
 // ---- MaxPool2d(3, 2, 1) of the stem (pose3d_resnet.py:104,186) on epi_maxpool3x3s2_* --------------------------------------------
 struct MaxPool3x3s2 : public torch::autograd::Function<MaxPool3x3s2> {
     static Tensor forward(AutogradContext* ctx, Tensor x) {
@@ -813,6 +1015,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "torch-autograd glue over the libepipolar_hip C ABI (no compute of its own)";
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
+    m.def("deconv_bn_act", &deconv_bn_act, "ConvTranspose2d(k4, s2, p1) -> BatchNorm -> ReLU as one autograd node, NHWC bf16");
+    m.def("conv1x1_bias", &conv1x1_bias, "1x1 convolution (+ bias) on the NHWC view as one autograd node");
     m.def("maxpool3x3s2", &maxpool3x3s2, "MaxPool2d(kernel 3, stride 2, padding 1), NHWC bf16, autograd-aware");
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
     m.def("flush_pending_reduces", &flush_pending_reduces,

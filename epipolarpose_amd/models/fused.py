@@ -6,11 +6,17 @@
 * ``Conv1x1``            -- the final 1x1 convolution as an MFMA GEMM (``epi_gemm_bf16``).
 All activations are NHWC (``channels_last``) bf16; parameters stay fp32 (master weights).  No CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import hip
 from ..optim import sync_training_copy
+
+
+# EPI_HEAD=python: deconvolution head and final convolution through the Python autograd.Functions of round 1 instead of the C++ nodes
+HEAD_BACKEND = os.environ.get("EPI_HEAD", "glue")
 
 
 def _nhwc_bf16(x):
@@ -199,12 +205,23 @@ class Deconv4x4s2(nn.Module):
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.ConvTranspose2d default initialisation
         self.register_parameter("bias", None)
 
-    def forward(self, x):
+    def operands(self):
+        """(weight the autograd node differentiates, packed forward operand or None)"""
         if getattr(self, "weight_lp", None) is not None:
-            w, wp = sync_training_copy(self), getattr(self, "weight_phase", None)
-        else:
-            w, wp = self.weight, None
+            return sync_training_copy(self), getattr(self, "weight_phase", None)
+        return self.weight, None
+
+    def forward(self, x):
+        w, wp = self.operands()
         return _DeconvFunction.apply(_nhwc_bf16(x), w, wp)
+
+
+def deconv_bn_act(deconv, bn, x):
+    """``Deconv4x4s2`` -> ``FusedBatchNormAct`` as ONE C++ autograd node (``deconv_bn_act`` of the glue): transposed convolution +
+    BatchNorm statistics + apply forward; BatchNorm backward + backward-data + backward-weight (on the second stream) backward."""
+    w, wp = deconv.operands()
+    g, b, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
+    return hip.glue().deconv_bn_act(x, w, wp, g, b, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, bn.training, bn.momentum, bn.eps, bn.relu)
 
 
 class _Conv1x1Function(torch.autograd.Function):
@@ -262,4 +279,6 @@ class Conv1x1(nn.Module):
 
     def forward(self, x):
         w = self.weight if getattr(self, "weight_lp", None) is None else sync_training_copy(self)
-        return _Conv1x1Function.apply(_nhwc_bf16(x), w, self.bias)
+        if HEAD_BACKEND == "python":                                  # round-1 path: Python autograd.Function over ctypes (A/B switch)
+            return _Conv1x1Function.apply(_nhwc_bf16(x), w, self.bias)
+        return hip.glue().conv1x1_bias(x, w, self.bias)

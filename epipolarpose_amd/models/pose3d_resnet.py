@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
-from .fused import Conv1x1, Deconv4x4s2, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
+from .fused import HEAD_BACKEND, Conv1x1, Deconv4x4s2, deconv_bn_act, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
 
 BN_MOMENTUM = 0.1
 # Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1).  Measured round 1 at B=32 (ms/step, whole training step):
@@ -149,6 +149,9 @@ class PoseResNet(nn.Module):
             head += [deconv, FusedBatchNormAct(planes, momentum=BN_MOMENTUM, relu=True), nn.Identity()]
             width = planes
         self.deconv_layers = nn.Sequential(*head)
+        # (deconvolution, BatchNorm) pairs that run as one C++ autograd node each; empty: module by module
+        pairs = [(head[i], head[i + 1]) for i in range(0, len(head), 3)]
+        self._head_pairs = tuple(pairs) if HEAD_BACKEND != "python" and all(isinstance(d, Deconv4x4s2) for d, _ in pairs) else ()
 
         fk = extra.FINAL_CONV_KERNEL
         out_ch = self.num_joints * self.depth_res if self.volume else self.num_joints
@@ -174,7 +177,13 @@ class PoseResNet(nn.Module):
         if x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)
         feat = self.features(x)
-        heat = self.final_layer(self.deconv_layers(feat))
+        if self._head_pairs and feat.is_cuda:
+            up = feat
+            for deconv, bn in self._head_pairs:
+                up = deconv_bn_act(deconv, bn, up)
+        else:
+            up = self.deconv_layers(feat)
+        heat = self.final_layer(up)
         if self.volume:
             return heat
         depth = self.depth_fc(self.avgpool(feat).flatten(1))
