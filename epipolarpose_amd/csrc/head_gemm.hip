@@ -1101,8 +1101,9 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
     }
     int cfg = (ov == 0 && N <= 64 && (long long)M * nphase >= 256 * 256) ? CFG_TALL : CFG_SMALL;
     // smaller tiles while the launch leaves CUs without two workgroups (EPI_GEMM_FILL: the workgroup count below which the next
-    // smaller tile is taken; 0 = never)
-    static const long long fill_env = [] { const char* e = getenv("EPI_GEMM_FILL"); return e ? atoll(e) : 384LL; }();
+    // smaller tile is taken; 0 = never, the default -- measured per layer and in the step (profiles/r02_conv_layers_g_*): a few layers
+    // gain 1 .. 5 us, the stride-2 3x3 layers lose 30 us, the step 7.64 (off) / 7.70 (384) / 7.81 ms (640))
+    static const long long fill_env = [] { const char* e = getenv("EPI_GEMM_FILL"); return e ? atoll(e) : 0LL; }();
     if (cfg == CFG_SMALL && ov == 0 && !out_f32 && fill_env > 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase;
         const long long t64x128 = (long long)((M + 63) / 64) * ((N + 127) / 128) * nphase;

@@ -247,11 +247,13 @@ void flush_pending_reduces() {
         }
         for (auto& r : P.rows) { r.chunk_begin = chunks; chunks += epi_slab_reduce_chunks(r.n); }
         const size_t bytes = sizeof(EpiSlabReduce) * (size_t)nrows;
-        // Which stream?  With weight gradients in flight on the second stream the sum runs THERE, behind them (and behind the main
-        // stream's own split launches: one more fork event), so that it overlaps whatever the main stream still has to do -- at the end
-        // of a ResNet backward the stem's max-pool / BatchNorm / convolution backward, ~0.3 ms against ~0.18 ms of reduce.
+        // Which stream?  Optionally the second one, behind the weight gradients in flight there (and behind the main stream's own split
+        // launches: one more fork event), overlapping what the main stream still has to do -- at the end of a ResNet backward the stem's
+        // max-pool / BatchNorm / convolution backward.
         hipStream_t stream = c10::hip::getCurrentHIPStream(P.dev.index()).stream();
-        static const bool reduce_on_side = [] { const char* e = getenv("EPI_REDUCE_STREAM"); return !(e && e[0] == '0'); }();      // A/B switch
+        // (EPI_REDUCE_STREAM=1; measured on MI355X: 7.48 vs 7.46 ms/step on the main stream -- the sum then competes with the stem's
+        // backward instead of following it -- so it stays on the main stream by default)
+        static const bool reduce_on_side = [] { const char* e = getenv("EPI_REDUCE_STREAM"); return e && e[0] == '1'; }();
         if (reduce_on_side && g_side.dirty && g_side.device == P.dev.index()) stream = side_fork(P.dev.index(), stream);
         const auto byte_opts = at::TensorOptions().dtype(at::kByte).device(P.dev);
         // the table is the same from step to step (same layers, same arena offsets, gradients from the caching allocator usually at
@@ -867,7 +869,7 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
         }
         ctx->saved_data["has_bias"] = has_bias;
         ctx->saved_data["w_f32"] = w.scalar_type() != at::kBFloat16;
-        ctx->save_for_backward({x, w16, w});
+        ctx->save_for_backward({x, w16, w, has_bias ? *bias_opt : Tensor()});
         return y;
     }
 
@@ -891,9 +893,19 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
                                 (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16");
         }
         if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) {
+            // bias gradient = column sums of dy (one more read of the 285 MB logits gradient): second stream as well when nobody reads it early
             Tensor sums = at::zeros({2 * (int64_t)Cout}, x.options().dtype(at::kFloat));
-            check(epi_column_sums_bf16(dy.data_ptr(), (long long)M, Cout, sums.data_ptr<float>(), current_stream(x)), "epi_column_sums_bf16");
             db = sums.slice(0, 0, Cout);
+            const Tensor bias_leaf = saved[3];
+            if (side_mode() != 0 && bias_leaf.defined() && gradient_consumed_after_backward(bias_leaf)) {
+                const Tensor dyin = dy, out = sums;
+                g_side.jobs.push_back(SideStream::Job{dy, sums, db, [=](epi_stream_t st) {
+                    check(epi_column_sums_bf16(dyin.data_ptr(), (long long)M, Cout, out.data_ptr<float>(), st), "epi_column_sums_bf16");
+                    return EpiSlabReduce();
+                }, "bias_column_sums", 0.0, 2.0 * (double)M * Cout});
+            } else {
+                check(epi_column_sums_bf16(dy.data_ptr(), (long long)M, Cout, sums.data_ptr<float>(), current_stream(x)), "epi_column_sums_bf16");
+            }
         }
         if (ctx->needs_input_grad(1)) {
             // the weight gradient of a 1x1 convolution: dW[co][ci] = sum_m dy[m][co] x[m][ci] (bf16 or fp32 result, split sums deferrable)
