@@ -187,9 +187,13 @@ hipStream_t side_fork(int dev, hipStream_t main_stream) {
         TORCH_CHECK(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, low ? least : 0) == hipSuccess,
                     "weight-gradient stream: create");
         if (S.fork.empty()) {
+            // ordering between two streams of ONE device: the kernels' own agent-scope release / acquire makes the data visible; the
+            // system-scope fence an event adds by default (cache write-back + invalidate) is not needed (EPI_EVENT_FENCE=1 keeps it)
+            static const bool fence = [] { const char* e = getenv("EPI_EVENT_FENCE"); return e && e[0] == '1'; }();
+            const unsigned flags = hipEventDisableTiming | (fence ? 0u : (unsigned)hipEventDisableSystemFence);
             S.fork.resize(256);
-            for (auto& e : S.fork) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "weight-gradient stream: event");
-            TORCH_CHECK(hipEventCreateWithFlags(&S.joined, hipEventDisableTiming) == hipSuccess, "weight-gradient stream: event");
+            for (auto& e : S.fork) TORCH_CHECK(hipEventCreateWithFlags(&e, flags) == hipSuccess, "weight-gradient stream: event");
+            TORCH_CHECK(hipEventCreateWithFlags(&S.joined, flags) == hipSuccess, "weight-gradient stream: event");
         }
         S.device = dev;
         S.low_priority = low;
