@@ -282,6 +282,9 @@ def main():
     use_graph = bool(args.graph)
     cfg, model, criterion, optimizer, images, label, weight, meta, scenes = build_problem(args, device, rank, capturable=use_graph)
     grad_sync = None
+    if world == 1 and not args.force_grad_sync and not args.graph:
+        from epipolarpose_amd.optim import enable_step_in_backward
+        enable_step_in_backward(optimizer, model)       # EPI_STEP_IN_BACKWARD=1 only (measured: < 1 %)
     if world > 1 or args.force_grad_sync:
         epd.broadcast_module(model, optimizer=optimizer)
         grad_sync = epd.BucketedGradSync(model, optimizer=optimizer)

@@ -221,9 +221,6 @@ struct PendingReduces {
     // the tensor as .grad (it would clone the not-yet-reduced memory instead); a storage that died before the flush is skipped
     std::vector<c10::weak_intrusive_ptr<c10::StorageImpl>> keep;
     c10::Device dev = c10::Device(c10::kCPU);
-    Tensor table_dev, table_host;    // device copy of rows / pinned staging
-    std::vector<EpiSlabReduce> uploaded;
-    hipEvent_t upload_done = nullptr;
     int device = -1;
 };
 PendingReduces g_pend;
@@ -239,18 +236,63 @@ bool defer_wgrad_reduce(bool on) {
     return before;
 }
 
+void end_of_pass_callback();
+
+// one cached device table per flush position inside a pass (0: an early flush from begin_early_step(), 1: the end of the pass): the
+// tables repeat from step to step, so each slot is uploaded only when its content changed
+struct ReduceTable {
+    Tensor dev, host;                // device copy of the rows / pinned staging
+    std::vector<EpiSlabReduce> uploaded;
+    hipEvent_t upload_done = nullptr;
+};
+ReduceTable g_reduce_tables[2];
+
+// sum the registered slabs with one launch on `stream`; leaves the arena bookkeeping alone
+void launch_pending_rows(hipStream_t stream, int slot) {
+    PendingReduces& P = g_pend;
+    if (P.rows.empty()) return;
+    ReduceTable& T = g_reduce_tables[slot];
+    const int nrows = (int)P.rows.size();
+    long long chunks = 0;
+    std::vector<c10::intrusive_ptr<c10::StorageImpl>> alive(P.keep.size());
+    for (size_t i = 0; i < P.rows.size(); ++i) {
+        alive[i] = P.keep[i].lock();
+        if (!alive[i]) { P.rows[i].n = 0; P.rows[i].nsplit = 0; }                    // nobody holds this gradient any more
+    }
+    for (auto& r : P.rows) { r.chunk_begin = chunks; chunks += epi_slab_reduce_chunks(r.n); }
+    const size_t bytes = sizeof(EpiSlabReduce) * (size_t)nrows;
+    const auto byte_opts = at::TensorOptions().dtype(at::kByte).device(P.dev);
+    // the table is the same from step to step (same layers, same arena offsets, gradients from the caching allocator usually at
+    // the same addresses): upload only when it changed
+    const bool same = T.uploaded.size() == P.rows.size() && std::memcmp(T.uploaded.data(), P.rows.data(), bytes) == 0;
+    if (!same) {
+        if (!T.dev.defined() || (size_t)T.dev.numel() < bytes || T.dev.device() != P.dev) {
+            T.dev = at::empty({(int64_t)std::max<size_t>(bytes, 8192)}, byte_opts);
+            T.host = at::empty({T.dev.numel()}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+        }
+        if (T.upload_done) {                             // the previous copy must have read the staging buffer
+            TORCH_CHECK(hipEventSynchronize(T.upload_done) == hipSuccess, "deferred reduce: event");
+        } else {
+            TORCH_CHECK(hipEventCreateWithFlags(&T.upload_done, hipEventDisableTiming) == hipSuccess, "deferred reduce: event");
+        }
+        std::memcpy(T.host.data_ptr(), P.rows.data(), bytes);
+        TORCH_CHECK(hipMemcpyAsync(T.dev.data_ptr(), T.host.data_ptr(), bytes, hipMemcpyHostToDevice, stream) == hipSuccess,
+                    "deferred reduce: table upload");
+        TORCH_CHECK(hipEventRecord(T.upload_done, stream) == hipSuccess, "deferred reduce: event");
+        T.uploaded = P.rows;
+    }
+    if (chunks > 0) {
+        ScopedTimer timer("conv_bwd_weight", 0.0, 0.0, reinterpret_cast<epi_stream_t>(stream));    // (the reduce belongs to the family's time)
+        check(epi_slab_reduce_multi(reinterpret_cast<const EpiSlabReduce*>(T.dev.data_ptr()), nrows, chunks,
+                                    reinterpret_cast<epi_stream_t>(stream)), "epi_slab_reduce_multi");
+    }
+    P.rows.clear();
+    P.keep.clear();
+}
+
 void flush_pending_reduces() {
     PendingReduces& P = g_pend;
     if (!P.rows.empty()) {
-        const int nrows = (int)P.rows.size();
-        long long chunks = 0;
-        std::vector<c10::intrusive_ptr<c10::StorageImpl>> alive(P.keep.size());
-        for (size_t i = 0; i < P.rows.size(); ++i) {
-            alive[i] = P.keep[i].lock();
-            if (!alive[i]) { P.rows[i].n = 0; P.rows[i].nsplit = 0; }                    // nobody holds this gradient any more
-        }
-        for (auto& r : P.rows) { r.chunk_begin = chunks; chunks += epi_slab_reduce_chunks(r.n); }
-        const size_t bytes = sizeof(EpiSlabReduce) * (size_t)nrows;
         // Which stream?  Optionally the second one, behind the weight gradients in flight there (and behind the main stream's own split
         // launches: one more fork event), overlapping what the main stream still has to do -- at the end of a ResNet backward the stem's
         // max-pool / BatchNorm / convolution backward.
@@ -259,33 +301,8 @@ void flush_pending_reduces() {
         // backward instead of following it -- so it stays on the main stream by default)
         static const bool reduce_on_side = [] { const char* e = getenv("EPI_REDUCE_STREAM"); return e && e[0] == '1'; }();
         if (reduce_on_side && g_side.dirty && g_side.device == P.dev.index()) stream = side_fork(P.dev.index(), stream);
-        const auto byte_opts = at::TensorOptions().dtype(at::kByte).device(P.dev);
-        // the table is the same from step to step (same layers, same arena offsets, gradients from the caching allocator usually at
-        // the same addresses): upload only when it changed
-        const bool same = P.uploaded.size() == P.rows.size() && std::memcmp(P.uploaded.data(), P.rows.data(), bytes) == 0;
-        if (!same) {
-            if (!P.table_dev.defined() || (size_t)P.table_dev.numel() < bytes) {
-                P.table_dev = at::empty({(int64_t)std::max<size_t>(bytes, 8192)}, byte_opts);
-                P.table_host = at::empty({P.table_dev.numel()}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
-            }
-            if (P.upload_done) {                             // the previous copy must have read the staging buffer
-                TORCH_CHECK(hipEventSynchronize(P.upload_done) == hipSuccess, "deferred reduce: event");
-            } else {
-                TORCH_CHECK(hipEventCreateWithFlags(&P.upload_done, hipEventDisableTiming) == hipSuccess, "deferred reduce: event");
-            }
-            std::memcpy(P.table_host.data_ptr(), P.rows.data(), bytes);
-            TORCH_CHECK(hipMemcpyAsync(P.table_dev.data_ptr(), P.table_host.data_ptr(), bytes, hipMemcpyHostToDevice, stream) == hipSuccess,
-                        "deferred reduce: table upload");
-            TORCH_CHECK(hipEventRecord(P.upload_done, stream) == hipSuccess, "deferred reduce: event");
-            P.uploaded = P.rows;
-        }
-        if (chunks > 0) {
-            ScopedTimer timer("conv_bwd_weight", 0.0, 0.0, reinterpret_cast<epi_stream_t>(stream));    // (the reduce belongs to the family's time)
-            check(epi_slab_reduce_multi(reinterpret_cast<const EpiSlabReduce*>(P.table_dev.data_ptr()), nrows, chunks,
-                                        reinterpret_cast<epi_stream_t>(stream)), "epi_slab_reduce_multi");
-        }
-        P.rows.clear();
-        P.keep.clear();
+        else side_join();            // the slabs may still be in flight on the weight-gradient stream
+        launch_pending_rows(stream, 1);
     }
     side_join();                     // the main stream waits for everything on the weight-gradient stream: unsplit gradients, slabs, the sum
     P.target = std::max(P.target, P.wanted);
@@ -294,13 +311,28 @@ void flush_pending_reduces() {
     P.wanted = 0;
 }
 
+// Optimizer work INSIDE the backward pass (optim.FusedAdam.enable_step_in_backward): called from a tensor hook at a point of the
+// pass where the gradients of everything downstream are final except for their pending slab sums.  Sums those slabs on the
+// weight-gradient stream (behind the launches that write them) and returns that stream: what the caller enqueues on it next -- the
+// Adam update and the weight re-packing of those parameters -- runs beside the rest of the backward pass instead of after it.  The
+// main stream joins at the end of the pass as usual.  Returns 0 when the second stream is off (the caller then does nothing early).
+int64_t begin_early_step(int64_t device_index) {
+    if (side_mode() == 0) return 0;
+    PendingReduces& P = g_pend;
+    hipStream_t main_stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)device_index).stream();
+    hipStream_t side = side_fork((int)device_index, main_stream);          // behind everything enqueued so far on either stream
+    if (!P.rows.empty() && P.dev.index() == device_index) launch_pending_rows(side, 0);
+    end_of_pass_callback();                                                // somebody has to join, even if no weight gradient follows
+    return reinterpret_cast<int64_t>(side);
+}
+
 // slab memory for one backward-weight launch of `bytes`, or nullptr when the arena is full (the caller then reduces at once)
 void* pending_slab_alloc(size_t bytes, const Tensor& like) {
     PendingReduces& P = g_pend;
     bytes = (bytes + 255) & ~(size_t)255;
     if (P.device != like.device().index()) {            // one process drives one GPU; a device change starts over
         TORCH_CHECK(P.rows.empty(), "deferred reduce: pending work on another device");
-        P.arena = Tensor(); P.table_dev = Tensor(); P.uploaded.clear(); P.device = like.device().index();
+        P.arena = Tensor(); P.device = like.device().index();
     }
     P.wanted += bytes;
     if (!P.arena.defined()) {
@@ -985,13 +1017,17 @@ Tensor maxpool3x3s2(Tensor x) { return MaxPool3x3s2::apply(x); }
 // the Adam kernel has been enqueued), and write parameter / shadow / gradient addresses into the pinned host table.  Returns
 // (changed, temporaries): `changed` tells the caller to upload the table again.
 std::tuple<bool, std::vector<Tensor>> adam_prepare(const std::vector<Tensor>& params, const std::vector<c10::optional<Tensor>>& copies,
-                                                  Tensor table_host, int64_t row) {
+                                                  Tensor table_host, int64_t row, const std::vector<int64_t>& only) {
     TORCH_CHECK(params.size() == copies.size() && table_host.scalar_type() == at::kLong && table_host.numel() >= (int64_t)params.size() * row,
                 "adam_prepare: table size");
     int64_t* t = table_host.data_ptr<int64_t>();
     bool changed = false;
     std::vector<Tensor> keep;
-    for (size_t i = 0; i < params.size(); ++i) {
+    // `only`: the parameter indices to refresh (a partial step, optim.FusedAdam.enable_step_in_backward); empty = all
+    const size_t count = only.empty() ? params.size() : only.size();
+    for (size_t k = 0; k < count; ++k) {
+        const size_t i = only.empty() ? k : (size_t)only[k];
+        TORCH_CHECK(i < params.size(), "adam_prepare: parameter index");
         const Tensor& p = params[i];
         const bool has_copy = copies[i].has_value() && copies[i]->defined();
         Tensor g = has_copy ? copies[i]->grad() : p.grad();
@@ -1035,6 +1071,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv1x1_bias", &conv1x1_bias, "1x1 convolution (+ bias) on the NHWC view as one autograd node");
     m.def("maxpool3x3s2", &maxpool3x3s2, "MaxPool2d(kernel 3, stride 2, padding 1), NHWC bf16, autograd-aware");
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
+    m.def("begin_early_step", &begin_early_step,
+          "inside a backward pass: sum the pending weight-gradient slabs on the second stream and return that stream (0: second stream off)");
     m.def("flush_pending_reduces", &flush_pending_reduces,
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
     m.def("wgrad_stream_mode", &wgrad_stream_mode,

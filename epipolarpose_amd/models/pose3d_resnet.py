@@ -165,6 +165,13 @@ class PoseResNet(nn.Module):
             self.depth_fc = nn.Linear(self.backbone_planes, self.num_joints * self.depth_res)
         self.to(memory_format=torch.channels_last)
 
+    def step_in_backward_split(self):
+        """(boundary, late modules) for ``optim.FusedAdam.enable_step_in_backward``: when the backward pass crosses the output of
+        ``layer1`` every gradient behind it (layers 2-4, the head: 99 % of the parameters) is final."""
+        n = int(os.environ.get("EPI_EARLY_BOUNDARY", "1"))          # measurement switch: the boundary after layer n
+        layers = [self.layer1, self.layer2, self.layer3, self.layer4]
+        return layers[n - 1], [self.conv1, self.bn1] + layers[:n]
+
     def features(self, x):
         x = self.bn1(self.conv1(x))
         if x.is_cuda and x.shape[1] % 8 == 0 and MAXPOOL_BACKEND == "hip":      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)

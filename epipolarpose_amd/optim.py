@@ -85,6 +85,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if lp_modules else None
         self._lp_of = {}
+        self._parts, self._early_done, self._early_handle = None, False, None
         self._clear_list = None
         self._lp_modules = lp_modules
         self._offs = offs
@@ -124,48 +125,132 @@ class FusedAdam(torch.optim.Optimizer):
         """Backward-data operands (``weight_bwd``: transposed / parity-phase-ordered bf16 weights, include/epipolar_hip.h) of every
         convolution that runs on the implicit-GEMM kernels (modules carrying ``epi_geometry``, models/fused.py:FusedConvBn): one flat
         buffer, refreshed by ONE multi-layer pack launch after each Adam step."""
-        lib = hip.load()
         convs = [m for m in lp_modules if getattr(m, "epi_geometry", None) is not None]
         deconvs = [m for m in lp_modules if getattr(m, "epi_deconv", False) and m.weight.is_contiguous(memory_format=torch.channels_last)]
         self._pack_rows, self._pack_tiles, self._pack_table = 0, 0, None
+        self._pack_convs, self._pack_deconvs = convs, deconvs
         if not convs and not deconvs:
             return
-        import ctypes
         total = sum(m.weight.numel() for m in convs) + sum(m.weight.numel() for m in deconvs)
         self._packed = torch.empty(total, dtype=torch.bfloat16, device=dev)
-        row_bytes = lib.epi_conv2d_pack_row_bytes()
-        host = torch.zeros((len(convs) + len(deconvs)) * row_bytes, dtype=torch.uint8)
-        off, tiles, r = 0, 0, 0
-        nt = ctypes.c_longlong(0)
+        off = 0
         for m in convs:
             n = m.weight.numel()
-            wb = self._packed[off:off + n]
+            object.__setattr__(m, "weight_bwd", self._packed[off:off + n])
             off += n
-            object.__setattr__(m, "weight_bwd", wb)
-            k, stride, pad = m.epi_geometry
-            cout, cin = m.weight.shape[0], m.weight.shape[1]
-            hip._check(lib.epi_conv2d_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), wb.data_ptr(), cout, cin, k, k,
-                                                    stride, pad, tiles, ctypes.byref(nt)), "epi_conv2d_pack_fill_row")
-            tiles += nt.value
-            r += 1
         for m in deconvs:       # ConvTranspose2d(k4 s2 p1): the channels_last copy IS the backward-data operand; pack the forward one
             cin, cout = m.weight.shape[0], m.weight.shape[1]
             n = m.weight.numel()
-            wp = self._packed[off:off + n].view(4, cout, 4 * cin)
+            object.__setattr__(m, "weight_phase", self._packed[off:off + n].view(4, cout, 4 * cin))
             off += n
-            object.__setattr__(m, "weight_phase", wp)
-            hip._check(lib.epi_deconv4x4s2_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), wp.data_ptr(), cin, cout, tiles,
-                                                         ctypes.byref(nt)), "epi_deconv4x4s2_pack_fill_row")
-            tiles += nt.value
-            r += 1
-        self._pack_table = host.to(dev)
-        self._pack_rows, self._pack_tiles = r, tiles
+        self._pack_table, self._pack_rows, self._pack_tiles = self._build_pack_table(convs, deconvs, dev)
         self._pack_weights()
 
-    def _pack_weights(self):
-        if self._pack_rows:
-            hip._check(hip.load().epi_conv2d_pack_weight_bwd_multi(self._pack_table.data_ptr(), self._pack_rows, self._pack_tiles,
-                                                                   hip._stream()), "epi_conv2d_pack_weight_bwd_multi")
+    def _build_pack_table(self, convs, deconvs, dev):
+        """Device table of the multi-layer pack launch for the given modules: (table, rows, tiles)."""
+        import ctypes
+        lib = hip.load()
+        if not convs and not deconvs:
+            return None, 0, 0
+        row_bytes = lib.epi_conv2d_pack_row_bytes()
+        host = torch.zeros((len(convs) + len(deconvs)) * row_bytes, dtype=torch.uint8)
+        tiles, r = 0, 0
+        nt = ctypes.c_longlong(0)
+        for m in convs:
+            k, stride, pad = m.epi_geometry
+            cout, cin = m.weight.shape[0], m.weight.shape[1]
+            hip._check(lib.epi_conv2d_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), m.weight_bwd.data_ptr(), cout, cin, k, k,
+                                                    stride, pad, tiles, ctypes.byref(nt)), "epi_conv2d_pack_fill_row")
+            tiles += nt.value
+            r += 1
+        for m in deconvs:
+            cin, cout = m.weight.shape[0], m.weight.shape[1]
+            hip._check(lib.epi_deconv4x4s2_pack_fill_row(host.data_ptr() + r * row_bytes, m.weight_lp.data_ptr(), m.weight_phase.data_ptr(), cin, cout,
+                                                         tiles, ctypes.byref(nt)), "epi_deconv4x4s2_pack_fill_row")
+            tiles += nt.value
+            r += 1
+        return host.to(dev), r, tiles
+
+    def _pack_weights(self, part=None):
+        table, rows, tiles = (self._pack_table, self._pack_rows, self._pack_tiles) if part is None else part["pack"]
+        if rows:
+            hip._check(hip.load().epi_conv2d_pack_weight_bwd_multi(table.data_ptr(), rows, tiles, hip._stream()), "epi_conv2d_pack_weight_bwd_multi")
+
+    # ---- the update of the deep part of the network INSIDE the backward pass ---------------------------------------------------------
+    def enable_step_in_backward(self, boundary, late_modules):
+        """Run the update of every parameter whose gradient is final when the backward pass crosses ``boundary``'s output (everything
+        NOT in ``late_modules``: for PoseResNet ``boundary = model.layer1``, ``late_modules = [conv1, bn1, layer1]`` leaves 99 % of the
+        parameters) from a tensor hook at that point, on the second HIP stream of the C++ glue: the slab sums of their weight gradients,
+        their Adam update and the re-packing of their backward operands then run BESIDE the rest of the backward pass instead of after
+        it (0.4 ms of HBM-bound work at the end of every ResNet-50 step).  ``step()`` finishes the late parameters.
+        Measured gain on MI355X: below 1 % (see ``enable_step_in_backward`` at the end of this file), so nothing enables it by default.
+
+        Opt-in, because it changes WHEN parameters change: only for loops that run exactly one backward pass per ``step()``, always
+        call ``step()`` after it, use no gradient clipping (``max_grad_norm``) and no gradient all-reduce between backward and step
+        (one process per GPU with ``BucketedGradSync``: leave it off).  The arithmetic of the update is unchanged."""
+        if self.max_grad_norm is not None:
+            raise ValueError("enable_step_in_backward: not with gradient clipping (the norm needs every gradient)")
+        late_ids = {id(p) for m in late_modules for p in m.parameters()}
+        late_mods = {id(m) for lm in late_modules for m in lm.modules()}
+        early_idx = [i for i, p in enumerate(self._params) if id(p) not in late_ids]
+        late_idx = [i for i, p in enumerate(self._params) if id(p) in late_ids]
+        if not early_idx or not late_idx:
+            raise ValueError("enable_step_in_backward: the split leaves one side empty")
+        dev = self._table_dev.device
+        self._parts = {}
+        for name, idx in (("early", early_idx), ("late", late_idx)):
+            keep = set(idx)
+            chunks = [c for c in self._chunks_all if c[0] in keep]
+            in_part = (lambda m: id(m) not in late_mods) if name == "early" else (lambda m: id(m) in late_mods)
+            self._parts[name] = {"idx": idx, "nchunks": len(chunks), "chunks": torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous(),
+                                 "pack": self._build_pack_table([m for m in self._pack_convs if in_part(m)],
+                                                                [m for m in self._pack_deconvs if in_part(m)], dev)}
+        self._early_done = False
+        if self._early_handle is not None:
+            self._early_handle.remove()
+        self._early_handle = boundary.register_forward_hook(self._boundary_forward_hook)
+
+    def disable_step_in_backward(self):
+        if self._early_handle is not None:
+            self._early_handle.remove()
+        self._early_handle, self._parts, self._early_done = None, None, False
+
+    def _boundary_forward_hook(self, module, inputs, output):
+        if self._parts is not None and torch.is_grad_enabled() and isinstance(output, torch.Tensor) and output.requires_grad:
+            output.register_hook(self._early_step_hook)
+
+    def _early_step_hook(self, grad):
+        if self._parts is None:
+            return None
+        if self._early_done:
+            raise RuntimeError("FusedAdam.enable_step_in_backward: a second backward pass before optimizer.step()")
+        handle = hip.glue().begin_early_step(grad.device.index)       # sums the pending weight-gradient slabs on the second stream
+        if handle:
+            with torch.cuda.stream(torch.cuda.ExternalStream(handle, device=grad.device)), torch.no_grad():
+                self._update(self._parts["early"], self._step + 1)
+            self._early_done = True
+        return None
+
+    def _update(self, part, step_no):
+        """Adam + backward-operand packing of one part of the parameters (None: all) on the current stream."""
+        if self._table_event is not None:
+            self._table_event.synchronize()              # the previous upload (a whole step ago) must have left the staging buffer
+            self._table_event = None
+        changed, keep = hip.glue().adam_prepare(self._params, self._copies, self._table_host, _ROW, [] if part is None else part["idx"])
+        if changed:
+            self._table_dev.copy_(self._table_host, non_blocking=True)
+            self._table_event = torch.cuda.Event()
+            self._table_event.record()
+        group = self.param_groups[0]
+        chunks, nchunks = (self._chunks_dev, len(self._chunks_all)) if part is None else (part["chunks"], part["nchunks"])
+        if self.max_grad_norm is not None:
+            self.last_grad_norm_sq = torch.zeros((), dtype=torch.float32, device=self._table_dev.device)
+            hip.adam_step_clipped(self._table_dev, chunks, nchunks, group["lr"], group["betas"][0], group["betas"][1],
+                                  group["eps"], step_no, float(self.max_grad_norm), self.last_grad_norm_sq)
+        else:
+            hip.adam_step(self._table_dev, chunks, nchunks, group["lr"], group["betas"][0], group["betas"][1], group["eps"], step_no)
+        del keep
+        self._pack_weights(part)                     # backward-data operands of the implicit-GEMM convolutions follow the update
 
     def refresh_training_copies(self):
         """Re-copy every fp32 master into its bf16 training copy (after the masters were loaded / broadcast)."""
@@ -185,6 +270,7 @@ class FusedAdam(torch.optim.Optimizer):
         return dict(self._lp_of)
 
     def zero_grad(self, set_to_none=True):
+        self._early_done = False             # (a pass whose step() never came -- an exception in the loop -- must not block the next one)
         if set_to_none:                      # one C++ call for the ~170 parameters and their bf16 training copies
             if self._clear_list is None:
                 self._clear_list = list(self._params) + list(self._lp_of.values())
@@ -202,26 +288,13 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         # gradient / parameter / shadow addresses -> the pinned host table, in C++ (no Python loop over ~170 parameters); the
-        # addresses are stable once the allocator has warmed up, so the upload below is rare
-        if self._table_event is not None:
-            self._table_event.synchronize()              # the previous upload (a whole step ago) must have left the staging buffer
-            self._table_event = None
-        changed, keep = hip.glue().adam_prepare(self._params, self._copies, self._table_host, _ROW)
-        if changed:
-            self._table_dev.copy_(self._table_host, non_blocking=True)
-            self._table_event = torch.cuda.Event()
-            self._table_event.record()
-        group = self.param_groups[0]
+        # addresses are stable once the allocator has warmed up, so the table upload is rare
         self._step += 1
-        if self.max_grad_norm is not None:
-            self.last_grad_norm_sq = torch.zeros((), dtype=torch.float32, device=self._table_dev.device)
-            hip.adam_step_clipped(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
-                                  group["eps"], self._step, float(self.max_grad_norm), self.last_grad_norm_sq)
+        if self._parts is not None and self._early_done:      # the deep part was updated inside the backward pass
+            self._early_done = False
+            self._update(self._parts["late"], self._step)
         else:
-            hip.adam_step(self._table_dev, self._chunks_dev, len(self._chunks_all), group["lr"], group["betas"][0], group["betas"][1],
-                          group["eps"], self._step)
-        del keep
-        self._pack_weights()                         # backward-data operands of the implicit-GEMM convolutions follow the update
+            self._update(None, self._step)
         return loss
 
     def state_dict(self):
@@ -261,3 +334,20 @@ class FusedAdam(torch.optim.Optimizer):
             self._exp_avg.zero_()
             self._exp_avg_sq.zero_()
         self.refresh_training_copies()               # masters may have been reloaded too
+
+
+def enable_step_in_backward(optimizer, model, grad_sync=None):
+    """Switch on ``FusedAdam.enable_step_in_backward`` when asked for (EPI_STEP_IN_BACKWARD=1) and where it applies: a FusedAdam
+    without clipping, a model that names its split (``PoseResNet.step_in_backward_split``), no gradient all-reduce between backward
+    and step.  Returns whether it is on.  OFF by default -- measured on MI355X (ResNet-50, batch 32, four boxes): the 0.4 ms of slab
+    sums + Adam + weight packing leave the end of the step, but they are HBM-bound work beside an HBM-bound part of the backward pass
+    (BatchNorm of the wide early layers), and the step gains 0.3 .. 0.9 % (7.24 / 7.27 vs 7.27 / 7.29 ms; boundary after layer 2, 3
+    or 4 instead of 1: the same)."""
+    import os
+    if os.environ.get("EPI_STEP_IN_BACKWARD", "0") != "1" or grad_sync is not None:
+        return False
+    if not isinstance(optimizer, FusedAdam) or optimizer.max_grad_norm is not None or not hasattr(model, "step_in_backward_split"):
+        return False
+    boundary, late = model.step_in_backward_split()
+    optimizer.enable_step_in_backward(boundary, late)
+    return True

@@ -1,0 +1,90 @@
+"""FusedAdam.enable_step_in_backward: the update of the deep part of a network issued from a tensor hook INSIDE the backward pass, on
+the second HIP stream of the C++ glue, must leave exactly the parameters a plain ``step()`` after the pass leaves."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _train(model, data, steps, early, boundary=None, late=None):
+    from epipolarpose_amd.optim import FusedAdam
+    opt = FusedAdam(model, lr=1e-2)
+    if early:
+        opt.enable_step_in_backward(boundary(model), late(model))
+    fired = []
+    for s in range(steps):
+        opt.zero_grad(set_to_none=True)
+        loss = model(data[s]).float().square().mean()
+        loss.backward()
+        fired.append(opt._early_done)
+        opt.step()
+        assert not opt._early_done
+    torch.cuda.synchronize()
+    return opt, fired
+
+
+def test_step_in_backward_is_bit_identical_on_a_deterministic_network():
+    """Linear layers only (deterministic GEMMs, no atomics): the early update of layers 2 and 3 from the hook on layer 1's output +
+    the late update of layer 1 in step() == one update of everything in step(), bit for bit, moments and step count included."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(),
+                              torch.nn.Linear(256, 32)).to(dev)
+    alt = copy.deepcopy(ref)
+    data = [torch.randn(128, 64, device=dev) for _ in range(4)]
+    o_ref, fired_ref = _train(ref, data, 4, early=False)
+    o_alt, fired_alt = _train(alt, data, 4, early=True, boundary=lambda m: m[0], late=lambda m: [m[0]])
+    assert fired_ref == [False] * 4 and fired_alt == [True] * 4
+    for (k, a), (_, b) in zip(ref.state_dict().items(), alt.state_dict().items()):
+        assert torch.equal(a, b), k
+    sa, sb = o_ref.state_dict()["state"], o_alt.state_dict()["state"]
+    for i in sa:
+        assert float(sa[i]["step"]) == float(sb[i]["step"]) == 4.0
+        assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"])
+
+
+def test_step_in_backward_on_the_pose_network():
+    """PoseResNet-18 on the hand-written kernels (bf16 training copies, packed backward operands, deferred slab sums, weight gradients
+    on the second stream): three steps with the update of layers 2-4 + head inside the backward pass against three plain steps.
+    BatchNorm sums by atomics make two runs of the SAME code differ slightly, so the yardstick is that run-to-run difference."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.EXTRA.NUM_LAYERS = 18
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = 4, 16, [64, 64]
+    torch.manual_seed(1)
+    base = get_pose_net(cfg, is_train=False).to(dev).train()
+    data = [torch.randn(8, 3, 64, 64, device=dev) for _ in range(3)]
+
+    def run(early):
+        m = copy.deepcopy(base)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            opt, fired = _train(m, data, 3, early, boundary=lambda mm: mm.step_in_backward_split()[0],
+                                late=lambda mm: mm.step_in_backward_split()[1])
+        assert fired == [early] * 3
+        # the packed backward operands follow the bf16 training copies in both modes
+        for mod in m.modules():
+            if getattr(mod, "weight_bwd", None) is not None and mod.weight.shape[2] == 1 and getattr(mod, "epi_geometry", (0, 0, 0))[1] == 1:
+                assert torch.equal(mod.weight_bwd.view(mod.weight.shape[1], mod.weight.shape[0]), mod.weight_lp.flatten(1).t())
+        return {k: v.detach().float().clone() for k, v in m.named_parameters()}, m
+    a, _ = run(False)
+    a2, _ = run(False)
+    b, mb = run(True)
+    moved = 0
+    for k in a:
+        noise = float((a[k] - a2[k]).abs().max())
+        diff = float((a[k] - b[k]).abs().max())
+        start = dict(base.named_parameters())[k].detach().float()
+        step = float((a[k] - start).abs().max())
+        moved += step > 0
+        assert diff <= 3.0 * noise + 0.05 * step + 1e-7, (k, diff, noise, step)     # a part that was not updated would differ by ~step
+        assert float((b[k] - start).abs().max()) > 0 or step == 0, k
+    assert moved >= len(a) - 2
+    # the bf16 training copies follow their masters
+    for mod in mb.modules():
+        if getattr(mod, "weight_lp", None) is not None:
+            assert torch.equal(mod.weight_lp.detach(), mod.weight.detach().to(torch.bfloat16)), type(mod)
