@@ -11,10 +11,18 @@
 
 namespace epi {
 
+// XCD-aware block order (8 XCDs with private L2s; the dispatcher places linear block b on XCD b % 8): every XCD gets a CONTIGUOUS range
+// of logical blocks, so the input rows that neighbouring output rows share are fetched into one L2 instead of two (PMC, first version:
+// the forward read x 1.5 times, the backward dy and the positions 2.1 times; profiles/r02_pmc_traffic_summary.csv)
+__device__ __forceinline__ long long pool_block(long long lin, long long total) {
+    const long long q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // one thread: 8 consecutive channels (16 bytes) of one output pixel
 __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
                                                                unsigned char* __restrict__ pos, int H, int W, int C8, int Ho, int Wo, long long total) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = pool_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int c8 = (int)(t % C8);
     long long r = t / C8;
@@ -58,7 +66,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned sh
 // one thread: 8 consecutive channels of one INPUT pixel; sums (fp32, rounded once) dy of the windows that selected it
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned char* __restrict__ pos,
                                                                unsigned short* __restrict__ dx, int H, int W, int C8, int Ho, int Wo, long long total) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = pool_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int c8 = (int)(t % C8);
     long long r = t / C8;

@@ -51,6 +51,22 @@ def main():
         for _ in range(REPS):
             y = m(x, residual=r)
             y.backward(dy)
+    # backbone convolutions (round 2): one 1x1, one 3x3 and one stride-2 layer of ResNet-50, forward / backward-data / backward-weight
+    for cin, cout, k, s, h in ((256, 64, 1, 1, 64), (64, 256, 1, 1, 64), (128, 128, 3, 1, 32), (256, 256, 3, 2, 32), (1024, 256, 1, 1, 16), (512, 2048, 1, 1, 8)):
+        pad = k // 2
+        x = cl(torch.randn(b, cin, h, h, device=DEV).to(torch.bfloat16))
+        w = cl((torch.randn(cout, cin, k, k, device=DEV) * 0.05).to(torch.bfloat16))
+        y = hip.conv2d_fwd(x, w, s, pad)
+        dy = cl(torch.randn_like(y.float()).to(torch.bfloat16))
+        wb = hip.conv2d_pack_weight_bwd(w, s, pad)
+        for _ in range(REPS):
+            hip.conv2d_fwd(x, w, s, pad)
+            hip.conv2d_bwd_data(dy, wb, tuple(x.shape), k, s, pad)
+            hip.conv2d_bwd_weight(x, dy, k, s, pad, dtype=torch.bfloat16)
+    x = cl(torch.randn(b, 64, 128, 128, device=DEV).clamp_min(0).to(torch.bfloat16))
+    for _ in range(REPS):
+        y, pos = hip.maxpool3x3s2_fwd(x)
+        hip.maxpool3x3s2_bwd(y, pos, (128, 128))
     torch.cuda.synchronize()
     print("pmc target done")
 
