@@ -50,14 +50,18 @@ class GraphedTrainStep:
     are copied into the static buffers before each replay.  Requires a capturable optimizer
     (``torch.optim.Adam(..., capturable=True)``) and warmed-up MIOpen kernels (done here on a side stream).
     Measured on MI355X / ROCm 7.2 ("measured and rejected"): replay adds ~2.5 us per graph node, 11.4 ms per
-    step against 9.5 ms for eager launches at ~570 launches per step, and the eager step is GPU-bound since the C++
-    autograd glue (host enqueue 5.3 ms) -- so ``bench.py`` keeps eager as the default and this class as an option
-    (``--graph 1``).
+    step against 9.5 ms for eager launches at ~570 launches per step; the eager step is GPU-bound (host enqueue 3-4 ms
+    against 7.2 ms, kernels back to back with 0.00 us gaps in the trace) and overlaps its weight gradients on a second
+    stream -- so ``bench.py`` keeps eager as the default and this class as an option (``--graph 1``).
     """
 
     def __init__(self, model, criterion, optimizer, batch_data, batch_label, batch_label_weight, meta=None, n_view=None,
                  ss_method="iterative", autocast=True, warmup=3):
         self.data, self.label, self.weight = batch_data, batch_label, batch_label_weight
+        # a captured step is one stream of nodes: the eager path's second stream and its end-of-pass slab sum (host-side table uploads
+        # with an event wait) stay out of the capture
+        hip.glue().wgrad_stream_mode(0)
+        hip.glue().defer_wgrad_reduce(False)
         args = (model, criterion, optimizer, self.data, self.label, self.weight)
         kw = dict(meta=meta, n_view=n_view, ss_method=ss_method, autocast=autocast)
         side = torch.cuda.Stream()
