@@ -1025,6 +1025,47 @@ __global__ void splitk_finish_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
+// The same finish for a convolution that feeds a training-mode BatchNorm (plain rows, bf16 result, no bias / addend / phases): it also
+// accumulates the per-column sum and sum of squares of the bf16-ROUNDED outputs into p.stats, as the unsplit launches do from their GEMM
+// epilogue -- the deep layers at batch 32 (2048 rows) are the ones that split K, and each of them paid a separate statistics launch.
+// Block: 256 threads = 64 column quads x 4 row lanes over a tile of FS_ROWS rows x 256 columns; registers -> LDS combine of the 4 row
+// lanes -> one contiguous atomic per column and block into copy (row tile % stats_copies).
+constexpr int FS_ROWS = 32;
+__global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const float* __restrict__ slabs, int nsplit, GemmArgs p) {
+    __shared__ float red[4][2][256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col_tiles = (p.N + 255) / 256;
+    const int tile_m = blockIdx.x / col_tiles, tile_n = blockIdx.x - tile_m * col_tiles;
+    const int n = tile_n * 256 + tx * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < p.N) {
+        for (int r = ty; r < FS_ROWS; r += 4) {
+            const int m = tile_m * FS_ROWS + r;
+            if (m >= p.M) break;
+            float4v a; a.x = a.y = a.z = a.w = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float4v v = *reinterpret_cast<const float4v*>(slabs + ((long long)sp * p.M + m) * p.N + n);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            uint2 o;
+            o.x = pack_bf16x2(a.x, a.y);
+            o.y = pack_bf16x2(a.z, a.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
+            const float v[4] = {__uint_as_float(o.x << 16), __uint_as_float(o.x & 0xffff0000u), __uint_as_float(o.y << 16), __uint_as_float(o.y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[ty][0][tx * 4 + e] = s1[e]; red[ty][1][tx * 4 + e] = s2[e]; }
+    __syncthreads();
+    float* dst = p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N;
+    for (int t = threadIdx.x; t < 512; t += 256) {
+        const int which = t >> 8, c = t & 255, col = tile_n * 256 + c;
+        if (col < p.N) atomicAdd(dst + which * p.N + col, red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c]);
+    }
+}
+
 }  // namespace epi
 
 using namespace epi;
@@ -1276,8 +1317,15 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             else rc = pp.nb == 3 ? launch_patch<PatchWide, 3>(a, pp, st) : launch_patch<PatchWide, 2>(a, pp, st);
             if (rc != EPI_OK) return rc;
             if (pp.nsplit > 1) {
-                const long long n = (long long)a.M * (a.N >> 2);
-                hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.slabs, pp.nsplit, 1, a);
+                if (want_stats && !a.addend) {            // the finish also accumulates the BatchNorm batch sums
+                    a.stats = want_stats;
+                    if (stats_done) *stats_done = 1;
+                    const unsigned blocks = (unsigned)(((a.M + FS_ROWS - 1) / FS_ROWS) * ((a.N + 255) / 256));
+                    hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(blocks), dim3(256), 0, st, a.slabs, pp.nsplit, a);
+                } else {
+                    const long long n = (long long)a.M * (a.N >> 2);
+                    hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.slabs, pp.nsplit, 1, a);
+                }
                 EPI_CHECK_LAUNCH();
             }
             return EPI_OK;
@@ -1302,7 +1350,12 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (pl.nsplit > 1) {
         const long long n = (long long)nphase * a.M * (a.N >> 2);
         const dim3 fg((unsigned)((n + 255) / 256));
-        if (out_f32) hipLaunchKernelGGL(splitk_finish_kernel<true>, fg, dim3(256), 0, st, a.slabs, pl.nsplit, nphase, a);
+        if (!out_f32 && want_stats && nphase == 1 && !a.bias && !a.addend && !a.sc.enabled && !a.ph.enabled && a.N % 4 == 0) {
+            a.stats = want_stats;                         // split-K convolution in front of a BatchNorm: statistics from the finish kernel
+            if (stats_done) *stats_done = 1;
+            const unsigned blocks = (unsigned)(((a.M + FS_ROWS - 1) / FS_ROWS) * ((a.N + 255) / 256));
+            hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(blocks), dim3(256), 0, st, a.slabs, pl.nsplit, a);
+        } else if (out_f32) hipLaunchKernelGGL(splitk_finish_kernel<true>, fg, dim3(256), 0, st, a.slabs, pl.nsplit, nphase, a);
         else hipLaunchKernelGGL(splitk_finish_kernel<false>, fg, dim3(256), 0, st, a.slabs, pl.nsplit, nphase, a);
         EPI_CHECK_LAUNCH();
     }
