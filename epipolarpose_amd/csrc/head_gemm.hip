@@ -1376,6 +1376,14 @@ extern "C" int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, vo
 // All four output-parity phases run in ONE launch (blockIdx.z); workspace: epi_gemm_workspace_bytes(B*H*W, Cout, 4*Cin, 4).
 extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
                                    void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return epi_deconv4x4s2_fwd_stats(x, w_phase, y, B, H, W, Cin, Cout, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same with the BatchNorm batch sums of the result (as epi_conv2d_fwd): bn_sums [epi_bn_sum_copies(Cout)][2 Cout] f32 += per-channel
+// (sum, sum of squares) of the bf16 outputs when the launch can do it from its epilogue (*stats_done = 1), else untouched (*stats_done = 0).
+extern "C" int epi_deconv4x4s2_fwd_stats(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, float* bn_sums,
+                                         int* stats_done, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (stats_done) *stats_done = 0;
     if (!x || !w_phase || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (Cin % GBK || Cout % 4) return EPI_ERR_UNSUPPORTED;
     GemmArgs a = {};
@@ -1390,7 +1398,9 @@ extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, 
         a.ph.bt_off[phase] = (long long)phase * Cout * 4 * Cin;
         for (int t = 0; t < 4; ++t) { a.ph.dy[phase][t] = (phase >> 1) - (t >> 1); a.ph.dx[phase][t] = (phase & 1) - (t & 1); }
     }
-    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream);
+    a.stats = bn_sums;
+    a.stats_copies = epi_bn_sum_copies(Cout);
+    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream, stats_done);
 }
 
 // Backward-data of the same layer:  dy [B][2H][2W][Cout] -> dx [B][H][W][Cin];

@@ -809,15 +809,30 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
         }
         Tensor raw = at::empty({B, Cout, 2 * H, 2 * W}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
         const double flops = 2.0 * B * H * W * 16.0 * Cin * Cout;
+        int sums_done = 0;
+        TORCH_CHECK(!training || sums_ws.numel() == 2 * (int64_t)Cout * epi_bn_sum_copies(Cout), "deconv_bn_act: sums_ws must be [epi_bn_sum_copies(C)][2C]");
+        if (training) {             // the accumulator hand-over of bn_forward, done here because the GEMM epilogue may fill sums_ws
+            int* fl = flags.data_ptr<int>();
+            if (fl[0]) sums_ws.zero_();
+            fl[0] = 1;
+            fl[1] = 0;
+        }
         {
             Tensor& ws = workspace(epi_gemm_workspace_bytes(B * H * W, Cout, 4 * Cin, 4), x);
             ScopedTimer timer("head_deconv4x4s2_fwd", flops, 0.0, current_stream(x));
-            check(epi_deconv4x4s2_fwd(x.data_ptr(), w_phase.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(), (size_t)ws.numel(),
-                                      current_stream(x)), "epi_deconv4x4s2_fwd");
+            check(epi_deconv4x4s2_fwd_stats(x.data_ptr(), w_phase.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout,
+                                            training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(),
+                                            (size_t)ws.numel(), current_stream(x)), "epi_deconv4x4s2_fwd");
         }
         BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
         Tensor stats;
-        Tensor y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats);
+        Tensor y;
+        if (training && !sums_done) {       // the statistics pass runs separately; re-arm the flag protocol for bn_forward
+            flags.data_ptr<int>()[0] = 0;
+            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, false);
+        } else {
+            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, training);
+        }
         ctx->saved_data["training"] = training;
         if (training) {
             auto holder = c10::make_intrusive<SavedHolder>();

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "epi_gemm_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "epi_deconv4x4s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "epi_deconv4x4s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_fwd_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_conv2d_workspace_bytes": (_sz, [_i] * 9),
     "epi_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -512,8 +513,9 @@ def deconv_weight_forms(weight, w_phase=None):
     return w_phase, w            # w: logical [Cin, Cout, 4, 4], memory [Cin][16*Cout]
 
 
-def deconv4x4s2_fwd(x, w_phase):
-    """x [B, Cin, H, W] channels_last bf16 -> y [B, Cout, 2H, 2W] channels_last bf16 (raw ConvTranspose2d output)."""
+def deconv4x4s2_fwd(x, w_phase, bn_sums=None):
+    """x [B, Cin, H, W] channels_last bf16 -> y [B, Cout, 2H, 2W] channels_last bf16 (raw ConvTranspose2d output).  ``bn_sums`` (zeroed f32
+    [bn_sum_copies(Cout) * 2*Cout]): asks for the per-channel (sum, sum of squares) of the result from the GEMM epilogue; returns (y, done) then."""
     lib = load()
     x = _nhwc_bf16(x, "x")
     b, cin, h, w = x.shape
@@ -522,10 +524,12 @@ def deconv4x4s2_fwd(x, w_phase):
     ws = _workspace(lib.epi_gemm_workspace_bytes(b * h * w, cout, 4 * cin, 4), x.device)
     with _on(x.device):
         ev = timer.start("epi_deconv4x4s2_fwd")
-        _check(lib.epi_deconv4x4s2_fwd(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _ptr(ws), ws.numel(), _stream()),
+        done = ctypes.c_int(0)
+        _check(lib.epi_deconv4x4s2_fwd_stats(_ptr(x), _ptr(w_phase), _ptr(y), b, h, w, cin, cout, _ptr(bn_sums),
+                                             ctypes.addressof(done) if bn_sums is not None else None, _ptr(ws), ws.numel(), _stream()),
                "epi_deconv4x4s2_fwd")
         timer.stop(ev)
-    return y
+    return y if bn_sums is None else (y, bool(done.value))
 
 
 def deconv4x4s2_bwd_data(dy, w_bwd):

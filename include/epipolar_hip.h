@@ -188,6 +188,11 @@ int epi_deconv4x4s2_pack_fill_row(void* row_host, const void* w_cl, void* w_phas
  * workspace: epi_gemm_workspace_bytes(B*H*W, Cout, 4*Cin, 4). */
 int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
                         void* workspace, size_t workspace_bytes, epi_stream_t stream);
+/* The same with the BatchNorm batch sums of the result (cf. epi_conv2d_fwd): bn_sums [epi_bn_sum_copies(Cout)][2 Cout] f32 (zeroed by the
+ * caller) += per-channel (sum, sum of squares) of the bf16 outputs when the launch can do it from its epilogue (*stats_done = 1: the
+ * BatchNorm that follows needs no statistics pass), else left alone (*stats_done = 0).  Either pointer may be NULL. */
+int epi_deconv4x4s2_fwd_stats(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, float* bn_sums,
+                              int* stats_done, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 
 /* dx [B][H][W][Cin] from dy [B][2H][2W][Cout]: a 4x4 stride-2 implicit GEMM with K = 16*Cout.  Cout % 64 == 0.
  * workspace: epi_gemm_workspace_bytes(B*H*W, Cin, 16*Cout, 1). */

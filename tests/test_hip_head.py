@@ -291,3 +291,30 @@ def test_maxpool3x3s2_matches_torch(shape):
     yg = hip.glue().maxpool3x3s2(xg)
     yg.backward(dy)
     assert torch.equal(torch.nan_to_num(yg.float(), nan=12345.0), torch.nan_to_num(y.float(), nan=12345.0)) and torch.equal(xg.grad, dx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", [(32, 256, 256, 32), (32, 256, 256, 16), (8, 2048, 256, 8), (2, 64, 64, 8)], ids=lambda g: "b%d_%dto%d_h%d" % g)
+def test_deconv_fwd_fused_bn_statistics(geo):
+    """BatchNorm batch sums from the transposed convolution's epilogue (four output-parity phases in one launch): equal to the column
+    sums of the bf16 tensor it wrote; a launch that cannot do it (split-K) says so and leaves the accumulator alone."""
+    from epipolarpose_amd import hip
+    b, cin, cout, h = geo
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(b + cin + h)
+    x = torch.randn((b, cin, h, h), generator=gen).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cin, cout, 4, 4), generator=gen) * (1.0 / (4 * cin)) ** 0.5).to(dev)
+    wp, _ = hip.deconv_pack_weight(w)
+    sums = torch.zeros(hip.bn_sum_copies(cout) * 2 * cout, dtype=torch.float32, device=dev)
+    y, done = hip.deconv4x4s2_fwd(x, wp, bn_sums=sums)
+    assert torch.equal(y, hip.deconv4x4s2_fwd(x, wp))
+    sums = sums.view(-1, 2 * cout).sum(0)
+    if done:
+        yf = y.float()
+        s1, s2 = yf.sum(dim=(0, 2, 3)), (yf * yf).sum(dim=(0, 2, 3))
+        torch.testing.assert_close(sums[:cout], s1, rtol=2e-4, atol=2e-3 * float(yf.abs().max()) * (yf.numel() / cout) ** 0.5)
+        torch.testing.assert_close(sums[cout:], s2, rtol=2e-4, atol=1e-3 * max(1.0, float(s2.max())))
+    else:
+        assert float(sums.abs().max()) == 0.0
+    if geo[0] == 32 and h >= 16:
+        assert done                         # the two large head layers of the bench configuration take the fused path
