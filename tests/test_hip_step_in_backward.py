@@ -74,16 +74,22 @@ def test_step_in_backward_on_the_pose_network():
     a, _ = run(False)
     a2, _ = run(False)
     b, mb = run(True)
-    moved = 0
+    # Summed absolute differences over each PART of the network (the late part: stem + layer1, the early part: everything else): Adam moves
+    # every element by ~lr per step whatever its gradient, so single elements whose tiny gradient changes sign between two runs differ by
+    # up to 2 * steps * lr -- per-parameter maxima (and means over a 64-element BatchNorm weight) would measure that; a part that was NOT
+    # updated, or updated twice, differs by the whole step in (almost) every element
+    _, late_modules = base.step_in_backward_split()
+    late_names = {n for n, p_ in base.named_parameters() if any(p_ is q for m_ in late_modules for q in m_.parameters())}
+    start = {k: v.detach().float() for k, v in base.named_parameters()}
+    for part in ("late", "early"):
+        keys = [k for k in a if (k in late_names) == (part == "late")]
+        assert keys
+        diff = sum(float((a[k] - b[k]).abs().sum()) for k in keys)
+        noise = sum(float((a[k] - a2[k]).abs().sum()) for k in keys)
+        step = sum(float((a[k] - start[k]).abs().sum()) for k in keys)
+        assert step > 0 and diff <= 3.0 * noise + 0.1 * step, (part, diff, noise, step)
     for k in a:
-        noise = float((a[k] - a2[k]).abs().max())
-        diff = float((a[k] - b[k]).abs().max())
-        start = dict(base.named_parameters())[k].detach().float()
-        step = float((a[k] - start).abs().max())
-        moved += step > 0
-        assert diff <= 3.0 * noise + 0.05 * step + 1e-7, (k, diff, noise, step)     # a part that was not updated would differ by ~step
-        assert float((b[k] - start).abs().max()) > 0 or step == 0, k
-    assert moved >= len(a) - 2
+        assert float((b[k] - start[k]).abs().max()) > 0 or float((a[k] - start[k]).abs().max()) == 0, k
     # the bf16 training copies follow their masters
     for mod in mb.modules():
         if getattr(mod, "weight_lp", None) is not None:
