@@ -13,6 +13,7 @@
 #include <torch/extension.h>
 #include <torch/custom_class.h>
 #include <torch/csrc/autograd/engine.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
 #include <hip/hip_runtime_api.h>
@@ -109,9 +110,10 @@ Tensor& workspace(size_t bytes, const Tensor& like, int slot = 0) {      // slot
 // ---- weight gradients on a second stream ---------------------------------------------------------------------------
 // Nothing inside the backward pass waits for a weight gradient: the chain is BatchNorm backward -> backward-data -> the next layer's
 // BatchNorm backward, and the weight-gradient GEMMs (1.7 of the 8 ms step on ResNet-50 / batch 32, each one under-filling the chip)
-// only have to be complete when the optimizer runs.  With EPI_WGRAD_STREAM != 0 they are launched on a second HIP stream: fork = an
-// event recorded on the main stream after the layer's BatchNorm backward, join = the main stream waits once, at the end of the pass
-// (the engine's final callback, together with the deferred slab sums) or earlier when somebody consumes a gradient inside the pass.
+// only have to be complete when the optimizer runs.  With EPI_WGRAD_STREAM != 0 they are launched on a second HIP stream: fork = ONE
+// event per autograd node, recorded on the main stream when the node's own work has been enqueued (side_run_jobs), join = the main
+// stream waits once, at the end of the pass (the engine's final callback, together with the deferred slab sums) or earlier when
+// somebody consumes a gradient inside the pass.  State is per process (one process drives one GPU; nodes of a pass run one at a time).
 // The operands (x, dy) are kept alive until the join instead of being registered with the caching allocator's per-stream use list
 // (recordStream costs an event per tensor when it is freed; holding ~2x the activations for one backward pass costs nothing at 288 GB).
 struct SideStream {
@@ -177,6 +179,7 @@ hipStream_t side_fork(int dev, hipStream_t main_stream) {
     SideStream& S = g_side;
     const bool low = S.mode == 2;
     if (S.stream == nullptr || S.device != dev || S.low_priority != low) {
+        c10::hip::HIPGuard device_guard((c10::DeviceIndex)dev);          // the stream and its events belong to `dev`, whatever the caller's current device
         if (S.stream != nullptr && S.device == dev) side_join();           // priority class changed: drain, then replace the stream
         TORCH_CHECK(!S.dirty, "weight-gradient stream: pending work on another device");
         if (S.stream != nullptr) (void)hipStreamDestroy(S.stream);        // (destruction waits for the stream's work)
