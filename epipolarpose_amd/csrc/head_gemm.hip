@@ -1287,7 +1287,11 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (!out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
         const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);
-        if (want_stats && !a.bias) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
+        // BatchNorm statistics from THIS kernel's epilogue are off by default (EPI_FUSE_BN_STATS_ASTAT=1 turns them on): in the step trace the
+        // A-stationary launches with statistics take 39 / 37 us (K = 64 / 128) against 21 / 20 us without -- more than the separate statistics
+        // pass over their output costs (14 / 8 us); measured in the step, same box: 7.06 ms without, 7.13 ms with
+        static const bool astat_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS_ASTAT"); return e && e[0] == '1'; }();
+        if (want_stats && !a.bias && astat_stats) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
 #define EPI_ASTAT(KS)                                                                                                      \
         do {                                                                                                               \
             const size_t lds = AS_RING * (size_t)AS_BN * 32 * KS + AS_WAVES * 4096 + (size_t)((a.N + AS_BN - 1) / AS_BN) * AS_BN * 4 * 3;                                          \
