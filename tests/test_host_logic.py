@@ -154,3 +154,49 @@ def test_bucket_pack_variants_write_the_same_bytes():
     t = torch.arange(24.0).reshape(2, 3, 2, 2).contiguous(memory_format=torch.channels_last)
     assert torch.equal(epd._memory_order_flat(t), t.permute(0, 2, 3, 1).reshape(-1))
     assert epd._memory_order_flat(t[:, :2]) is None
+
+
+def test_step_in_backward_split_partitions_the_parameters():
+    """PoseResNet.step_in_backward_split (optim.FusedAdam.enable_step_in_backward): the late modules are exactly what runs before the
+    boundary's output in the forward pass -- stem + layer1 -- and hold ~1 % of the parameters; the helper is a no-op without the opt-in."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from epipolarpose_amd import optim
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    model = get_pose_net(cfg, is_train=False)
+    boundary, late = model.step_in_backward_split()
+    assert boundary is model.layer1 and late == [model.conv1, model.bn1, model.layer1]
+    n_late = sum(p.numel() for m in late for p in m.parameters())
+    n_all = sum(p.numel() for p in model.parameters())
+    assert 0 < n_late < 0.02 * n_all
+    assert optim.enable_step_in_backward(object(), model) is False             # EPI_STEP_IN_BACKWARD unset: nothing is switched on
+
+
+def test_trace_step_sequence_tool(tmp_path):
+    """tools/trace_step_sequence.py on a synthetic two-queue rocprofv3 kernel trace: window between two marker launches, per-queue gaps,
+    summed kernel time against the time with at least one kernel running."""
+    import subprocess
+    import sys
+    rows = ["Kind,Agent_Id,Queue_Id,Kernel_Name,Start_Timestamp,End_Timestamp,LDS_Block_Size,Workgroup_Size_X,Workgroup_Size_Y,Workgroup_Size_Z,"
+            "Grid_Size_X,Grid_Size_Y,Grid_Size_Z"]
+
+    def k(q, name, s, e, grid=256 * 4):
+        rows.append("KERNEL_DISPATCH,0,%d,%s,%d,%d,0,256,1,1,%d,1,1" % (q, name, s, e, grid))
+    t = 0
+    for step in range(3):
+        k(1, "marker_kernel(int)", t, t + 1000)
+        k(1, "void epi::a_kernel<1>(float*)", t + 1000, t + 5000)
+        k(2, "void epi::b_kernel(float*)", t + 3000, t + 9000)           # overlaps a_kernel by 2 us, runs alone for 4 us
+        k(1, "void epi::c_kernel(float*)", t + 10000, t + 12000)         # 5 us after a_kernel on queue 1
+        t += 20000
+    path = tmp_path / "trace.csv"
+    path.write_text("\n".join(rows) + "\n")
+    out = tmp_path / "seq.txt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "trace_step_sequence.py"), str(path), "marker_kernel", str(out), "-1"])
+    text = out.read_text().splitlines()
+    assert "4 launches" in text[0] and "0.013 ms summed kernel time" in text[0] and "0.011 ms with at least one kernel running" in text[0]
+    body = [l.split() for l in text[2:]]
+    assert [l[-1] for l in body] == ["a_kernel<1>", "b_kernel", "c_kernel", "marker_kernel"]
+    assert float(body[2][2]) == 5.0 and int(body[0][4]) == 4             # c_kernel's gap on its own queue; workgroups = grid / block
