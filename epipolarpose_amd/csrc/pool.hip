@@ -12,8 +12,9 @@
 namespace epi {
 
 // XCD-aware block order (8 XCDs with private L2s; the dispatcher places linear block b on XCD b % 8): every XCD gets a CONTIGUOUS range
-// of logical blocks, so the input rows that neighbouring output rows share are fetched into one L2 instead of two (PMC, first version:
-// the forward read x 1.5 times, the backward dy and the positions 2.1 times; profiles/r02_pmc_traffic_summary.csv)
+// of logical blocks, so the input rows that neighbouring output rows share are fetched into one L2 instead of two (PMC: the forward
+// read x 1.5 times and the backward dy + positions 2.1 times in linear block order, 1.02 and 1.00 times in this order;
+// profiles/r02_pmc_traffic_summary.csv, _b_pool_xcd_order.csv)
 __device__ __forceinline__ long long pool_block(long long lin, long long total) {
     const long long q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
