@@ -1827,6 +1827,15 @@ static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size
     return EPI_OK;
 }
 
+// The plan a weight-gradient launch of this shape would use (host only, no device work): plan[0] tile configuration (0: 128 x 128,
+// 1: 64 x 128, 2: 256 x 256), plan[1] output tiles, plan[2] reduction splits (= fp32 slabs), plan[3] rows per split.
+extern "C" int epi_gemm_tn_plan(int R, int I, int J, int ntap, long long* plan) {
+    if (!plan || R <= 0 || I <= 0 || J <= 0 || ntap <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    const TnPlan pl = tn_plan(R, I, J * ntap);
+    plan[0] = pl.cfg; plan[1] = pl.tiles; plan[2] = pl.nsplit; plan[3] = pl.rps;
+    return EPI_OK;
+}
+
 extern "C" size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap) {
     if (R <= 0 || I <= 0 || J <= 0 || ntap <= 0) return 0;
     const TnPlan pl = tn_plan(R, I, J * ntap);

@@ -65,6 +65,7 @@ _SIGNATURES = {
                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epi_gemm_tn_plan": (_i, [_i, _i, _i, _i, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_gemm_tn_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_deconv4x4s2_pack_phase_cl": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -571,6 +572,14 @@ def glue():
             raise RuntimeError("epipolarpose_amd: glue / library version mismatch (%s vs %s): rebuild" % (mod.abi_version(), ver))
         _glue = mod
     return _glue
+
+
+def gemm_tn_plan(r, i, j, ntap=1):
+    """The plan of a weight-gradient launch (host only): dict(cfg, tiles, nsplit, rows_per_split, slab_bytes)."""
+    plan = (ctypes.c_longlong * 4)()
+    _check(load().epi_gemm_tn_plan(r, i, j, ntap, plan), "epi_gemm_tn_plan")
+    return {"cfg": int(plan[0]), "tiles": int(plan[1]), "nsplit": int(plan[2]), "rows_per_split": int(plan[3]),
+            "slab_bytes": int(plan[2]) * i * j * ntap * 4 if plan[2] > 1 else 0}
 
 
 def gemm_tn_bf16(a, b):

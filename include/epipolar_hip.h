@@ -307,6 +307,9 @@ int epi_slab_reduce_multi(const EpiSlabReduce* rows_dev, int nrows, long long to
  *                                [Cin, Cout, 4, 4] weight -- from x [B][H][W][Cin], dy [B][2H][2W][Cout]
  *   epi_column_sums_bf16:        sums[2C] += per-column (sum, sum of squares) of x [R][C]  (bias gradient; zero it first) */
 size_t epi_gemm_tn_workspace_bytes(int R, int I, int J, int ntap);
+/* The plan behind that figure (host only, nothing is launched): plan[0] tile configuration (0: 128 x 128, 1: 64 x 128, 2: 256 x 256),
+ * plan[1] output tiles, plan[2] reduction splits (each writes one fp32 slab of the whole result), plan[3] rows per split. */
+int epi_gemm_tn_plan(int R, int I, int J, int ntap, long long* plan);
 int epi_gemm_tn_bf16(const void* A, int lda, const void* B, int ldb, float* C, int R, int I, int J,
                      void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_deconv4x4s2_bwd_weight(const void* x, const void* dy, void* dw_taps, int dw_dtype, int B, int H, int W, int Cin, int Cout,

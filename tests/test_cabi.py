@@ -115,3 +115,19 @@ def test_glue_calls_use_the_header_prototypes():
     src = open(os.path.join(ROOT, "epipolarpose_amd", "csrc", "torch_glue.cpp")).read()
     assert '#include "../../include/epipolar_hip.h"' in src
     assert not re.search(r'extern\s+"C"\s+int\s+epi_', src)
+
+
+def test_weight_gradient_plan_is_consistent_with_its_workspace():
+    """epi_gemm_tn_plan (host only): the slab workspace the library asks for is exactly splits x result x 4 bytes, a split covers whole
+    64-row reduction tiles and all splits together cover R; the deep layers of ResNet-50 at batch 32 as pinned examples."""
+    from epipolarpose_amd import hip
+    lib = hip.load()
+    for r, i, j, ntap in ((131072, 64, 64, 1), (131072, 64, 64, 9), (32768, 512, 128, 1), (8192, 256, 256, 9), (2048, 2048, 512, 1), (2048, 512, 512, 9),
+                          (131072, 1088, 256, 1), (8192, 2048, 256, 16), (512, 64, 64, 1)):
+        p = hip.gemm_tn_plan(r, i, j, ntap)
+        assert p["cfg"] in (0, 1, 2) and p["tiles"] >= 1 and p["nsplit"] >= 1
+        assert lib.epi_gemm_tn_workspace_bytes(r, i, j, ntap) == p["slab_bytes"]
+        assert p["rows_per_split"] % 64 == 0 and p["nsplit"] * p["rows_per_split"] >= r > (p["nsplit"] - 1) * p["rows_per_split"]
+        if i <= 64:
+            assert p["cfg"] == 1                     # the narrow tile serves the 64-channel layers
+    assert hip.gemm_tn_plan(2048, 512, 512, 9) == {"cfg": 0, "tiles": 144, "nsplit": 2, "rows_per_split": 1024, "slab_bytes": 2 * 512 * 4608 * 4}
