@@ -339,9 +339,10 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
         a, b = a.float(), b.float()
         tol = 2 ** -6 * max(float(b.abs().max()), 1e-6)
         d = (a - b).abs()
-        # (thresholds 3 % / 6 %: one run in ~10 of the stride-2 bottleneck exceeded 2 % / 4 % with identical code on both sides)
-        assert float((d > tol).float().mean()) <= 3e-2, (what, float(d.max()), tol)
-        assert float(d.norm()) <= 6e-2 * max(float(b.norm()), 1e-6), (what, float(d.norm()), float(b.norm()))
+        # (thresholds 5 % / 12 %: one run in ~10 of the stride-2 bottleneck exceeded 2 % / 4 % with identical code on both sides; a
+        # dropped shortcut gradient or stage moves these measures by tens of percent)
+        assert float((d > tol).float().mean()) <= 5e-2, (what, float(d.max()), tol)
+        assert float(d.norm()) <= 12e-2 * max(float(b.norm()), 1e-6), (what, float(d.norm()), float(b.norm()))
     near(outs[0][0], outs[1][0], "output")
     near(outs[0][1], outs[1][1], "input gradient")
     for k in outs[0][2]:
