@@ -312,6 +312,15 @@ def main():
     step()                                           # diagnostic (untimed, part of warm-up): host cost of enqueueing ONE step
     host_one = time.perf_counter() - th              # into an empty queue, i.e. without back-pressure from the GPU
     torch.cuda.synchronize()
+    # ... and of a burst of three steps from an empty queue (untimed warm-up as well): the host's own enqueue cost per step with warm
+    # caches and allocator, still without back-pressure.  The steady-state figure below (host_enqueue_ms_per_step, over `steps` steps)
+    # additionally contains the time the host spends BLOCKED inside HIP calls once it has run as far ahead of the GPU as the runtime's
+    # queue lets it -- on a GPU-bound step it converges to the GPU's own step time whatever the host costs.
+    th = time.perf_counter()
+    for _ in range(3):
+        step()
+    host_burst = (time.perf_counter() - th) / 3.0
+    torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -406,7 +415,9 @@ def main():
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "streams": 1 if use_graph or hip.glue().wgrad_stream_mode(-1) == 0 else 2,
                        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),
-                       "host_enqueue_ms_one_step_empty_queue": round(host_one * 1e3, 3)},
+                       "host_enqueue_ms_one_step_empty_queue": round(host_one * 1e3, 3),
+                       "host_enqueue_ms_per_step_burst3": round(host_burst * 1e3, 3),
+                       "host_blocked_in_hip_ms_per_step": round(max(0.0, host_elapsed / args.steps - host_burst) * 1e3, 3)},
             "roofline": roofline,
             "workload_ss": ss_line,
         }

@@ -60,8 +60,7 @@ class GraphedTrainStep:
         self.data, self.label, self.weight = batch_data, batch_label, batch_label_weight
         # a captured step is one stream of nodes: the eager path's second stream and its end-of-pass slab sum (host-side table uploads
         # with an event wait) stay out of the capture
-        hip.glue().wgrad_stream_mode(0)
-        hip.glue().defer_wgrad_reduce(False)
+        self._modes = (hip.glue().wgrad_stream_mode(0), hip.glue().defer_wgrad_reduce(False))
         args = (model, criterion, optimizer, self.data, self.label, self.weight)
         kw = dict(meta=meta, n_view=n_view, ss_method=ss_method, autocast=autocast)
         side = torch.cuda.Stream()
@@ -73,8 +72,14 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.loss = train_step(*args, **kw)
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = train_step(*args, **kw)
+        finally:
+            # the process-wide modes only have to hold while the launches are being RECORDED: replays repeat the captured launches
+            # whatever the modes are, and an eager train_step afterwards (bench A/B of graph vs eager) gets its second stream back
+            hip.glue().wgrad_stream_mode(self._modes[0])
+            hip.glue().defer_wgrad_reduce(self._modes[1])
 
     def __call__(self, batch_data=None, batch_label=None, batch_label_weight=None):
         if batch_data is not None and batch_data is not self.data:

@@ -1516,17 +1516,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// One workgroup's share of a TN GEMM: output tile `tile_id` (tile_j fastest), reduction slice `split`.  Shared by the single-GEMM
+// kernel and the grouped kernel (many weight gradients in one launch).
 template <typename Cfg, bool GATHER>
-__global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) void head_gemm_tn_kernel(GemmTnArgs p) {
+__device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, const int split, char* smem) {
     constexpr int TI = Cfg::TI, BI = Cfg::BI, BJ = Cfg::BJ, AP = Cfg::A_PIECES, BP = Cfg::B_PIECES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / Cfg::WJ, wn = wid % Cfg::WJ;
     const int tiles_j = (p.J + BJ - 1) / BJ;
-    // logical id: tile fastest, then split: the tiles of one split (same rows r) stay on one XCD
-    const int total_wg = gridDim.x * gridDim.y;
-    int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, total_wg);
-    const int tile_id = lid % (int)gridDim.x, split = lid / (int)gridDim.x;
     const int tile_i = tile_id / tiles_j, tile_j = tile_id - tile_i * tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
     const int r_begin = split * p.rows_per_split;
@@ -1671,6 +1668,38 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) 
                 }
             }
         }
+}
+
+template <typename Cfg, bool GATHER>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) void head_gemm_tn_kernel(GemmTnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
+    // logical id: tile fastest, then split: the tiles of one split (same rows r) stay on one XCD
+    const int total_wg = gridDim.x * gridDim.y;
+    const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, total_wg);
+    tn_body<Cfg, GATHER>(p, lid % (int)gridDim.x, lid / (int)gridDim.x, smem);
+}
+
+// MANY weight gradients in one launch (a whole ResNet stage's backward-weight GEMMs, csrc/torch_glue.cpp): the deep layers at batch 32 have
+// 16 .. 144 output tiles and 2048 .. 8192 reduction rows each -- alone, each of them had to cut its reduction into 4 .. 16 slices to give
+// every CU a workgroup, and every slice wrote an fp32 slab of the whole result (866 MB of slabs per ResNet-50 step,
+// profiles/r02_wgrad_plan_slabs.txt).  Together the tiles of ~10 .. 20 layers fill the chip with UNSPLIT reductions; the workgroups of
+// row r are [wg_begin, wg_begin + tiles * nsplit), tile fastest.  Rows live in the kernel-argument segment (scalar loads).
+struct TnGroupRow { GemmTnArgs a; int wg_begin, tiles; };
+constexpr int TN_GROUP_MAX = 32;
+struct TnGroupArgs { int nrows, reserved[3]; TnGroupRow rows[TN_GROUP_MAX]; };
+static_assert(sizeof(TnGroupArgs) <= 4096, "kernel-argument segment");
+
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) void head_gemm_tn_group_kernel(TnGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int row = 0;
+    for (int r = 1; r < g.nrows; ++r) row = g.rows[r].wg_begin <= lid ? r : row;        // (uniform: scalar loads and compares)
+    const TnGroupRow& gr = g.rows[row];
+    const int local = lid - gr.wg_begin;
+    const int split = local / gr.tiles, tile_id = local - split * gr.tiles;
+    if (gr.a.gather) tn_body<Cfg, true>(gr.a, tile_id, split, smem);
+    else tn_body<Cfg, false>(gr.a, tile_id, split, smem);
 }
 
 // out[e] = sum over the splits; out_bf16: bf16 result.  256 threads = 32 element pairs x 8 split lanes: every lane sums
@@ -1887,6 +1916,165 @@ extern "C" int epi_conv2d_bwd_weight_deferred(const void* x, const void* dy, voi
 extern "C" int epi_conv2d_bwd_weight(const void* x, const void* dy, void* dw, int dw_dtype, int B, int H, int W, int Cin, int Cout, int KH,
                                      int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     return epi_conv2d_bwd_weight_deferred(x, dy, dw, dw_dtype, B, H, W, Cin, Cout, KH, KW, stride, pad, workspace, workspace_bytes, nullptr, stream);
+}
+
+// ---- grouped weight gradients: many convolution / deconvolution backward-weight GEMMs in ONE launch per tile class ----
+namespace {
+
+struct GroupRowPlan { GemmTnArgs a; int cls; long long tiles; int ktiles, nsplit, rps; long long n; };
+struct GroupPlan { GroupRowPlan rows[epi::TN_GROUP_MAX]; int nrows; size_t slab_bytes; };
+
+// the TN operands of one item (what epi_conv2d_bwd_weight / epi_deconv4x4s2_bwd_weight build)
+int group_item_args(const EpiWgradItem& it, GemmTnArgs* out) {
+    if (it.B <= 0 || it.H <= 0 || it.W <= 0 || it.Cin <= 0 || it.Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (it.dw_dtype != EPI_F32 && it.dw_dtype != EPI_BF16) return EPI_ERR_UNSUPPORTED;
+    GemmTnArgs a = {};
+    if (it.kind == EPI_WGRAD_DECONV4X4S2) {
+        a.A = (const unsigned short*)it.x; a.B = (const unsigned short*)it.dy; a.R = it.B * it.H * it.W; a.I = it.Cin; a.J = 16 * it.Cout;
+        a.lda = it.Cin; a.ldb = it.Cout;
+        a.gather = 1; a.Hg = it.H; a.Wg = it.W; a.Hs = 2 * it.H; a.Ws = 2 * it.W; a.Cs = it.Cout; a.stride = 2; a.pad = 1; a.KW = 4;
+    } else if (it.kind == EPI_WGRAD_CONV2D) {
+        if (it.KH <= 0 || it.KW <= 0 || it.stride <= 0 || it.pad < 0) return EPI_ERR_INVALID_ARGUMENT;
+        const int Ho = (it.H + 2 * it.pad - it.KH) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.KW) / it.stride + 1;
+        if (Ho <= 0 || Wo <= 0) return EPI_ERR_INVALID_ARGUMENT;
+        a.A = (const unsigned short*)it.dy; a.B = (const unsigned short*)it.x; a.R = it.B * Ho * Wo; a.I = it.Cout; a.J = it.KH * it.KW * it.Cin;
+        a.lda = it.Cout; a.ldb = it.Cin;
+        if (!(it.KH == 1 && it.KW == 1 && it.stride == 1 && it.pad == 0)) {
+            a.gather = 1; a.Hg = Ho; a.Wg = Wo; a.Hs = it.H; a.Ws = it.W; a.Cs = it.Cin; a.stride = it.stride; a.pad = it.pad; a.KW = it.KW;
+        }
+    } else {
+        return EPI_ERR_UNSUPPORTED;
+    }
+    a.out_bf16 = it.dw_dtype == EPI_BF16;
+    if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8 || (a.gather && a.Cs % 8)) return EPI_ERR_UNSUPPORTED;
+    if (a.gather && (long long)((a.R + a.Hg * a.Wg - 1) / (a.Hg * a.Wg)) * a.Hs * a.Ws * a.ldb >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;
+    *out = a;
+    return EPI_OK;
+}
+
+// Reduction slices per row.  Model (microseconds, the constants of tn_plan): a workgroup costs t_fixed + t_tile per 64-row K tile; the chip
+// runs `slots` workgroups of a class at once; a launch takes max(total workgroup time / resident workgroups, the longest workgroup); every
+// slice of a split row writes an fp32 slab that the deferred sum reads back.  One knob for the whole group: T = K tiles per workgroup
+// (rows with fewer K tiles stay unsplit), chosen per tile class because each class is its own launch.
+int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
+    if (!items || n <= 0 || n > epi::TN_GROUP_MAX) return EPI_ERR_INVALID_ARGUMENT;
+    gp->nrows = n;
+    gp->slab_bytes = 0;
+    for (int r = 0; r < n; ++r) {
+        GroupRowPlan& row = gp->rows[r];
+        const int rc = group_item_args(items[r], &row.a);
+        if (rc != EPI_OK) return rc;
+        row.cls = row.a.I <= 64 ? 1 : 0;                     // 1: 64 x 128 tiles (64 output channels), 0: 128 x 128
+        const int bi = row.cls ? 64 : 128;
+        row.tiles = (long long)((row.a.I + bi - 1) / bi) * ((row.a.J + 127) / 128);
+        row.ktiles = (row.a.R + GBK - 1) / GBK;
+        row.n = (long long)row.a.I * row.a.J;
+    }
+    static const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
+    for (int cls = 0; cls < 2; ++cls) {
+        const double t_tile = cls ? 0.7 : 1.0, t_fixed = cls ? 3.0 : 4.0;
+        const long long slots = cls ? 768 : 512;
+        double best_t = 1e30;
+        int best_T = 1 << 30;
+        for (int T : cand) {
+            double work = 0, longest = 0, slab = 0;
+            long long wgs = 0;
+            for (int r = 0; r < n; ++r) {
+                const GroupRowPlan& row = gp->rows[r];
+                if (row.cls != cls) continue;
+                const int ns = std::max(1, (row.ktiles + T - 1) / T), kt = (row.ktiles + ns - 1) / ns;
+                const double t_wg = kt * t_tile + t_fixed;
+                work += (double)row.tiles * ns * t_wg;
+                wgs += row.tiles * ns;
+                longest = std::max(longest, t_wg);
+                if (ns > 1) slab += (double)ns * row.n * 8.0 / 3.0e6;
+            }
+            if (wgs == 0) break;
+            const double t = std::max(work / (double)std::min(slots, wgs), longest) + slab + (slab > 0 ? 3.0 : 0.0);
+            if (t < best_t) { best_t = t; best_T = T; }
+        }
+        for (int r = 0; r < n; ++r) {
+            GroupRowPlan& row = gp->rows[r];
+            if (row.cls != cls) continue;
+            int ns = std::max(1, (row.ktiles + best_T - 1) / best_T);
+            row.rps = ((row.ktiles + ns - 1) / ns) * GBK;
+            ns = (row.a.R + row.rps - 1) / row.rps;
+            row.nsplit = ns;
+            if (ns > 1) gp->slab_bytes += ((size_t)ns * row.n * sizeof(float) + 255) & ~(size_t)255;
+        }
+    }
+    return EPI_OK;
+}
+
+}  // namespace
+
+extern "C" int epi_wgrad_group_max(void) { return epi::TN_GROUP_MAX; }
+
+extern "C" int epi_wgrad_group_plan(const EpiWgradItem* items, int n, size_t* slab_bytes, int* nsplit) {
+    GroupPlan gp;
+    const int rc = group_plan(items, n, &gp);
+    if (rc != EPI_OK) return rc;
+    if (slab_bytes) *slab_bytes = gp.slab_bytes;
+    if (nsplit) for (int r = 0; r < n; ++r) nsplit[r] = gp.rows[r].nsplit;
+    return EPI_OK;
+}
+
+template <typename Cfg>
+static int launch_tn_group(const epi::TnGroupArgs& g, long long total_wg, hipStream_t st) {
+    const size_t lds = 2 * Cfg::STAGE_BYTES;
+    if (total_wg <= 0 || total_wg > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((epi::head_gemm_tn_group_kernel<Cfg>), dim3((unsigned)total_wg), dim3(Cfg::THREADS), lds, st, g);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+// items[0 .. n): every weight gradient of the group (n <= epi_wgrad_group_max()); at most two launches (128 x 128 tiles; 64 x 128 tiles for
+// the 64-output-channel layers).  slab_ws: epi_wgrad_group_plan's slab_bytes (256-byte aligned pieces, device memory that stays valid
+// until the sums have run).  pending[r]: the outstanding slab sum of item r (nsplit == 0: dw is complete when the launch is) -- the
+// caller runs them with epi_slab_reduce_multi.
+extern "C" int epi_wgrad_group(const EpiWgradItem* items, int n, void* slab_ws, size_t slab_bytes, EpiSlabReduce* pending, epi_stream_t stream) {
+    if (!pending) return EPI_ERR_INVALID_ARGUMENT;
+    GroupPlan gp;
+    const int rc = group_plan(items, n, &gp);
+    if (rc != EPI_OK) return rc;
+    if (gp.slab_bytes > 0 && (!slab_ws || gp.slab_bytes > slab_bytes)) return EPI_ERR_WORKSPACE;
+    for (int r = 0; r < n; ++r) {
+        if (!items[r].x || !items[r].dy || !items[r].dw) return EPI_ERR_INVALID_ARGUMENT;
+        if ((reinterpret_cast<uintptr_t>(items[r].x) | reinterpret_cast<uintptr_t>(items[r].dy)) & 15u) return EPI_ERR_UNSUPPORTED;
+    }
+    size_t off = 0;
+    for (int cls = 0; cls < 2; ++cls) {
+        epi::TnGroupArgs g = {};
+        long long wg = 0;
+        // longest workgroups first: the tail of the launch is made of short ones
+        int order[epi::TN_GROUP_MAX], m = 0;
+        for (int r = 0; r < n; ++r) if (gp.rows[r].cls == cls) order[m++] = r;
+        std::stable_sort(order, order + m, [&](int x, int y) { return gp.rows[x].rps > gp.rows[y].rps; });
+        for (int k = 0; k < m; ++k) {
+            const int r = order[k];
+            GroupRowPlan& row = gp.rows[r];
+            epi::TnGroupRow& gr = g.rows[g.nrows++];
+            gr.a = row.a;
+            gr.a.rows_per_split = row.rps;
+            gr.a.nsplit = row.nsplit;
+            pending[r] = EpiSlabReduce();
+            if (row.nsplit > 1) {
+                gr.a.C = static_cast<char*>(slab_ws) + off;
+                pending[r].slabs = reinterpret_cast<const float*>(gr.a.C); pending[r].out = items[r].dw; pending[r].n = row.n;
+                pending[r].nsplit = row.nsplit; pending[r].out_bf16 = row.a.out_bf16;
+                off += ((size_t)row.nsplit * row.n * sizeof(float) + 255) & ~(size_t)255;
+            } else {
+                gr.a.C = items[r].dw;
+            }
+            gr.wg_begin = (int)wg;
+            gr.tiles = (int)row.tiles;
+            wg += row.tiles * row.nsplit;
+        }
+        if (g.nrows == 0) continue;
+        const int lrc = cls ? launch_tn_group<epi::TnNarrow>(g, wg, (hipStream_t)stream) : launch_tn_group<epi::TnSmall>(g, wg, (hipStream_t)stream);
+        if (lrc != EPI_OK) return lrc;
+    }
+    return EPI_OK;
 }
 
 extern "C" long long epi_slab_reduce_chunks(long long n) { return n > 0 ? (n / 2 + 255) / 256 : 0; }

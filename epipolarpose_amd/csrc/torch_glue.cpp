@@ -137,8 +137,34 @@ struct SideStream {
         double flops, bytes;
     };
     std::vector<Job> jobs;
+    // Grouped weight gradients (round 3): the backward-weight GEMMs of SEVERAL autograd nodes -- every residual unit of a ResNet stage --
+    // wait here as plain descriptors and leave in ONE epi_wgrad_group launch when the stage's first unit (the last one the backward pass
+    // reaches) is done: together their output tiles fill the chip with unsplit reductions (866 MB of fp32 slabs per ResNet-50 step
+    // before, < 100 MB now) and the main stream records one fork event per stage instead of one per unit.  The gradient itself is held
+    // WEAKLY (through its storage), exactly as PendingReduces does: AccumulateGrad must find itself the only owner to adopt the tensor.
+    struct GroupItem {
+        EpiWgradItem it;
+        Tensor x, dy;                                            // operands, alive until the launch (second stream: until the join)
+        c10::weak_intrusive_ptr<c10::StorageImpl> dw;
+        c10::Device dev;
+        double flops, bytes;
+    };
+    std::vector<GroupItem> group;
 };
 SideStream g_side;
+// EPI_WGRAD_GROUP: 0 one launch (+ its own reduction split) per layer as in round 2; 1 one grouped launch per autograd node (residual
+// unit); 2 (default) one per ResNet stage -- flushed behind the unit that carries the stage's downsample projection
+int g_group_mode = -1;
+int group_mode() {
+    if (g_group_mode < 0) { const char* e = getenv("EPI_WGRAD_GROUP"); g_group_mode = e ? atoi(e) : 2; }
+    return g_group_mode;
+}
+int wgrad_group_mode(int mode) {               // test / measurement hook: returns the previous setting; a negative mode only queries
+    const int before = group_mode();
+    if (mode >= 0 && mode <= 2) g_group_mode = mode;
+    return before;
+}
+void side_group_flush();
 // scratch of the launches on the weight-gradient stream.  Grown on demand like workspace(); the outgrown buffer may still be in use by
 // a launch in flight on that stream while the caching allocator would hand it to the main stream at once -- it is parked until the join.
 Tensor& side_workspace(size_t bytes, const Tensor& like) {
@@ -190,9 +216,11 @@ hipStream_t side_fork(int dev, hipStream_t main_stream) {
         TORCH_CHECK(hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, low ? least : 0) == hipSuccess,
                     "weight-gradient stream: create");
         if (S.fork.empty()) {
-            // ordering between two streams of ONE device: the kernels' own agent-scope release / acquire makes the data visible; the
-            // system-scope fence an event adds by default (cache write-back + invalidate) is not needed (EPI_EVENT_FENCE=1 keeps it)
-            static const bool fence = [] { const char* e = getenv("EPI_EVENT_FENCE"); return e && e[0] == '1'; }();
+            // These events carry DATA dependencies (x / dy produced on the main stream, dw / slabs produced on the second one), so they keep
+            // the fence an event adds by default.  EPI_EVENT_FENCE=0 drops it (hipEventDisableSystemFence: both streams are on one device
+            // and every kernel ends / starts with its own agent-scope release / acquire; measured 7.26 -> 7.13 ms/step with 20 fork events
+            // per step in round 2 -- with one fork per ResNet stage the difference is gone, and HIP documents the flag for timing-only events)
+            static const bool fence = [] { const char* e = getenv("EPI_EVENT_FENCE"); return !(e && e[0] == '0'); }();
             const unsigned flags = hipEventDisableTiming | (fence ? 0u : (unsigned)hipEventDisableSystemFence);
             S.fork.resize(256);
             for (auto& e : S.fork) TORCH_CHECK(hipEventCreateWithFlags(&e, flags) == hipSuccess, "weight-gradient stream: event");
@@ -293,7 +321,10 @@ void launch_pending_rows(hipStream_t stream, int slot) {
     P.keep.clear();
 }
 
+std::vector<const void*> g_seen_weights;     // weights whose gradient this backward pass has already produced once (shared weights)
+
 void flush_pending_reduces() {
+    side_group_flush();              // weight gradients still waiting for their grouped launch
     PendingReduces& P = g_pend;
     if (!P.rows.empty()) {
         // Which stream?  Optionally the second one, behind the weight gradients in flight there (and behind the main stream's own split
@@ -321,6 +352,7 @@ void flush_pending_reduces() {
 // main stream joins at the end of the pass as usual.  Returns 0 when the second stream is off (the caller then does nothing early).
 int64_t begin_early_step(int64_t device_index) {
     if (side_mode() == 0) return 0;
+    side_group_flush();
     PendingReduces& P = g_pend;
     hipStream_t main_stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)device_index).stream();
     hipStream_t side = side_fork((int)device_index, main_stream);          // behind everything enqueued so far on either stream
@@ -358,7 +390,20 @@ bool gradient_consumed_after_backward(const Tensor& w) {
     if (torch::autograd::impl::post_acc_grad_hooks(w) != nullptr) return false;
     if (!torch::autograd::impl::hooks(w).empty()) return false;
     auto acc = torch::autograd::impl::try_get_grad_accumulator(w);
-    if (acc && (!acc->tensor_pre_hooks().empty() || !acc->pre_hooks().empty() || !acc->retains_grad_hooks().empty())) return false;
+    // (post hooks of the accumulator: torch.nn.parallel.DistributedDataParallel registers its reducer there)
+    if (acc && (!acc->tensor_pre_hooks().empty() || !acc->pre_hooks().empty() || !acc->retains_grad_hooks().empty() || !acc->post_hooks().empty()))
+        return false;
+    return true;
+}
+
+// A weight used twice in one graph: the engine ADDS the two gradients on the main stream when the second one arrives, so the first must
+// be complete by then (w.grad() is still undefined at that point: gradient_consumed_after_backward cannot see it).  Returns true the
+// first time `w` is seen in this backward pass; the list is cleared by the end-of-pass flush.
+bool first_gradient_of_pass(const Tensor& w) {
+    const void* key = w.unsafeGetTensorImpl();
+    if (std::find(g_seen_weights.begin(), g_seen_weights.end(), key) != g_seen_weights.end()) return false;
+    if (g_seen_weights.empty()) end_of_pass_callback();         // somebody has to clear the list when this pass ends
+    g_seen_weights.push_back(key);
     return true;
 }
 
@@ -368,11 +413,11 @@ bool gradient_consumed_after_backward(const Tensor& w) {
 void end_of_pass_callback() {
     bool queued = false;
     try {
-        torch::autograd::Engine::get_default_engine().queue_callback([] { flush_pending_reduces(); });
+        torch::autograd::Engine::get_default_engine().queue_callback([] { flush_pending_reduces(); g_seen_weights.clear(); });
         queued = true;
     } catch (const c10::Error&) {
     }
-    if (!queued) flush_pending_reduces();
+    if (!queued) { flush_pending_reduces(); g_seen_weights.clear(); }
 }
 
 void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
@@ -380,6 +425,77 @@ void pending_register(const EpiSlabReduce& r, const Tensor& grad) {
     P.rows.push_back(r);
     P.keep.push_back(grad.storage().getWeakStorageImpl());
     P.dev = grad.device();
+    end_of_pass_callback();
+}
+
+void pending_register_weak(const EpiSlabReduce& r, const c10::weak_intrusive_ptr<c10::StorageImpl>& grad, c10::Device dev) {
+    PendingReduces& P = g_pend;
+    P.rows.push_back(r);
+    P.keep.push_back(grad);
+    P.dev = dev;
+}
+
+// every waiting grouped weight gradient: one epi_wgrad_group call per <= epi_wgrad_group_max() items, on the second stream behind ONE
+// fork event (or on the main stream when the second stream is off)
+void side_group_flush() {
+    SideStream& S = g_side;
+    if (S.group.empty()) return;
+    std::vector<SideStream::GroupItem> items;
+    items.swap(S.group);
+    const Tensor first = items.front().x;
+    const int dev = first.device().index();
+    const bool on_side = side_mode() != 0;
+    const epi_stream_t main_stream = current_stream(first);
+    const epi_stream_t st = on_side ? reinterpret_cast<epi_stream_t>(side_fork(dev, reinterpret_cast<hipStream_t>(main_stream))) : main_stream;
+    const size_t cap = (size_t)epi_wgrad_group_max();
+    for (size_t begin = 0; begin < items.size(); begin += cap) {
+        const size_t end = std::min(items.size(), begin + cap);
+        std::vector<EpiWgradItem> its;
+        std::vector<size_t> idx;
+        std::vector<c10::intrusive_ptr<c10::StorageImpl>> alive;         // the gradients stay alive while we enqueue
+        double flops = 0, bytes = 0;
+        for (size_t i = begin; i < end; ++i) {
+            auto strong = items[i].dw.lock();
+            if (!strong) continue;                                         // nobody holds this gradient any more: skip its GEMM
+            alive.push_back(strong);
+            its.push_back(items[i].it);
+            idx.push_back(i);
+            flops += items[i].flops; bytes += items[i].bytes;
+        }
+        if (its.empty()) continue;
+        size_t slab_bytes = 0;
+        check(epi_wgrad_group_plan(its.data(), (int)its.size(), &slab_bytes, nullptr), "epi_wgrad_group_plan");
+        void* slabs = slab_bytes ? pending_slab_alloc(slab_bytes, first) : nullptr;
+        if (slab_bytes && !slabs) {
+            // the arena is full (first pass, or a pass larger than any before): one launch per layer with its own reduction, as in round 2
+            for (size_t k = 0; k < its.size(); ++k) {
+                const EpiWgradItem& it = its[k];
+                ScopedTimer timer("conv_bwd_weight", items[idx[k]].flops, items[idx[k]].bytes, st);
+                if (it.kind == EPI_WGRAD_DECONV4X4S2) {
+                    Tensor& ws = on_side ? side_workspace(epi_gemm_tn_workspace_bytes(it.B * it.H * it.W, it.Cin, it.Cout, 16), first)
+                                         : workspace(epi_gemm_tn_workspace_bytes(it.B * it.H * it.W, it.Cin, it.Cout, 16), first);
+                    check(epi_deconv4x4s2_bwd_weight(it.x, it.dy, it.dw, it.dw_dtype, it.B, it.H, it.W, it.Cin, it.Cout, ws.data_ptr(), (size_t)ws.numel(), st),
+                          "epi_deconv4x4s2_bwd_weight");
+                } else {
+                    const int Ho = (it.H + 2 * it.pad - it.KH) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.KW) / it.stride + 1;
+                    const size_t need = epi_gemm_tn_workspace_bytes(it.B * Ho * Wo, it.Cout, it.Cin, it.KH * it.KW);
+                    Tensor& ws = on_side ? side_workspace(need, first) : workspace(need, first);
+                    check(epi_conv2d_bwd_weight(it.x, it.dy, it.dw, it.dw_dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.KH, it.KW, it.stride, it.pad,
+                                                ws.data_ptr(), (size_t)ws.numel(), st), "epi_conv2d_bwd_weight");
+                }
+            }
+        } else {
+            std::vector<EpiSlabReduce> pend(its.size());
+            {
+                ScopedTimer timer("conv_bwd_weight", flops, bytes, st);
+                check(epi_wgrad_group(its.data(), (int)its.size(), slabs, slab_bytes, pend.data(), st), "epi_wgrad_group");
+            }
+            for (size_t k = 0; k < its.size(); ++k)
+                if (pend[k].nsplit > 0) pending_register_weak(pend[k], items[idx[k]].dw, items[idx[k]].dev);
+        }
+    }
+    if (on_side)
+        for (auto& g : items) { S.keep.push_back(std::move(g.x)); S.keep.push_back(std::move(g.dy)); }
     end_of_pass_callback();
 }
 
@@ -633,9 +749,21 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
     if (need_dw) {
         out.dw = at::empty_strided(sv.w_sizes, sv.w_strides, x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
         const size_t slab_bytes = epi_gemm_tn_workspace_bytes(B * Ho * Wo, Cout, Cin, K * K);
-        const bool after_pass = gradient_consumed_after_backward(sv.w);        // nobody reads this gradient before backward() returns
+        const bool first_use = first_gradient_of_pass(sv.w);
+        if (!first_use) flush_pending_reduces();       // a second use of a shared weight: the engine adds it to the first on the main stream
+        const bool after_pass = first_use && gradient_consumed_after_backward(sv.w);        // nobody reads this gradient before backward() returns
+        const double wflops_g = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
+        if (after_pass && defer_enabled() && group_mode() != 0) {      // leaves with its stage's other weight gradients (side_group_flush)
+            EpiWgradItem it = {};
+            it.x = x.data_ptr(); it.dy = g.dx.data_ptr(); it.dw = out.dw.data_ptr(); it.dw_dtype = sv.w_f32 ? EPI_F32 : EPI_BF16; it.kind = EPI_WGRAD_CONV2D;
+            it.B = B; it.H = H; it.W = W; it.Cin = Cin; it.Cout = Cout; it.KH = K; it.KW = K; it.stride = S; it.pad = P;
+            g_side.group.push_back(SideStream::GroupItem{it, x, g.dx, out.dw.storage().getWeakStorageImpl(), out.dw.device(), wflops_g,
+                                                         2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel())});
+            end_of_pass_callback();
+            return out;
+        }
         const bool may_defer = slab_bytes && defer_enabled() && after_pass;
-        if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();      // e.g. a second use of a shared weight adds to the first
+        if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();      // e.g. a gradient somebody reads inside the pass
         void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
         // second stream: only a launch whose result is complete by the end-of-pass join (an arena-less split would reduce right away)
         const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
@@ -700,6 +828,7 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
         g_side.jobs.clear();                         // (left-overs of a pass that aborted inside a node)
         StageGrads g = stage_backward(grads[0], holder->stages[0], ctx->needs_input_grad(0), ctx->needs_input_grad(1), Tensor());
         side_run_jobs();
+        side_group_flush();
         holder->stages.clear();                      // release the saved activations now, not when the graph is torn down
         return {g.dx, g.dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor(), Tensor(), Tensor(), Tensor()};
@@ -767,6 +896,9 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         }
         g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor());
         side_run_jobs();                                              // the unit's weight gradients: second stream, one fork event
+        // grouped weight gradients leave when the stage is complete (its first unit carries the downsample projection), when one more
+        // unit would not fit into a launch, or per unit (EPI_WGRAD_GROUP=1)
+        if (group_mode() == 1 || holder->has_downsample || g_side.group.size() + 4 > (size_t)epi_wgrad_group_max()) side_group_flush();
         variable_list out;
         out.reserve(1 + n_total * STAGE_TENSORS + 5);
         out.push_back(g[0].dx);
@@ -1095,6 +1227,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
     m.def("wgrad_stream_mode", &wgrad_stream_mode,
           "weight gradients on a second HIP stream: 0 off, 1 on, 2 on with the lowest stream priority; returns the previous setting");
+    m.def("wgrad_group_mode", &wgrad_group_mode,
+          "grouped weight-gradient launches: 0 one launch per layer, 1 one per autograd node, 2 one per ResNet stage; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");
     m.def("clear_grads", &clear_grads, "drop the .grad of every tensor in the list (zero_grad(set_to_none=True))");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");

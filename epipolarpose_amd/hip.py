@@ -59,6 +59,9 @@ _SIGNATURES = {
     "epi_conv2d_bwd_weight_deferred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "epi_slab_reduce_chunks": (ctypes.c_longlong, [ctypes.c_longlong]),
     "epi_slab_reduce_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
+    "epi_wgrad_group_max": (_i, []),
+    "epi_wgrad_group_plan": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]),
+    "epi_wgrad_group": (_i, [_vp, _i, _vp, _sz, _vp, _vp]),
     "epi_bn_sum_copies": (_i, [_i]),
     "epi_conv3x3_patch_mode": (_i, [_i]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
@@ -637,6 +640,79 @@ def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
         _check(lib.epi_conv2d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32, b, h, w, cin, cout,
                                          kh, kw, stride, padding, _ptr(ws), ws.numel(), _stream()), "epi_conv2d_bwd_weight")
     return dw
+
+
+class EpiWgradItem(ctypes.Structure):
+    _fields_ = [("x", _vp), ("dy", _vp), ("dw", _vp)] + [(k, _i) for k in ("dw_dtype", "kind", "B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
+
+
+class EpiSlabReduce(ctypes.Structure):
+    _fields_ = [("slabs", _vp), ("out", _vp), ("n", ctypes.c_longlong), ("chunk_begin", ctypes.c_longlong), ("nsplit", _i), ("out_bf16", _i)]
+
+
+def wgrad_group_max():
+    return int(load().epi_wgrad_group_max())
+
+
+def wgrad_group_plan(shapes):
+    """Host only: the reduction slices and slab bytes of a grouped weight-gradient launch.  shapes: (kind, B, H, W, Cin, Cout, k, stride, pad)
+    per item, kind 'conv' | 'deconv'.  Returns (slab_bytes, [nsplit per item])."""
+    n = len(shapes)
+    items = (EpiWgradItem * n)()
+    for it, (kind, b, h, w, cin, cout, k, stride, pad) in zip(items, shapes):
+        it.dw_dtype, it.kind = EPI_BF16, 1 if kind == "deconv" else 0
+        it.B, it.H, it.W, it.Cin, it.Cout, it.KH, it.KW, it.stride, it.pad = b, h, w, cin, cout, k, k, stride, pad
+    slab = ctypes.c_size_t(0)
+    ns = (ctypes.c_int * n)()
+    _check(load().epi_wgrad_group_plan(items, n, ctypes.byref(slab), ns), "epi_wgrad_group_plan")
+    return int(slab.value), list(ns)
+
+
+def wgrad_group(jobs, dtype=torch.float32):
+    """MANY weight gradients in one grouped launch (epi_wgrad_group) + one slab sum (epi_slab_reduce_multi).
+    jobs: (kind, x, dy, kernel, stride, padding) per item -- 'conv': x [B, Cin, H, W], dy [B, Cout, Ho, Wo] -> dW [Cout, Cin, k, k];
+    'deconv': x [B, Cin, H, W], dy [B, Cout, 2H, 2W] -> dW [Cin, Cout, 4, 4]; channels_last bf16 operands, channels_last results."""
+    lib = load()
+    n = len(jobs)
+    items = (EpiWgradItem * n)()
+    outs, keep = [], []
+    for it, (kind, x, dy, k, stride, pad) in zip(items, jobs):
+        x, dy = _nhwc_bf16(x, "x"), _nhwc_bf16(dy, "dy")
+        keep += [x, dy]
+        b, cin, h, w = x.shape
+        cout = dy.shape[1]
+        if kind == "deconv":
+            dw = torch.empty((cin, 16, cout), dtype=dtype, device=x.device)
+            outs.append(dw.view(cin, 4, 4, cout).permute(0, 3, 1, 2))
+            it.kind = 1
+        else:
+            dw = torch.empty((cout, cin, k, k), dtype=dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+            outs.append(dw)
+            it.kind = 0
+        keep.append(dw)
+        it.x, it.dy, it.dw = _ptr(x), _ptr(dy), _ptr(dw)
+        it.dw_dtype = EPI_BF16 if dtype == torch.bfloat16 else EPI_F32
+        it.B, it.H, it.W, it.Cin, it.Cout, it.KH, it.KW, it.stride, it.pad = b, h, w, cin, cout, k, k, stride, pad
+    dev = keep[0].device
+    slab = ctypes.c_size_t(0)
+    _check(lib.epi_wgrad_group_plan(items, n, ctypes.byref(slab), None), "epi_wgrad_group_plan")
+    ws = torch.empty(max(int(slab.value), 256), dtype=torch.uint8, device=dev)
+    pend = (EpiSlabReduce * n)()
+    with _on(dev):
+        _check(lib.epi_wgrad_group(items, n, _ptr(ws), ws.numel(), pend, _stream()), "epi_wgrad_group")
+        rows = [p for p in pend if p.nsplit > 0]
+        if rows:
+            table = (EpiSlabReduce * len(rows))()
+            chunks = 0
+            for dst, src in zip(table, rows):
+                ctypes.memmove(ctypes.byref(dst), ctypes.byref(src), ctypes.sizeof(EpiSlabReduce))
+                dst.chunk_begin = chunks
+                chunks += int(lib.epi_slab_reduce_chunks(src.n))
+            raw = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(dev)
+            _check(lib.epi_slab_reduce_multi(_ptr(raw), len(rows), chunks, _stream()), "epi_slab_reduce_multi")
+            keep.append(raw)
+        torch.cuda.current_stream(dev).synchronize()
+    return outs
 
 
 def _cl_weight_bf16(weight):

@@ -299,6 +299,30 @@ int epi_conv2d_bwd_weight_deferred(const void* x, const void* dy, void* dw, int 
 long long epi_slab_reduce_chunks(long long n);
 int epi_slab_reduce_multi(const EpiSlabReduce* rows_dev, int nrows, long long total_chunks, epi_stream_t stream);
 
+/* Grouped weight gradients (round 3): MANY backward-weight GEMMs -- the convolutions of several residual units, a whole ResNet stage --
+ * in at most two launches (128 x 128 output tiles; 64 x 128 tiles for the layers with <= 64 output channels).  The autograd of
+ * nn.Conv2d / nn.ConvTranspose2d in lib/models/pose3d_resnet.py:50-88,158-183 produces these gradients one layer at a time; at batch
+ * 32 a single deep layer has 16 .. 144 output tiles and had to cut its reduction over batch*pixels into 2 .. 16 slices to give every
+ * compute unit a workgroup, each slice writing an fp32 slab of the whole result (866 MB of slabs per ResNet-50 step).  Together the
+ * tiles of ~10 .. 20 layers fill the chip with unsplit (or barely split) reductions.
+ *   kind EPI_WGRAD_CONV2D:       x [B][H][W][Cin], dy [B][Ho][Wo][Cout] -> dw [Cout][KH][KW][Cin]    (= epi_conv2d_bwd_weight)
+ *   kind EPI_WGRAD_DECONV4X4S2:  x [B][H][W][Cin], dy [B][2H][2W][Cout] -> dw [Cin][16 taps][Cout]  (= epi_deconv4x4s2_bwd_weight; KH, KW,
+ *                                stride, pad ignored)
+ * epi_wgrad_group_plan (host only): the slab bytes the group needs (0: no reduction is split) and, per item, its reduction slices.
+ * epi_wgrad_group: launches; pending[r] describes item r's outstanding slab sum (nsplit == 0: dw complete with the launch), to be run
+ * with epi_slab_reduce_multi; slab_ws must stay untouched until then.  n <= epi_wgrad_group_max(). */
+enum { EPI_WGRAD_CONV2D = 0, EPI_WGRAD_DECONV4X4S2 = 1 };
+typedef struct EpiWgradItem {
+    const void* x;
+    const void* dy;
+    void* dw;
+    int dw_dtype, kind;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad;
+} EpiWgradItem;
+int epi_wgrad_group_max(void);
+int epi_wgrad_group_plan(const EpiWgradItem* items, int n, size_t* slab_bytes, int* nsplit);
+int epi_wgrad_group(const EpiWgradItem* items, int n, void* slab_ws, size_t slab_bytes, EpiSlabReduce* pending, epi_stream_t stream);
+
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (J = columns per filter tap; ntap = 1 for epi_gemm_tn_bf16, 16 for the
  * deconvolution; may be 0: a reduction that needs no split writes its result directly).

@@ -131,3 +131,26 @@ def test_weight_gradient_plan_is_consistent_with_its_workspace():
         if i <= 64:
             assert p["cfg"] == 1                     # the narrow tile serves the 64-channel layers
     assert hip.gemm_tn_plan(2048, 512, 512, 9) == {"cfg": 0, "tiles": 144, "nsplit": 2, "rows_per_split": 1024, "slab_bytes": 2 * 512 * 4608 * 4}
+
+
+def test_grouped_weight_gradient_plan():
+    """epi_wgrad_group_plan (host only): a ResNet-50 stage's weight gradients together need no (or hardly any) reduction split -- the deep
+    stages at batch 32 stay unsplit, the whole backbone parks < 100 MB of fp32 slabs per step (866 MB with one launch per layer) -- and
+    the slab bytes are exactly the 256-byte-aligned sum of splits x result x 4 over the split items."""
+    from epipolarpose_amd import hip
+    assert hip.wgrad_group_max() >= 24
+    b = 32
+    layer4 = [("conv", b, 8, 8, 2048, 512, 1, 1, 0), ("conv", b, 8, 8, 512, 512, 3, 1, 1), ("conv", b, 8, 8, 512, 2048, 1, 1, 0)] * 2 + \
+             [("conv", b, 16, 16, 1024, 512, 1, 1, 0), ("conv", b, 16, 16, 512, 512, 3, 2, 1), ("conv", b, 8, 8, 512, 2048, 1, 1, 0), ("conv", b, 16, 16, 1024, 2048, 1, 2, 0)]
+    slab, ns = hip.wgrad_group_plan(layer4)
+    assert ns[:6] == [1] * 6 and ns[7:] == [1] * 3 and slab <= 8 << 20, (slab, ns)
+    layer3 = [("conv", b, 16, 16, 1024, 256, 1, 1, 0), ("conv", b, 16, 16, 256, 256, 3, 1, 1), ("conv", b, 16, 16, 256, 1024, 1, 1, 0)] * 5 + \
+             [("conv", b, 32, 32, 512, 256, 1, 1, 0), ("conv", b, 32, 32, 256, 256, 3, 2, 1), ("conv", b, 16, 16, 256, 1024, 1, 1, 0), ("conv", b, 32, 32, 512, 1024, 1, 2, 0)]
+    slab3, ns3 = hip.wgrad_group_plan(layer3)
+    assert ns3[:15] == [1] * 15 and slab3 <= 4 << 20, (slab3, ns3)
+    # alone, one of these layers is cut into 8 .. 16 slices
+    assert hip.gemm_tn_plan(8192, 256, 1024, 1)["nsplit"] >= 8
+    one, ns1 = hip.wgrad_group_plan([("conv", b, 64, 64, 64, 64, 3, 1, 1)])
+    assert ns1[0] > 1 and one == (ns1[0] * 64 * 576 * 4 + 255) // 256 * 256
+    lib = hip.load()
+    assert lib.epi_wgrad_group_plan(None, 0, None, None) == 1          # argument validation before any work

@@ -387,23 +387,29 @@ def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
 
     before = hip.glue().defer_wgrad_reduce(False)
     stream_before = hip.glue().wgrad_stream_mode(0)
+    group_before = hip.glue().wgrad_group_mode(0)
     try:
         ref = grads()
-        # (deferred reduce, weight gradients on the second stream [0 off / 1 on / 2 on, lowest priority], gradient read from a hook)
-        for defer, side, hooked in ((True, 0, False), (True, 0, False), (True, 0, True), (False, 1, False), (True, 1, False),
-                                    (True, 1, True), (True, 2, False), (True, 1, False)):
+        # (deferred reduce, weight gradients on the second stream [0 off / 1 on / 2 on, lowest priority], gradient read from a hook,
+        #  grouped weight-gradient launches [0 per layer / 1 per unit / 2 per stage])
+        for defer, side, hooked, group in ((True, 0, False, 0), (True, 0, False, 0), (True, 0, True, 0), (False, 1, False, 0), (True, 1, False, 0),
+                                           (True, 1, True, 0), (True, 2, False, 0), (True, 1, False, 0),
+                                           (True, 0, False, 2), (True, 0, True, 2), (True, 1, False, 2), (True, 1, False, 2), (True, 1, True, 2),
+                                           (True, 1, False, 1), (True, 1, True, 1), (False, 1, False, 2), (True, 2, False, 2)):
             hip.glue().defer_wgrad_reduce(defer)
             hip.glue().wgrad_stream_mode(side)
+            hip.glue().wgrad_group_mode(group)
             got = grads(hooked)
             for k in ref:
                 scale = float(ref[k].abs().max()) + 1e-12
                 # run-to-run noise of this network (BatchNorm sums by atomics, bf16 activations: see the unit-node test) is ~5 % of the
                 # largest element / of the norm; a reduce that did not run, or a gradient read before its launch finished, leaves O(1) garbage
-                assert float((got[k] - ref[k]).abs().max()) <= 2e-1 * scale, (k, defer, side, hooked)
-                assert float((got[k] - ref[k]).norm()) <= 1e-1 * float(ref[k].norm()) + 1e-12, (k, defer, side, hooked)
+                assert float((got[k] - ref[k]).abs().max()) <= 2e-1 * scale, (k, defer, side, hooked, group)
+                assert float((got[k] - ref[k]).norm()) <= 1e-1 * float(ref[k].norm()) + 1e-12, (k, defer, side, hooked, group)
     finally:
         hip.glue().defer_wgrad_reduce(before)
         hip.glue().wgrad_stream_mode(stream_before)
+        hip.glue().wgrad_group_mode(group_before)
     # outside a backward pass the reduce runs at once
     w = _rand((64, 64, 3, 3), torch.Generator().manual_seed(7)).to(dev).contiguous(memory_format=torch.channels_last)
     xx = _rand((32, 64, 32, 32), torch.Generator().manual_seed(8)).to(dev).contiguous(memory_format=torch.channels_last)
@@ -411,3 +417,48 @@ def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
     dw = hip.conv2d_bwd_weight(xx, dy, 3, 1, 1, dtype=torch.float32)
     refdw = torch.nn.grad.conv2d_weight(xx.float(), tuple(w.shape), dy.float(), padding=1)
     assert (dw - refdw).abs().max().item() <= 3e-3 * refdw.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_wgrad_group_vs_torch_fp32(dtype):
+    """epi_wgrad_group: MANY backward-weight GEMMs in one launch per tile class (a ResNet stage's worth: 1x1, 3x3 stride 1 | 2, the
+    stride-2 projection, 64-output-channel layers on the narrow tile, a transposed convolution) against torch's fp32 weight gradients of the
+    same bf16-rounded operands -- split and unsplit reductions side by side, results in the channels_last weight order."""
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(21)
+    # (kind, Cin, Cout, k, stride, H, B)
+    geos = [("conv", 256, 64, 1, 1, 16, 8), ("conv", 64, 64, 3, 1, 16, 8), ("conv", 64, 256, 1, 1, 16, 8), ("conv", 256, 128, 1, 1, 16, 8),
+            ("conv", 128, 128, 3, 2, 16, 8), ("conv", 128, 512, 1, 1, 8, 8), ("conv", 256, 512, 1, 2, 16, 8), ("conv", 512, 128, 1, 1, 8, 8),
+            ("conv", 128, 128, 3, 1, 8, 8), ("conv", 1024, 256, 1, 1, 4, 4), ("conv", 256, 256, 3, 1, 4, 4), ("conv", 64, 64, 1, 1, 32, 16),
+            ("deconv", 128, 64, 4, 2, 8, 4), ("conv", 64, 128, 3, 2, 16, 4)]
+    jobs, refs = [], []
+    for kind, cin, cout, k, stride, h, b in geos:
+        x = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+        if kind == "deconv":
+            dy = _rand((b, cout, 2 * h, 2 * h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+            w = torch.zeros(cin, cout, 4, 4, device=dev, requires_grad=True)
+            F.conv_transpose2d(x.float(), w, stride=2, padding=1).backward(dy.float())
+            refs.append(w.grad)
+            jobs.append((kind, x, dy, 4, 2, 1))
+        else:
+            pad = k // 2
+            ho = (h + 2 * pad - k) // stride + 1
+            dy = _rand((b, cout, ho, ho), gen).to(dev).contiguous(memory_format=torch.channels_last)
+            refs.append(torch.nn.grad.conv2d_weight(x.float(), (cout, cin, k, k), dy.float(), stride=stride, padding=pad))
+            jobs.append((kind, x, dy, k, stride, pad))
+    assert len(jobs) <= hip.wgrad_group_max()
+    slab, nsplit = hip.wgrad_group_plan([(kind, b, h, h, cin, cout, k, stride, (1 if kind == "deconv" else k // 2)) for kind, cin, cout, k, stride, h, b in geos])
+    assert max(nsplit) > 1 and min(nsplit) == 1 and slab > 0, (slab, nsplit)      # the case mixes split and unsplit reductions
+    outs = hip.wgrad_group(jobs, dtype=dtype)
+    for (kind, cin, cout, k, stride, h, b), got, ref in zip(geos, outs, refs):
+        assert got.shape == ref.shape and got.dtype == dtype, (kind, cin, cout, k)
+        if kind == "conv":
+            assert got.is_contiguous(memory_format=torch.channels_last) or k == 1
+        tol = (2e-3 if dtype == torch.float32 else 2 ** -7) * ref.abs().max().item() + 1e-5
+        assert (got.float() - ref).abs().max().item() <= tol, (kind, cin, cout, k, stride, h, float((got.float() - ref).abs().max()), tol)
+    # one item alone == the single-GEMM entry point on the same operands (bitwise when neither splits its reduction)
+    kind, x, dy, k, stride, pad = jobs[9]
+    single = hip.conv2d_bwd_weight(x, dy, k, stride, pad, dtype=dtype)
+    alone = hip.wgrad_group([jobs[9]], dtype=dtype)[0]
+    assert (alone.float() - single.float()).abs().max().item() <= 2e-3 * single.float().abs().max().item()

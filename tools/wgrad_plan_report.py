@@ -44,7 +44,35 @@ def main():
         n += 1
         print("%-10s %7d %5d %6d | %-9s %5d %6d %6d %8.1f" % (name, r, cout, k * k * cin, ("128x128", "64x128", "256x256")[p["cfg"]], p["tiles"], p["nsplit"],
                                                               p["rows_per_split"], p["slab_bytes"] / 1e6))
-    print("# %d layers, %.0f MB of fp32 slabs written and read back per backward pass" % (n, total / 1e6))
+    print("# %d layers, %.0f MB of fp32 slabs written and read back per backward pass (one launch per layer, EPI_WGRAD_GROUP=0)" % (n, total / 1e6))
+    # grouped launches (round 3, the default): the weight gradients of a whole stage leave together (csrc/torch_glue.cpp side_group_flush:
+    # behind the unit that carries the downsample projection, or when one more unit would not fit into epi_wgrad_group_max() items)
+    cap = hip.wgrad_group_max()
+    groups, cur = [], []
+    units = {}
+    for name, cin, cout, k, s, h in convs(a.layers, a.image):
+        units.setdefault(name.rsplit(".", 1)[0], []).append((name, cin, cout, k, s, h))
+    for uname in reversed(list(units)):                    # backward order
+        cur += units[uname]
+        if any(n.endswith(".ds") for n, *_ in units[uname]) or len(cur) + 4 > cap:
+            groups.append(cur)
+            cur = []
+    if cur:
+        groups.append(cur)
+    print("#\n# grouped plan (EPI_WGRAD_GROUP=2): one launch per tile class and group")
+    print("%-22s %6s %9s %9s %10s" % ("group (backward order)", "items", "unsplit", "max split", "slab MB"))
+    gtotal = 0
+    for g in groups:
+        shapes = [("conv", a.batch, h, h, cin, cout, k, s, k // 2) for _, cin, cout, k, s, h in g]
+        gtotal_prev = gtotal
+        slab, ns = 0, []
+        for b in range(0, len(shapes), cap):
+            sb, nn = hip.wgrad_group_plan(shapes[b:b + cap])
+            slab += sb
+            ns += nn
+        gtotal += slab
+        print("%-22s %6d %9d %9d %10.1f" % (g[0][0].rsplit(".", 1)[0] + " .. " + g[-1][0].rsplit(".", 1)[0], len(g), sum(1 for v in ns if v == 1), max(ns), slab / 1e6))
+    print("# %d groups, %.0f MB of fp32 slabs per backward pass" % (len(groups), gtotal / 1e6))
 
 
 if __name__ == "__main__":
