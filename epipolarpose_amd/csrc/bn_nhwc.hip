@@ -24,60 +24,60 @@ enum { BN_MASK_NONE = 0, BN_MASK_FROM_X = 1, BN_MASK_FROM_Y = 2 };
 // blockIdx.y = row block.  256 threads = 8 channel groups x 32 row lanes, four rows in flight per lane.  Each workgroup
 // ends with 128 fp32 atomics (64 channels x 2 sums); the partition keeps the total number of atomics per tensor ~64 K
 // whatever the shape (C = 64, R = 524 288 ... C = 2048, R = 2048).
-constexpr int BN_SLAB = 64;                 // channels per slab
+constexpr int BN_SLAB = 64;                 // channels per slab (bf16 storage; 32 with the fp32 storage of the fp32-grade mode)
 constexpr int BN_RLANES = BN_THREADS / 8;   // 32 row lanes
 
-__device__ __forceinline__ void slab_reduce_and_add(const float (&s)[8], const float (&q)[8], int g, int rl, int slab, int C,
-                                                    float* __restrict__ sums, float* red /* [32][128] */) {
+// Storage type T: unsigned short = bf16 (the training path) or float (the fp32-grade verification mode, models/precise.py: the same
+// kernels, 16 bytes = 4 channels per lane instead of 8).  V = channels per lane, SLAB = 8 V channels per workgroup column.
+template <int V>
+__device__ __forceinline__ void slab_reduce_and_add(const float (&s)[V], const float (&q)[V], int g, int rl, int slab, int C,
+                                                    float* __restrict__ sums, float* red /* [32][16 V] */) {
+    constexpr int SLAB = 8 * V;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { red[rl * 128 + g * 8 + k] = s[k]; red[rl * 128 + 64 + g * 8 + k] = q[k]; }
+    for (int k = 0; k < V; ++k) { red[rl * (2 * SLAB) + g * V + k] = s[k]; red[rl * (2 * SLAB) + SLAB + g * V + k] = q[k]; }
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 2 * SLAB) {
         float t = 0.f;
 #pragma unroll 8
-        for (int l = 0; l < BN_RLANES; ++l) t += red[l * 128 + threadIdx.x];
-        const int which = threadIdx.x >> 6, ch = slab * BN_SLAB + (threadIdx.x & 63);
+        for (int l = 0; l < BN_RLANES; ++l) t += red[l * (2 * SLAB) + threadIdx.x];
+        const int which = threadIdx.x / SLAB, ch = slab * SLAB + (threadIdx.x % SLAB);
         if (ch < C) atomicAdd(sums + which * C + ch, t);
     }
 }
 
 // sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)
 // (ncopies accumulator copies [ncopies][2C], row block b adds into copy b % ncopies: fewer atomics per 128-byte line; 1 = plain [2C])
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const unsigned short* __restrict__ x, long long R, int C,
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long long R, int C,
                                                               int rows_per_wg, float* __restrict__ sums, int ncopies) {
-    __shared__ float red[BN_RLANES * 128];
+    constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
+    __shared__ float red[BN_RLANES * 2 * SLAB];
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
-    const int ch0 = slab * BN_SLAB + g * 8;
-    float s[8], q[8];
+    const int ch0 = slab * SLAB + g * V;
+    float s[V], q[V];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    for (int k = 0; k < V; ++k) { s[k] = 0.f; q[k] = 0.f; }
     const long long r0 = (long long)blockIdx.y * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     if (ch0 < C) {
         long long r = r0 + rl;
-        for (; r + 3LL * BN_RLANES < r1; r += 4LL * BN_RLANES) {
-            uint4v raw[4];
+        for (; r + 3LL * BN_RLANES < r1; r += 4LL * BN_RLANES) {        // four rows (independent 16-byte loads) in flight per lane
+            float v[4][V];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4v*>(x + (r + (long long)u * BN_RLANES) * C + ch0);
+            for (int u = 0; u < 4; ++u) Elem<T>::load(x + (r + (long long)u * BN_RLANES) * C + ch0, v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned int w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
-                    s[2 * i] += lo; q[2 * i] = fmaf(lo, lo, q[2 * i]);
-                    s[2 * i + 1] += hi; q[2 * i + 1] = fmaf(hi, hi, q[2 * i + 1]);
-                }
-            }
+                for (int k = 0; k < V; ++k) { s[k] += v[u][k]; q[k] = fmaf(v[u][k], v[u][k], q[k]); }
         }
         for (; r < r1; r += BN_RLANES) {
-            float v[8];
-            Elem<unsigned short>::load(x + r * C + ch0, v);
+            float v[V];
+            Elem<T>::load(x + r * C + ch0, v);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
+            for (int k = 0; k < V; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
         }
     }
-    slab_reduce_and_add(s, q, g, rl, slab, C, sums + (long long)(blockIdx.y % ncopies) * 2 * C, red);
+    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums + (long long)(blockIdx.y % ncopies) * 2 * C, red);
 }
 
 // Per-channel affine of one BatchNorm call, derived inside the apply kernel.
@@ -97,9 +97,10 @@ struct BnAffine {
 };
 
 // y = act(x * scale[c] + shift[c] (+ res))
-template <bool RELU, bool RES>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned short* __restrict__ x, const unsigned short* __restrict__ res,
-                                                              long long nvec, int C, BnAffine a, unsigned short* __restrict__ y) {
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              long long nvec, int C, BnAffine a, T* __restrict__ y) {
+    constexpr int V = Elem<T>::VEC;
     extern __shared__ float ss[];                 // [C] scale | [C] shift
     const bool lead = blockIdx.x == 0;
     const double inv_r = a.inv_r;
@@ -135,48 +136,51 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const unsigned sho
     }
     if (lead && threadIdx.x == 0 && a.num_batches && a.sums) a.num_batches[0] += 1;
     __syncthreads();
-    const int cg = C >> 3;
+    const int cg = C / V;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
         const int g = (int)(i % cg);
-        float v[8], r[8];
-        Elem<unsigned short>::load(x + i * 8, v);
-        if (RES) Elem<unsigned short>::load(res + i * 8, r);
-        const float4v s0 = *reinterpret_cast<const float4v*>(ss + g * 8), s1 = *reinterpret_cast<const float4v*>(ss + g * 8 + 4);
-        const float4v h0 = *reinterpret_cast<const float4v*>(ss + C + g * 8), h1 = *reinterpret_cast<const float4v*>(ss + C + g * 8 + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        float v[V], r[V], sc[V], sh[V];
+        Elem<T>::load(x + i * V, v);
+        if (RES) Elem<T>::load(res + i * V, r);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < V; k += 4) {
+            const float4v s4 = *reinterpret_cast<const float4v*>(ss + g * V + k), h4 = *reinterpret_cast<const float4v*>(ss + C + g * V + k);
+            sc[k] = s4.x; sc[k + 1] = s4.y; sc[k + 2] = s4.z; sc[k + 3] = s4.w;
+            sh[k] = h4.x; sh[k + 1] = h4.y; sh[k + 2] = h4.z; sh[k + 3] = h4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
             float t = v[k] * sc[k] + sh[k];
             if (RES) t += r[k];
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
-        Elem<unsigned short>::store(y + i * 8, v);
+        Elem<T>::store(y + i * V, v);
     }
 }
 
 // sums[0..C) += sum dz, sums[C..2C) += sum dz * xhat,   dz = dy * mask,   xhat = (x - mean) * rstd   (sums zero on entry)
 //   MASK_FROM_X: mask = (x*scale + shift > 0)     MASK_FROM_Y: mask = (y > 0)     MASK_NONE: 1
-template <int MASK>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
-                                                                   const unsigned short* __restrict__ y, long long R, int C,
+template <typename T, int MASK>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                   const T* __restrict__ y, long long R, int C,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    int rows_per_wg, float* __restrict__ sums) {
-    __shared__ float red[BN_RLANES * 128];
+    constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
+    __shared__ float red[BN_RLANES * 2 * SLAB];
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
-    const int ch0 = slab * BN_SLAB + g * 8;
-    float s[8], q[8], sc[8], sh[8], mu[8], rs[8];
+    const int ch0 = slab * SLAB + g * V;
+    float s[V], q[V], sc[V], sh[V], mu[V], rs[V];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; sc[k] = sh[k] = mu[k] = rs[k] = 0.f; }
+    for (int k = 0; k < V; ++k) { s[k] = 0.f; q[k] = 0.f; sc[k] = sh[k] = mu[k] = rs[k] = 0.f; }
     const long long r0 = (long long)blockIdx.y * rows_per_wg;
     const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     if (ch0 < C) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { sc[k] = scale[ch0 + k]; sh[k] = shift[ch0 + k]; mu[k] = mean[ch0 + k]; rs[k] = rstd[ch0 + k]; }
-        auto accum = [&](const float (&xv)[8], const float (&gv)[8], const float (&yv)[8]) {
+        for (int k = 0; k < V; ++k) { sc[k] = scale[ch0 + k]; sh[k] = shift[ch0 + k]; mu[k] = mean[ch0 + k]; rs[k] = rstd[ch0 + k]; }
+        auto accum = [&](const float (&xv)[V], const float (&gv)[V], const float (&yv)[V]) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < V; ++k) {
                 bool on = true;
                 if (MASK == BN_MASK_FROM_X) on = xv[k] * sc[k] + sh[k] > 0.f;
                 if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
@@ -187,37 +191,37 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const unsigne
         };
         long long r = r0 + rl;
         for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {        // two rows (4-6 independent 16-byte loads) in flight per lane
-            float xa[8], ga[8], ya[8], xb[8], gb[8], yb[8];
-            Elem<unsigned short>::load(x + r * C + ch0, xa);
-            Elem<unsigned short>::load(dy + r * C + ch0, ga);
-            Elem<unsigned short>::load(x + (r + BN_RLANES) * C + ch0, xb);
-            Elem<unsigned short>::load(dy + (r + BN_RLANES) * C + ch0, gb);
+            float xa[V], ga[V], ya[V], xb[V], gb[V], yb[V];
+            Elem<T>::load(x + r * C + ch0, xa);
+            Elem<T>::load(dy + r * C + ch0, ga);
+            Elem<T>::load(x + (r + BN_RLANES) * C + ch0, xb);
+            Elem<T>::load(dy + (r + BN_RLANES) * C + ch0, gb);
             if (MASK == BN_MASK_FROM_Y) {
-                Elem<unsigned short>::load(y + r * C + ch0, ya);
-                Elem<unsigned short>::load(y + (r + BN_RLANES) * C + ch0, yb);
+                Elem<T>::load(y + r * C + ch0, ya);
+                Elem<T>::load(y + (r + BN_RLANES) * C + ch0, yb);
             }
             accum(xa, ga, ya);
             accum(xb, gb, yb);
         }
         for (; r < r1; r += BN_RLANES) {
-            float xv[8], gv[8], yv[8];
-            Elem<unsigned short>::load(x + r * C + ch0, xv);
-            Elem<unsigned short>::load(dy + r * C + ch0, gv);
-            if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + r * C + ch0, yv);
+            float xv[V], gv[V], yv[V];
+            Elem<T>::load(x + r * C + ch0, xv);
+            Elem<T>::load(dy + r * C + ch0, gv);
+            if (MASK == BN_MASK_FROM_Y) Elem<T>::load(y + r * C + ch0, yv);
             accum(xv, gv, yv);
         }
     }
-    slab_reduce_and_add(s, q, g, rl, slab, C, sums, red);
+    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums, red);
 }
 
 // dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  dres = dz (residual branch gradient) when requested
-template <int MASK, bool DRES>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
-                                                                  const unsigned short* __restrict__ y, long long nvec, long long R, int C,
+template <typename T, int MASK, bool DRES>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                  const T* __restrict__ y, long long nvec, long long R, int C,
                                                                   const float* __restrict__ gamma, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ sums,
-                                                                  unsigned short* __restrict__ dx, unsigned short* __restrict__ dres,
+                                                                  T* __restrict__ dx, T* __restrict__ dres,
                                                                   float* __restrict__ fwd_sums_clear, int fwd_sums_copies,
                                                                   float* __restrict__ param_grads) {
     if (blockIdx.x == 0) {
@@ -226,17 +230,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
         if (param_grads)                           // (dbeta | dgamma) handed to the caller in memory the accumulator protocol never touches
             for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) param_grads[c] = sums[c];
     }
-    const int cg = C >> 3;
+    constexpr int V = Elem<T>::VEC;
+    const int cg = C / V;
     const float inv_r = 1.f / (float)R;
     for (long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x; i < nvec; i += (long long)gridDim.x * BN_THREADS) {
         const int g = (int)(i % cg);
-        float xv[8], gv[8], yv[8], o[8], z[8];
-        Elem<unsigned short>::load(x + i * 8, xv);
-        Elem<unsigned short>::load(dy + i * 8, gv);
-        if (MASK == BN_MASK_FROM_Y) Elem<unsigned short>::load(y + i * 8, yv);
+        float xv[V], gv[V], yv[V], o[V], z[V];
+        Elem<T>::load(x + i * V, xv);
+        Elem<T>::load(dy + i * V, gv);
+        if (MASK == BN_MASK_FROM_Y) Elem<T>::load(y + i * V, yv);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = g * 8 + k;
+        for (int k = 0; k < V; ++k) {
+            const int c = g * V + k;
             bool on = true;
             if (MASK == BN_MASK_FROM_X) on = xv[k] * scale[c] + shift[c] > 0.f;
             if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const unsigned
             z[k] = dz;
             o[k] = gamma[c] * rstd[c] * (dz - sums[c] * inv_r - xh * sums[C + c] * inv_r);
         }
-        Elem<unsigned short>::store(dx + i * 8, o);
-        if (DRES) Elem<unsigned short>::store(dres + i * 8, z);
+        Elem<T>::store(dx + i * V, o);
+        if (DRES) Elem<T>::store(dres + i * V, z);
     }
 }
 
@@ -256,8 +261,8 @@ static inline unsigned stream_grid(long long nvec) {
     return (unsigned)(want < 8192 ? want : 8192);
 }
 // 2-D blocking of the reduction kernels: nslab x nrb workgroups, ~512-1024 in total, >= 128 rows each
-static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* grid) {
-    const int nslab = (C + BN_SLAB - 1) / BN_SLAB;
+static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* grid, int slab_width = BN_SLAB) {
+    const int nslab = (C + slab_width - 1) / slab_width;
     long long nrb = (nslab >= 2 ? 1024 : 512) / nslab;
     const long long max_rb = (R + 127) / 128;
     if (nrb > max_rb) nrb = max_rb;
@@ -278,10 +283,12 @@ using namespace epi;
 // layers (few rows, so few producers -- and every apply workgroup reads all of them).
 extern "C" int epi_bn_sum_copies(int C) { return C <= 512 ? 4 : 1; }
 
-extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
-                              float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
-                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
-                              float* bwd_sums, void* y, epi_stream_t stream) {
+template <typename T>
+static int bn_act_fwd_impl(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
+                           float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
+                           long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
+                           float* bwd_sums, void* y, epi_stream_t stream) {
+    constexpr int V = Elem<T>::VEC;
     if (!x || !gamma || !beta || !scale_shift || !y) return EPI_ERR_INVALID_ARGUMENT;
     if (training && (!mean || !rstd || !sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
     if (!training && (!running_mean || !running_var)) return EPI_ERR_INVALID_ARGUMENT;
@@ -291,11 +298,11 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     if (training && training != 2) {             // 2: the producer already accumulated the batch sums into sums_ws
         int rpw = 0;
         dim3 rgrid;
-        reduce_blocking(R, C, &rpw, &rgrid);
-        hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums_ws, epi_bn_sum_copies(C));
+        reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
+        hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)x, R, C, rpw, sums_ws, epi_bn_sum_copies(C));
         EPI_CHECK_LAUNCH();
     }
-    const long long nvec = R * (C >> 3);
+    const long long nvec = R * (C / V);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     const size_t lds = (size_t)2 * C * sizeof(float);
     if (lds > 65536) return EPI_ERR_UNSUPPORTED;
@@ -303,40 +310,58 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
     a.sums = training ? sums_ws : nullptr; a.ncopies = epi_bn_sum_copies(C); a.R = R; a.inv_r = 1.0 / (double)R; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum;
     a.running_mean = running_mean; a.running_var = running_var; a.num_batches = num_batches_tracked;
     a.mean = mean; a.rstd = rstd; a.scale = scale_shift; a.shift = scale_shift + C; a.bwd_sums = bwd_sums;
-    const unsigned short* xs = (const unsigned short*)x;
-    const unsigned short* rs = (const unsigned short*)residual;
-    unsigned short* ys = (unsigned short*)y;
-    if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
-    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
-    else if (residual) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    const T* xs = (const T*)x;
+    const T* rs = (const T*)residual;
+    T* ys = (T*)y;
+    if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else if (residual) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, false, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
-extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
-                              const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
-                              float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
+extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
+                              float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
+                              float* bwd_sums, void* y, epi_stream_t stream) {
+    return bn_act_fwd_impl<unsigned short>(x, residual, R, C, gamma, beta, eps, momentum, training, relu, running_mean, running_var,
+                                           num_batches_tracked, mean, rstd, scale_shift, sums_ws, bwd_sums, y, stream);
+}
+// the same on fp32 activations (x, residual, y are float [R][C]): the fp32-grade verification mode (models/precise.py)
+extern "C" int epi_bn_act_fwd_f32(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
+                                  float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
+                                  long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws,
+                                  float* bwd_sums, void* y, epi_stream_t stream) {
+    return bn_act_fwd_impl<float>(x, residual, R, C, gamma, beta, eps, momentum, training, relu, running_mean, running_var,
+                                  num_batches_tracked, mean, rstd, scale_shift, sums_ws, bwd_sums, y, stream);
+}
+
+template <typename T>
+static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
+                           const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                           float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
+    constexpr int V = Elem<T>::VEC;
     if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int rpw = 0;
     dim3 rgrid;
-    reduce_blocking(R, C, &rpw, &rgrid);
+    reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
     const int mask = !relu ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
-    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x, *ys = (const unsigned short*)y;
+    const T *dys = (const T*)dy, *xs = (const T*)x, *ys = (const T*)y;
     const float *sc = scale_shift, *sh = scale_shift + C;
-#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
+#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
     if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
     else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
     else EPI_BN_RED(BN_MASK_FROM_Y);
 #undef EPI_BN_RED
     EPI_CHECK_LAUNCH();
-    const long long nvec = R * (C >> 3);
+    const long long nvec = R * (C / V);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
-    unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, epi_bn_sum_copies(C), param_grads)
+    T *dxs = (T*)dx, *drs = (T*)dres;
+#define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, epi_bn_sum_copies(C), param_grads)
     if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
     else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }
     else { if (dres) EPI_BN_APP(BN_MASK_FROM_Y, true); else EPI_BN_APP(BN_MASK_FROM_Y, false); }
@@ -345,16 +370,34 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
     return EPI_OK;
 }
 
-// Per-column sum and sum of squares of a bf16 matrix x [R][C], ACCUMULATED into sums [2C] f32 (caller zeroes it)
+extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
+                              const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                              float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
+    return bn_act_bwd_impl<unsigned short>(dy, x, y, R, C, gamma, mean, rstd, scale_shift, relu, dbeta_dgamma, dx, dres, fwd_sums_clear, param_grads, stream);
+}
+extern "C" int epi_bn_act_bwd_f32(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
+                                  const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                                  float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
+    return bn_act_bwd_impl<float>(dy, x, y, R, C, gamma, mean, rstd, scale_shift, relu, dbeta_dgamma, dx, dres, fwd_sums_clear, param_grads, stream);
+}
+
+// Per-column sum and sum of squares of a matrix x [R][C] (bf16; _f32: float), ACCUMULATED into sums [2C] f32 (caller zeroes it)
 // (bias gradient of the final conv: db = sum over rows of dlogits).
-extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
+template <typename T>
+static int column_sums_impl(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
     if (!x || !sums) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     int rpw = 0;
     dim3 rgrid;
-    reduce_blocking(R, C, &rpw, &rgrid);
-    hipLaunchKernelGGL(bn_stats_kernel, rgrid, dim3(BN_THREADS), 0, st, (const unsigned short*)x, R, C, rpw, sums, 1);
+    reduce_blocking(R, C, &rpw, &rgrid, 8 * Elem<T>::VEC);
+    hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)x, R, C, rpw, sums, 1);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
+}
+extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
+    return column_sums_impl<unsigned short>(x, R, C, sums, stream);
+}
+extern "C" int epi_column_sums_f32(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
+    return column_sums_impl<float>(x, R, C, sums, stream);
 }

@@ -1385,8 +1385,8 @@ extern "C" int epi_deconv4x4s2_fwd(const void* x, const void* w_phase, void* y, 
 
 // The same with the BatchNorm batch sums of the result (as epi_conv2d_fwd): bn_sums [epi_bn_sum_copies(Cout)][2 Cout] f32 += per-channel
 // (sum, sum of squares) of the bf16 outputs when the launch can do it from its epilogue (*stats_done = 1), else untouched (*stats_done = 0).
-extern "C" int epi_deconv4x4s2_fwd_stats(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, float* bn_sums,
-                                         int* stats_done, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+static int deconv4x4s2_fwd_impl(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, float* bn_sums,
+                               int* stats_done, void* workspace, size_t workspace_bytes, epi_stream_t stream, bool out_f32) {
     if (stats_done) *stats_done = 0;
     if (!x || !w_phase || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (Cin % GBK || Cout % 4) return EPI_ERR_UNSUPPORTED;
@@ -1402,16 +1402,25 @@ extern "C" int epi_deconv4x4s2_fwd_stats(const void* x, const void* w_phase, voi
         a.ph.bt_off[phase] = (long long)phase * Cout * 4 * Cin;
         for (int t = 0; t < 4; ++t) { a.ph.dy[phase][t] = (phase >> 1) - (t >> 1); a.ph.dx[phase][t] = (phase & 1) - (t & 1); }
     }
-    a.stats = bn_sums;
+    a.stats = out_f32 ? nullptr : bn_sums;
     a.stats_copies = epi_bn_sum_copies(Cout);
-    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream, stats_done);
+    return launch_gemm(a, out_f32, 4, workspace, workspace_bytes, (hipStream_t)stream, stats_done);
+}
+extern "C" int epi_deconv4x4s2_fwd_stats(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, float* bn_sums,
+                                         int* stats_done, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return deconv4x4s2_fwd_impl(x, w_phase, y, B, H, W, Cin, Cout, bn_sums, stats_done, workspace, workspace_bytes, stream, false);
+}
+// fp32 result (y float [B][2H][2W][Cout]): the fp32-grade verification mode (csrc/precise.hip), operands bf16 as always
+extern "C" int epi_deconv4x4s2_fwd_f32(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout,
+                                       void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return deconv4x4s2_fwd_impl(x, w_phase, y, B, H, W, Cin, Cout, nullptr, nullptr, workspace, workspace_bytes, stream, true);
 }
 
 // Backward-data of the same layer:  dy [B][2H][2W][Cout] -> dx [B][H][W][Cin];
 // w_bwd: [Cin][16 taps * Cout] packed by epi_deconv4x4s2_pack_weight (tap = kh*4 + kw).
 // workspace: epi_gemm_workspace_bytes(B*H*W, Cin, 16*Cout, 1).
-extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
-                                        void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+static int deconv4x4s2_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                                    void* workspace, size_t workspace_bytes, epi_stream_t stream, bool out_f32) {
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (Cout % GBK || Cin % 4) return EPI_ERR_UNSUPPORTED;
     GemmArgs a = {};
@@ -1420,7 +1429,15 @@ extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void*
     a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = 2 * H; a.ga.Ws = 2 * W; a.ga.Cs = Cout; a.ga.stride = 2;
     for (int kh = 0; kh < 4; ++kh)
         for (int kw = 0; kw < 4; ++kw) { a.ga.dy[4 * kh + kw] = kh - 1; a.ga.dx[4 * kh + kw] = kw - 1; }   // oh = 2*ih - 1 + kh
-    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                                        void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return deconv4x4s2_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, workspace, workspace_bytes, stream, false);
+}
+extern "C" int epi_deconv4x4s2_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                                            void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return deconv4x4s2_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, workspace, workspace_bytes, stream, true);
 }
 
 namespace epi {
@@ -2299,9 +2316,9 @@ extern "C" size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int C
     return need;
 }
 
-extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                              int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
-                              epi_stream_t stream) {
+static int conv2d_fwd_impl(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                          int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
+                          epi_stream_t stream, bool out_f32) {
     if (bn_sums_done) *bn_sums_done = 0;
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
@@ -2320,14 +2337,24 @@ extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int 
             for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = kh - pad; a.ga.dx[kh * KW + kw] = kw - pad; }
         if ((long long)B * H * W * Cin >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;      // 32-bit element offsets in the gather
     }
-    a.stats = bn_sums;
+    a.stats = out_f32 ? nullptr : bn_sums;
     a.stats_copies = epi_bn_sum_copies(Cout);
-    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
+    return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
+}
+extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                              int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
+                              epi_stream_t stream) {
+    return conv2d_fwd_impl(x, w, y, B, H, W, Cin, Cout, KH, KW, stride, pad, bn_sums, bn_sums_done, workspace, workspace_bytes, stream, false);
+}
+// fp32 result (y float [B][Ho][Wo][Cout]; operands bf16): the fp32-grade verification mode feeds split operands (csrc/precise.hip)
+extern "C" int epi_conv2d_fwd_f32(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                  int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return conv2d_fwd_impl(x, w, y, B, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, nullptr, workspace, workspace_bytes, stream, true);
 }
 
-extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
-                                   int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
-                                   epi_stream_t stream) {
+static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                               int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
+                               epi_stream_t stream, bool out_f32) {
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
@@ -2347,7 +2374,7 @@ extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, 
             for (int kh = 0; kh < KH; ++kh)
                 for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = pad - kh; a.ga.dx[kh * KW + kw] = pad - kw; }
         }
-        return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream);
+        return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream);
     }
     // stride 2: dx pixel (2i + py, 2j + px) gathers dy pixels (i + dy_t, j + dx_t) over the taps of its parity phase
     if ((H & 1) || (W & 1) || Cout % GBK) return EPI_ERR_UNSUPPORTED;
@@ -2363,5 +2390,14 @@ extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, 
         a.ph.bt_off[p] = L.bt_off[p];
         for (int t = 0; t < 4; ++t) { a.ph.dy[p][t] = L.dy[p][t]; a.ph.dx[p][t] = L.dx[p][t]; }
     }
-    return launch_gemm(a, false, 4, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_gemm(a, out_f32, 4, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
+                                   epi_stream_t stream) {
+    return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, addend, workspace, workspace_bytes, stream, false);
+}
+extern "C" int epi_conv2d_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                       int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, workspace, workspace_bytes, stream, true);
 }

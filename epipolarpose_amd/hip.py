@@ -74,6 +74,17 @@ _SIGNATURES = {
     "epi_deconv4x4s2_pack_phase_cl": (_i, [_vp, _i, _i, _vp, _vp]),
     "epi_deconv4x4s2_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
+    "epi_split_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _i, _i, _vp, _vp]),
+    "epi_conv2d_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_data_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_bwd_data_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "epi_bn_act_fwd_f32": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epi_bn_act_bwd_f32": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epi_column_sums_f32": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
+    "epi_maxpool3x3s2_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "epi_maxpool3x3s2_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "epi_adam_tensor_bytes": (_sz, []),
     "epi_adam_chunk_elems": (_i, []),
     "epi_adam_step": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_longlong, _vp]),

@@ -398,6 +398,38 @@ int epi_evaluate_poses(const double* pred_img, const double* gt_img, const doubl
                        const double* c_p, int N, int J, int root, const int32_t* j14, int n14, double* metrics,
                        double* per_joint, epi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp32-grade verification mode (round 3; epipolarpose_amd/models/precise.py, csrc/precise.hip) -- NOT on the training hot path.
+ * The training path computes bf16 x bf16 -> fp32 with bf16 activations, so against the reference's fp32 network
+ * (lib/models/pose3d_resnet.py:185-201, lib/core/integral_loss.py:140-160) it can only be held to a bf16 yardstick.  These entry
+ * points let the SAME MFMA GEMM kernels carry fp32 activations: every operand is split into bf16 pieces x = hi + lo (+ lo2)
+ * (epi_split_bf16) laid out along the GEMM's reduction dimension, the kernels accumulate in fp32 as always and write fp32
+ * (the *_f32 entry points; epi_conv2d_bwd_weight / epi_deconv4x4s2_bwd_weight / epi_gemm_bf16 / epi_gemm_tn_bf16 already could),
+ * and BatchNorm / max-pool / bias sums run on fp32 storage (same kernels instantiated for float where they are templates).
+ *   epi_split_bf16: x [rows][C] f32 -> bf16 pieces; pieces[b] in {0: bf16(x), 1: bf16(x - hi), 2: bf16(x - hi - lo)};
+ *                   row_concat 0: out [rows][nblk*C] (channel blocks -- forward / backward-data operands),
+ *                   row_concat 1: out [nblk][rows][C] (row blocks -- weight-gradient operands); C % 4 == 0, nblk <= 8.
+ * ------------------------------------------------------------------------------------------------ */
+int epi_split_bf16(const float* x, long long rows, int C, const int* pieces, int nblk, int row_concat, void* out, epi_stream_t stream);
+int epi_conv2d_fwd_f32(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       void* workspace, size_t workspace_bytes, epi_stream_t stream);
+int epi_conv2d_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                            int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+int epi_deconv4x4s2_fwd_f32(const void* x, const void* w_phase, void* y, int B, int H, int W, int Cin, int Cout, void* workspace,
+                            size_t workspace_bytes, epi_stream_t stream);
+int epi_deconv4x4s2_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, void* workspace,
+                                 size_t workspace_bytes, epi_stream_t stream);
+int epi_bn_act_fwd_f32(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta, float eps,
+                       float momentum, int training, int relu, float* running_mean, float* running_var,
+                       long long* num_batches_tracked, float* mean, float* rstd, float* scale_shift, float* sums_ws, float* bwd_sums,
+                       void* y, epi_stream_t stream);
+int epi_bn_act_bwd_f32(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
+                       const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
+                       float* fwd_sums_clear, float* param_grads, epi_stream_t stream);
+int epi_column_sums_f32(const void* x, long long R, int C, float* sums, epi_stream_t stream);
+int epi_maxpool3x3s2_fwd_f32(const void* x, void* y, void* pos, int B, int H, int W, int C, epi_stream_t stream);
+int epi_maxpool3x3s2_bwd_f32(const void* dy, const void* pos, void* dx, int B, int H, int W, int C, epi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

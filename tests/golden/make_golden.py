@@ -23,7 +23,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import ref_shims                                   # noqa: E402
 from det_weights import fill_state_dict, seeded_array   # noqa: E402
-from make_golden_cases import BIG_HEAD_STD, DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES   # noqa: E402
+from make_golden_cases import (BIG_HEAD_STD, DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES,   # noqa: E402
+                               TRAJECTORY_CASES, TRAJECTORY_HEAD_STD)
 from epipolarpose_amd.synthetic import SyntheticScenes  # noqa: E402
 
 REF = ref_shims.load_reference()
@@ -410,7 +411,43 @@ def gen_refiner():
     save("refiner.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------------
+# 8. training trajectory (VERDICT round 2, item 2 iii): the reference's model, criterion and torch.optim.Adam stepped 20 times
+#    (scripts/train.py:105 -> lib/core/function.py:23-52, lib/utils/utils.py:55-59) on one fixed synthetic batch, fp32 on the CPU
+# --------------------------------------------------------------------------------------------------
+def gen_trajectory():
+    out = {}
+    for name, layers, image, j, d, b, steps, lr in TRAJECTORY_CASES:
+        model = REF.pose3d_resnet.get_pose_net(ref_cfg(layers, image, j, d), is_train=True)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(fill_state_dict(shapes, seed=2, head_std=TRAJECTORY_HEAD_STD))
+        model.train()
+        x = torch.from_numpy(seeded_array("img/traj/" + name, (b, 3, image, image)))
+        gt = torch.from_numpy(seeded_array("gt/traj/" + name, (b, 3 * j), scale=0.2))
+        wt = torch.ones(b, 3 * j)
+        crit = REF.integral_loss.SmoothL1JointLocationLoss(num_joints=j)
+        opt = torch.optim.Adam(model.parameters(), lr=lr)              # utils.py:55-59: Adam(lr), no weight decay
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = crit(model(x), gt, wt)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.item()))
+        with torch.no_grad():
+            final = crit(model(x), gt, wt)                              # (train mode: one more statistics update, as a 21st forward would)
+        losses.append(float(final.item()))
+        out[name + "/losses"] = np.array(losses, dtype=np.float64)
+        sd = model.state_dict()
+        for k in ("conv1.weight", "layer2.0.conv1.weight", "final_layer.weight", "final_layer.bias", "bn1.running_mean", "deconv_layers.7.running_var",
+                  "layer4.1.bn2.weight"):
+            v = sd[k].numpy().reshape(-1)
+            out[name + "/end/" + k] = v[:: max(1, v.size // 20000)].copy()
+        print(name, "losses", " ".join("%.5f" % v for v in losses), flush=True)
+    save("trajectory.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation", "network_big", "refiner"]
+    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation", "network_big", "refiner", "trajectory"]
     for w in which:
         globals()["gen_" + w]()

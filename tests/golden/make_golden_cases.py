@@ -19,3 +19,11 @@ NETWORK_BIG_CASES = [  # name, layers, image, J, D, batch
     ("cfg2_r50_256", 50, 256, 17, 64, 4),     # configs[1] shape (the bench configuration) at batch 4
     ("cfg5_r152_384", 152, 384, 17, 64, 2),   # configs[4]: ResNet-152, 384x384 (heat-map 96^2, D = 64 != W)
 ]
+
+# 20 optimisation steps of the live reference (model + SmoothL1 criterion + torch.optim.Adam, fp32, CPU) on one fixed batch: the loss
+# trajectory and the end state, stored in trajectory.npz.  name, layers, image, J, D, batch, steps, lr
+TRAJECTORY_CASES = [
+    ("cfg1_r18_128", 18, 128, 17, 64, 2, 20, 1e-3),      # BASELINE.json configs[0]: ResNet-18, 2-view 128x128, batch 2
+    ("r50_128_b8", 50, 128, 17, 32, 8, 20, 1e-3),        # the bench network at a quarter of the pixels, 2 groups x 4 views
+]
+TRAJECTORY_HEAD_STD = 0.001

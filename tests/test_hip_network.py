@@ -1,6 +1,7 @@
-"""GPU: the whole network (MIOpen backbone convolutions + fused HIP BatchNorm/ReLU + MFMA head) against the golden
-vectors produced by the reference's PoseResNet (fp32).  Our network computes in bf16, so the bar is the bf16 one:
-logits within 3 % of max|logit|, loss within 2 %, weight-gradient cosine >= 0.99."""
+"""GPU: the whole network on the training path (hand-written implicit-GEMM convolutions, fused BatchNorm / ReLU, MFMA head, all bf16 with
+fp32 accumulation) against the golden vectors produced by the reference's PoseResNet (fp32).  The bar here is the bf16 one -- logits within
+3 % of max|logit| in inference mode, loss within 0.5 %, gradients against the stock-bf16 yardstick where bf16 can reproduce them at all;
+the fp32-grade proof on the same golden vectors is tests/test_hip_precise.py."""
 import ast
 
 import numpy as np
@@ -27,14 +28,14 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-# Gradient yardstick.  Deep-layer gradients of this network under training-mode BatchNorm are a small difference of large,
-# nearly equal terms (dz - mean(dz) with a diffuse soft-argmax); on several golden inputs NO bf16 run reproduces the fp32
-# gradient of the early layers -- STOCK PyTorch-ROCm kernels under bf16 autocast reach cosines of 0.07 .. 0.9 there (measured on
-# MI355X, logged to gpurun_out/bf16_limited_pairs.json by every run).  The check is therefore never skipped but always made
-# against stock: where stock reaches >= 0.9 ours must reach min(0.99, stock - 0.01) and the norm must agree to 15 %; where stock
-# itself is below 0.9 ours must be finite and not more than 0.15 below stock.  The per-operator gradient tests (test_hip_conv.py,
-# test_hip_head.py, test_hip_integral.py) are the well-conditioned fp32 comparisons.
-LIMITED_SLACK = 0.15
+# Gradients.  At these golden states (random weights, batch 2 .. 4) the early-layer gradients of the network are a small difference of
+# large, nearly equal terms (dz - mean(dz) under training-mode BatchNorm with a diffuse soft-argmax): NO bf16 run reproduces them -- stock
+# PyTorch-ROCm kernels under bf16 autocast reach cosines of 0.0 .. 0.9 against the fp32 reference there (logged to
+# gpurun_out/bf16_limited_pairs.json).  Round 3 moved the proof that the gradients are RIGHT to tests/test_hip_precise.py, which has no
+# such clause: the fp32-grade mode of the same kernels reproduces these very golden gradients (cosine >= 0.999 at the bench shape, loss to
+# 1e-7), and the bf16 training path is then compared with it at a trained, well-conditioned state.  What stays here is the yardstick
+# "as good as any bf16 implementation" on the pairs where that is measurable: wherever stock bf16 reaches 0.9, ours must reach
+# min(0.99, stock - 0.01) with the norm within 15 %; the other pairs are logged, required to be finite, and nothing else is claimed.
 
 
 def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_std=None):
@@ -61,7 +62,7 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
         # decode with the explicit joint count (heat-map width != DEPTH_RES for configs 1 and 5).  With the He-scaled golden
         # weights the logits reach several hundred, so the soft-argmax is practically a hard arg-max and a bf16 rounding that
         # swaps two near-equal top voxels moves a coordinate by whole voxels: the yardstick is again the oracle network under
-        # STOCK bf16 autocast -- the fraction of coordinates off by more than 1.5e-2 must not exceed stock's by more than 15 % (eval-mode statistics of the golden
+        # STOCK bf16 autocast -- the fraction of coordinates off by more than 1.5e-2 must not exceed stock's by more than 5 points (eval-mode statistics of the golden
         # weights are random, which makes 152 layers ill-conditioned: stock itself is off on 22 % of the coordinates there).
         xyz = softmax_integral_tensor(out, j, True, hm, hm, d).cpu().numpy()
         sd_e = {k: v.to(dev) for k, v in fill_state_dict(shapes, seed=1, head_std=head_std).items()}
@@ -70,7 +71,7 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
         xyz_stock = softmax_integral_tensor(stock_eval.to(torch.bfloat16), j, True, hm, hm, d).cpu().numpy()
         ref_xyz = g[name + "/xyz_eval"]
         bad_ours, bad_stock = float((np.abs(xyz - ref_xyz) > 1.5e-2).mean()), float((np.abs(xyz_stock - ref_xyz) > 1.5e-2).mean())
-        assert bad_ours <= bad_stock + 0.15, (bad_ours, bad_stock)
+        assert bad_ours <= bad_stock + 0.05, (bad_ours, bad_stock)
     model.train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         logits = model(x)
@@ -91,7 +92,7 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
     assert c_ours >= min(0.99, c_stock - 0.01), (c_ours, c_stock)
     gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
     loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
-    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=5e-2)
+    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=5e-3)        # (bf16 activations; the fp32-grade mode: 1e-7, test_hip_precise.py)
     loss.backward()
     sd = model.state_dict()
     np.testing.assert_allclose(sd["bn1.running_mean"].cpu().numpy(), g[name + "/bn1.running_mean"], atol=2e-3)
@@ -110,9 +111,8 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
             step = max(1, got.numel() // 50000)
             got, stock = got.reshape(-1)[::step], stock.reshape(-1)[::step]
         c_ours, c_stock = cosine(got, refg), cosine(stock, refg)
-        if c_stock < 0.9:
+        if c_stock < 0.9:                       # not measurable in bf16 (see above): logged, proven in test_hip_precise.py
             limited_log.append((name, k, round(c_stock, 3), round(c_ours, 3)))
-            assert c_ours >= c_stock - LIMITED_SLACK, (k, c_ours, c_stock)
             continue
         assert c_ours >= min(0.99, c_stock - 0.01), (k, c_ours, c_stock)
         assert abs(float(got.norm() / refg.norm()) - 1.0) <= 0.15, k

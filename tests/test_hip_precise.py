@@ -1,0 +1,341 @@
+"""GPU: the fp32-grade verification mode (epipolarpose_amd/models/precise.py: fp32 activations through the SAME bf16 MFMA kernels with
+split operands) against the live reference's fp32 golden vectors -- logits, loss, running statistics and parameter gradients at
+BASELINE.json's configurations 1 and 2 (the bench shape) held to an fp32-grade bar -- and then, as the on-device fp32 yardstick,
+against the bf16 training path at a trained (well-conditioned) state.  Every measured deviation is written to
+gpurun_out/precise_parity.json."""
+import ast
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from det_weights import fill_state_dict, seeded_array
+from make_golden_cases import BIG_HEAD_STD, LOGIT_STRIDE, NETWORK_BIG_CASES, TRAJECTORY_CASES, TRAJECTORY_HEAD_STD
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def report_file():
+    yield
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "precise_parity.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def cosine(a, b):
+    a, b = a.reshape(-1).double(), b.reshape(-1).double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def rel(a, b):
+    """max |a - b| / max |b| in float64"""
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def gpu_state(shapes, seed, head_std, dev):
+    sd = {k: v.to(dev) for k, v in fill_state_dict(shapes, seed=seed, head_std=head_std).items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    return sd
+
+
+# ---- operators: the split-operand GEMMs, fp32 BatchNorm and max-pool against float64 on the CPU --------------------------------------
+@pytest.mark.parametrize("pieces,tol", [(2, 4e-5), (3, 2e-6)])
+def test_precise_convolutions_vs_float64(pieces, tol):
+    from epipolarpose_amd.models import precise
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(31 + pieces)
+    worst = {}
+    # (Cin, Cout, k, stride, H): 1x1, 3x3 stride 1 | 2 (patch-eligible geometry included), the stride-2 projection
+    for cin, cout, k, stride, h in ((64, 64, 1, 1, 16), (64, 64, 3, 1, 16), (128, 128, 3, 2, 16), (256, 512, 1, 2, 8), (512, 128, 1, 1, 8), (64, 256, 1, 1, 16)):
+        pad = k // 2
+        x = torch.randn((4, cin, h, h), generator=gen)
+        w = torch.randn((cout, cin, k, k), generator=gen) * (2.0 / (cin * k * k)) ** 0.5
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        ref = F.conv2d(xd, wd, stride=stride, padding=pad)
+        dy = torch.randn(ref.shape, generator=gen)
+        ref.backward(dy.double())
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        y = precise.conv2d(xg, wg, stride, pad, pieces)
+        y.backward(dy.to(dev))
+        for what, got, want in (("y", y, ref), ("dx", xg.grad, xd.grad), ("dw", wg.grad, wd.grad)):
+            e = rel(got.detach().cpu(), want.detach())
+            worst[what] = max(worst.get(what, 0.0), e)
+            assert e <= tol, (cin, cout, k, stride, what, e)
+    # transposed convolution and the final 1x1 convolution with bias
+    x = torch.randn((2, 128, 8, 8), generator=gen)
+    w = torch.randn((128, 64, 4, 4), generator=gen) * 0.05
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xd, wd, stride=2, padding=1)
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy.double())
+    xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = precise.deconv4x4s2(xg, wg, pieces)
+    y.backward(dy.to(dev))
+    for what, got, want in (("deconv y", y, ref), ("deconv dx", xg.grad, xd.grad), ("deconv dw", wg.grad, wd.grad)):
+        worst[what] = rel(got.detach().cpu(), want.detach())
+        assert worst[what] <= tol, (what, worst[what])
+    x = torch.randn((2, 256, 16, 16), generator=gen)
+    w = torch.randn((136, 256, 1, 1), generator=gen) * 0.05
+    bias = torch.randn(136, generator=gen)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, bd)
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy.double())
+    xg, wg, bg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    y = precise.conv1x1_bias(xg, wg, bg, pieces)
+    y.backward(dy.to(dev))
+    for what, got, want in (("final y", y, ref), ("final dx", xg.grad, xd.grad), ("final dw", wg.grad, wd.grad), ("final db", bg.grad, bd.grad)):
+        worst[what] = rel(got.detach().cpu(), want.detach())
+        assert worst[what] <= tol, (what, worst[what])
+    REPORT["operators/pieces%d" % pieces] = worst
+
+
+def test_precise_batchnorm_and_maxpool_vs_float64():
+    from epipolarpose_amd.models import precise
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(41)
+    worst = {}
+    for c, h, relu, has_res in ((64, 16, True, False), (256, 8, True, True), (32, 12, False, False), (1024, 4, True, True)):
+        x = torch.randn((4, c, h, h), generator=gen) * 2 + 0.3
+        res = torch.randn((4, c, h, h), generator=gen) if has_res else None
+        gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.1
+        rm, rv = torch.randn(c, generator=gen) * 0.1, torch.rand(c, generator=gen) + 0.5
+        xd, gd, bd = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        rd = res.double().requires_grad_(True) if has_res else None
+        rmd, rvd = rm.double().clone(), rv.double().clone()
+        ref = F.batch_norm(xd, rmd, rvd, gd, bd, True, 0.1, 1e-5)
+        if has_res:
+            ref = ref + rd
+        if relu:
+            ref = F.relu(ref)
+        dy = torch.randn(ref.shape, generator=gen)
+        ref.backward(dy.double())
+        sd = {"bn.weight": gamma.to(dev).requires_grad_(True), "bn.bias": beta.to(dev).requires_grad_(True), "bn.running_mean": rm.to(dev),
+              "bn.running_var": rv.to(dev), "bn.num_batches_tracked": torch.zeros((), dtype=torch.int64, device=dev)}
+        xg = x.to(dev).requires_grad_(True)
+        rg = res.to(dev).requires_grad_(True) if has_res else None
+        y = precise.bn_act(xg, sd, "bn", residual=rg, relu=relu, training=True)
+        y.backward(dy.to(dev))
+        checks = [("y", y, ref), ("dx", xg.grad, xd.grad), ("dgamma", sd["bn.weight"].grad, gd.grad), ("dbeta", sd["bn.bias"].grad, bd.grad),
+                  ("running_mean", sd["bn.running_mean"], rmd), ("running_var", sd["bn.running_var"], rvd)]
+        if has_res:
+            checks.append(("dres", rg.grad, rd.grad))
+        for what, got, want in checks:
+            e = rel(got.detach().cpu(), want.detach())
+            worst[what] = max(worst.get(what, 0.0), e)
+            assert e <= 2e-5, (c, h, what, e)
+        assert int(sd["bn.num_batches_tracked"].item()) == 1
+        # inference mode
+        ye = precise.bn_act(x.to(dev), sd, "bn", residual=res.to(dev) if has_res else None, relu=relu, training=False)
+        refe = F.batch_norm(x.double(), sd["bn.running_mean"].cpu().double(), sd["bn.running_var"].cpu().double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+        refe = F.relu(refe + (res.double() if has_res else 0)) if relu else refe + (res.double() if has_res else 0)
+        assert rel(ye.cpu(), refe) <= 2e-6
+    x = torch.randn((3, 64, 18, 18), generator=gen)
+    xd = x.double().requires_grad_(True)
+    ref = F.max_pool2d(xd, 3, 2, 1)
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy.double())
+    xg = x.to(dev).requires_grad_(True)
+    y = precise.maxpool3x3s2(xg)
+    y.backward(dy.to(dev))
+    assert torch.equal(y.detach().cpu().double(), ref.detach())
+    assert rel(xg.grad.cpu(), xd.grad) <= 1e-6                 # (an input pixel selected by two windows: one fp32 add, in either order)
+    REPORT["operators/batchnorm"] = worst
+
+
+# ---- the whole network against the live reference's fp32 golden vectors --------------------------------------------------------------
+# Bars (fp32 grade), with what was measured on MI355X at three bf16 pieces per operand (gpurun_out/precise_parity.json):
+#   logits   |ours - ref| <= 1e-4 * max|ref|   eval 3e-7 / 4e-7, training 8e-7 (config 1) / 2e-5 (bench shape: batch-4 BatchNorm over 50 layers)
+#   loss     rel 1e-5  -- BASELINE.md section 5's fp32 tolerance --                       measured 0 (bit-identical) / 1.2e-7
+#   running statistics rel 2e-6                                                            measured <= 5e-8
+#   every stored parameter gradient: cosine >= 0.999, norm within 0.5 %                  measured 1.0000000 (config 1) / 0.99951 .. 1.0 (bench shape,
+#   where the early-layer gradients are so ill-conditioned that bf16 -- ours and stock alike -- reaches 0.06 .. 0.1 on the same vectors)
+PRECISE_CASES = [c for c in NETWORK_BIG_CASES if c[0] in ("cfg1_r18_128", "cfg2_r50_256")]
+
+
+@pytest.mark.parametrize("case", PRECISE_CASES, ids=[c[0] for c in PRECISE_CASES])
+def test_precise_network_vs_reference_golden(golden, case):
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models import precise
+    name, layers, image, j, d, b = case
+    g = golden("network_big")
+    dev = torch.device("cuda:0")
+    shapes = {k: ast.literal_eval(s) for k, s in zip(g[name + "/keys"].tolist(), g[name + "/shapes"].tolist())}
+    sub = lambda a: a.reshape(-1)[::LOGIT_STRIDE]
+    rep = {}
+    x = torch.from_numpy(seeded_array("img/" + name, (b, 3, image, image))).to(dev)
+    sd = gpu_state(shapes, 1, BIG_HEAD_STD, dev)
+    with torch.no_grad():
+        le = precise.forward(sd, x, layers, training=False, pieces=3)
+    ref, ref_max = torch.from_numpy(g[name + "/logits_eval"]), float(g[name + "/logits_eval_absmax"])
+    got = sub(le.contiguous().cpu())
+    rep["logits_eval_err_over_max"] = float((got - ref).abs().max()) / ref_max
+    rep["logits_eval_cos"] = cosine(got, ref)
+    assert rep["logits_eval_err_over_max"] <= 1e-5 and rep["logits_eval_cos"] >= 1 - 1e-9, rep
+    logits = precise.forward(sd, x, layers, training=True, pieces=3)         # three bf16 pieces per operand: products to ~2^-24, fp32 itself
+    ref, ref_max = torch.from_numpy(g[name + "/logits_train"]), float(g[name + "/logits_train_absmax"])
+    got = sub(logits.detach().contiguous().cpu())
+    rep["logits_train_err_over_max"] = float((got - ref).abs().max()) / ref_max
+    rep["logits_train_cos"] = cosine(got, ref)
+    assert rep["logits_train_err_over_max"] <= 1e-4 and rep["logits_train_cos"] >= 1 - 1e-8, rep
+    gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
+    loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
+    rep["loss"], rep["loss_ref"] = float(loss.item()), float(g[name + "/loss"])
+    rep["loss_rel"] = abs(rep["loss"] - rep["loss_ref"]) / abs(rep["loss_ref"])
+    assert rep["loss_rel"] <= 1e-5, rep
+    loss.backward()
+    rep["bn1.running_mean_rel"] = rel(sd["bn1.running_mean"].cpu(), torch.from_numpy(g[name + "/bn1.running_mean"]))
+    rep["deconv7.running_var_rel"] = rel(sd["deconv_layers.7.running_var"].cpu(), torch.from_numpy(g[name + "/deconv_layers.7.running_var"]))
+    assert rep["bn1.running_mean_rel"] <= 2e-6 and rep["deconv7.running_var_rel"] <= 2e-6, rep
+    for k in sorted(kk[len(name) + 6:] for kk in g if kk.startswith(name + "/grad/")):
+        refg = torch.from_numpy(g[name + "/grad/" + k])
+        got = sd[k].grad.float().contiguous().cpu().reshape(-1)
+        got = got[:: max(1, got.numel() // 50000)]
+        rep["grad_cos/" + k] = cosine(got, refg)
+        rep["grad_norm_ratio/" + k] = float(got.double().norm() / refg.double().norm())
+    REPORT["network/" + name] = rep
+    for k, v in rep.items():
+        if k.startswith("grad_cos/"):
+            assert v >= 0.999, (k, v)
+        if k.startswith("grad_norm_ratio/"):
+            assert abs(v - 1.0) <= 5e-3, (k, v)
+
+
+# ---- 20 optimisation steps against the live reference's trajectory ------------------------------------------------------------------
+@pytest.mark.parametrize("case", TRAJECTORY_CASES, ids=[c[0] for c in TRAJECTORY_CASES])
+def test_training_trajectory_vs_reference(golden, case):
+    """The reference's model + criterion + torch.optim.Adam stepped 20 times on one fixed batch (tests/golden/make_golden.py
+    gen_trajectory) against (a) the fp32-grade mode with torch.optim.Adam and (b) the bf16 TRAINING PATH: train_step with FusedAdam,
+    C++ autograd nodes, grouped weight gradients on the second stream -- the product, end to end."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.core.function import train_step
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models import precise
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    from epipolarpose_amd.optim import FusedAdam
+    name, layers, image, j, d, b, steps, lr = case
+    g = golden("trajectory")
+    ref = g[name + "/losses"]
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(seeded_array("img/traj/" + name, (b, 3, image, image))).to(dev)
+    gt = torch.from_numpy(seeded_array("gt/traj/" + name, (b, 3 * j), scale=0.2)).to(dev)
+    wt = torch.ones(b, 3 * j, device=dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, d, [image, image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    model = get_pose_net(cfg, is_train=True).to(dev)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # (a) fp32-grade mode
+    sd = gpu_state(shapes, 2, TRAJECTORY_HEAD_STD, dev)
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=lr)
+    got = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = crit(precise.forward(sd, x, layers, training=True), gt, wt)
+        loss.backward()
+        opt.step()
+        got.append(float(loss.item()))
+    with torch.no_grad():
+        got.append(float(crit(precise.forward(sd, x, layers, training=True), gt, wt).item()))
+    got = np.asarray(got)
+    rep = {"ref": ref.tolist(), "precise": got.tolist(), "precise_rel": (np.abs(got - ref) / ref).tolist()}
+    # (b) the bf16 training path
+    model.load_state_dict(fill_state_dict(shapes, seed=2, head_std=TRAJECTORY_HEAD_STD))
+    model.train()
+    fopt = FusedAdam(model, lr=lr)
+    bf = [float(train_step(model, crit, fopt, x, gt, wt)) for _ in range(steps)]
+    model.train()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        bf.append(float(crit(model(x), gt, wt).item()))
+    bf = np.asarray(bf)
+    rep["bf16"] = bf.tolist()
+    rep["bf16_rel"] = (np.abs(bf - ref) / ref).tolist()
+    REPORT["trajectory/" + name] = rep
+    # The first step is one forward / backward on identical weights.  Afterwards Adam (whose update is ~lr * sign(g) wherever |g| is
+    # small) amplifies rounding differences step by step, and the reference's own trajectory has chaotic spikes (cfg1: steps 6 and 16,
+    # r50: step 5 -- a loss that jumps UP by 10 %): around a spike any two fp32 implementations differ by O(10 %), before and after
+    # they agree again.  Measured on MI355X: fp32-grade mode 1e-7 / 6e-5 / 5e-4 on steps 0 / 1 / 2, median 2e-3 .. 6e-3 over the 21
+    # losses; bf16 training path 1e-5 / 4e-4 / 3e-3, median 2e-3 .. 1.5e-2.
+    assert rep["precise_rel"][0] <= 2e-5 and max(rep["precise_rel"][:3]) <= 2e-3, rep["precise_rel"]
+    assert float(np.median(rep["precise_rel"])) <= 1.5e-2 and max(rep["precise_rel"]) <= 0.25, rep["precise_rel"]
+    assert rep["bf16_rel"][0] <= 1e-3 and max(rep["bf16_rel"][:3]) <= 1.5e-2, rep["bf16_rel"]
+    assert float(np.median(rep["bf16_rel"])) <= 4e-2 and max(rep["bf16_rel"]) <= 0.25, rep["bf16_rel"]
+    assert bf[-1] < 0.9 * bf[0] and got[-1] < 0.9 * got[0]
+
+
+# ---- the bf16 training path against the fp32-grade mode at a trained state -----------------------------------------------------------
+def test_bf16_training_path_vs_precise_at_trained_state():
+    """at random initialisation the early-layer gradients of this network are a tiny difference of large
+    terms and NO bf16 run reproduces them (cosine 0.07 .. 0.1, stock kernels included).  After a few optimisation steps the problem
+    is well conditioned: tools/probe_conditioning.py (reference network, CPU, bf16 autocast against fp32) reaches 0.87 .. 0.95 on the
+    early layers and 1.000 on the head from step 5 on.  Here: 10 Adam steps in the fp32-grade mode, then every parameter gradient of the
+    bf16 training path against the fp32-grade one on the same weights and batch -- no stock-bf16 escape clause."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models import precise
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    layers, image, j, d, b = 50, 128, 17, 32, 8
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, d, [image, image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    torch.manual_seed(7)
+    model = get_pose_net(cfg, is_train=True).to(dev)              # torch's default initialisation of the backbone ...
+    init = model.state_dict()
+    for k, v in init.items():                                     # ... and the reference's own N(0, 0.001) head (pose3d_resnet.py:222-239)
+        if v.dim() == 4 and (k.startswith("deconv_layers") or k.startswith("final_layer")):
+            v.normal_(0, 0.001)
+    sd = {k: v.detach().clone().float() if v.dtype.is_floating_point else v.detach().clone() for k, v in init.items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(seeded_array("img/trained", (b, 3, image, image))).to(dev)
+    gt = torch.from_numpy(seeded_array("gt/trained", (b, 3 * j), scale=0.2)).to(dev)
+    wt = torch.ones(b, 3 * j, device=dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    for _ in range(10):
+        opt.zero_grad()
+        crit(precise.forward(sd, x, layers, training=True), gt, wt).backward()
+        opt.step()
+    state = {k: v.detach().clone() for k, v in sd.items()}
+    opt.zero_grad()
+    loss32 = crit(precise.forward(sd, x, layers, training=True), gt, wt)
+    loss32.backward()
+    model.load_state_dict(state)
+    model.train()
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = model(x)
+    loss16 = crit(logits, gt, wt)
+    loss16.backward()
+    torch.cuda.synchronize()
+    rep = {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item())}
+    cos = {}
+    for k, p in model.named_parameters():
+        gk = p.grad
+        if gk is None:
+            continue
+        cos[k] = cosine(gk.float().cpu(), sd[k].grad.cpu())
+    rep["cos"] = cos
+    rep["min_cos"] = min(cos.values())
+    rep["n_params"] = len(cos)
+    REPORT["bf16_vs_precise_trained"] = rep
+    assert len(cos) >= 150, len(cos)
+    assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= 2e-3 * rep["loss_precise"], rep
+    head = [v for k, v in cos.items() if k.startswith(("deconv_layers", "final_layer"))]
+    assert min(head) >= 0.995, min(head)
+    assert rep["min_cos"] >= 0.80, sorted(cos.items(), key=lambda kv: kv[1])[:5]
+    assert float(np.median(list(cos.values()))) >= 0.93
