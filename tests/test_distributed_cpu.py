@@ -182,3 +182,25 @@ def test_resnet50_bucket_count_with_bf16_training_copies():
     assert {f.dtype for f, _, _ in sync.buckets} == {torch.float32, torch.bfloat16}
     assert sum(len(pl) for _, pl, _ in sync.buckets) == len(params)
     assert len(epd.BucketedGradSync(model).buckets) <= 6          # pure fp32 gradients
+
+
+def test_bf16_bucket_accumulation_error_at_eight_ranks():
+    """Decision record for the dtype of the gradient buckets: the convolution-weight gradients travel in bf16 (they are
+    produced in bf16, on the bf16 training copies) and RCCL's ring adds them hop by hop, rounding to bf16 after every hop.  Simulated here
+    for N = 8 on gradients of mixed magnitude: the ring sum's error against the exact mean is ~2x one bf16 rounding (which the gradient
+    carries anyway) -- RMS <= 0.6 % of the RMS gradient, cosine >= 0.9999 -- while fp32 buckets would double the 47 MB that leave per
+    step.  bf16 buckets stay; what an Adam step sees (g / sqrt(v)) moves by the same fraction of a per-cent."""
+    torch.manual_seed(0)
+    n, m = 8, 1 << 18
+    scale = torch.exp(torch.randn(m) * 2.0)                       # elements spanning orders of magnitude
+    g = [(torch.randn(m) * scale).to(torch.bfloat16) for _ in range(n)]
+    exact = sum(t.double() for t in g) / n
+    acc = g[0].clone()
+    for t in g[1:]:                                               # one hop of the ring: fp32 add, bf16 store
+        acc = (acc.float() + t.float()).to(torch.bfloat16)
+    ring = (acc.float() / n).to(torch.bfloat16).double()
+    one = (exact.float()).to(torch.bfloat16).double()             # a single rounding of the exact mean: the floor of any bf16 result
+    rel = lambda a: float(((a - exact) ** 2).mean().sqrt() / (exact ** 2).mean().sqrt())
+    cos = float(ring @ exact / (ring.norm() * exact.norm()))
+    assert rel(one) <= 2.5e-3 and rel(ring) <= 6e-3 and rel(ring) <= 3.0 * rel(one), (rel(one), rel(ring))
+    assert cos >= 0.9999, cos
