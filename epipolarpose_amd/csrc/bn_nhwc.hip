@@ -13,6 +13,7 @@
 // x [R][C]: R = B*H*W rows, C channels contiguous (C % 8 == 0); 16 bytes (8 channels) per lane per access;
 // per-channel reductions: registers -> LDS -> one fp32 atomic per channel per workgroup.
 #include "common.h"
+#include <cstdlib>
 
 namespace epi {
 
@@ -255,6 +256,179 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
     }
 }
 
+// ---- 2-D partitioned apply kernels (round 3) ------------------------------------------------------------------------------------
+// The kernels above walk the tensor with a grid-stride loop: every workgroup first derives the affine of ALL C channels into LDS (a few
+// float64 operations per channel and workgroup) and the backward one re-loads seven per-channel arrays for every 16-byte vector it
+// touches.  On the large early tensors that is noise; on the ~110 small launches of a ResNet-50 step (<= 8 MB tensors, 4 .. 9 us each, where
+// the payload itself is 1 .. 2 us of HBM time) it is most of the kernel.  These variants use the partition of the reduction kernels instead:
+// blockIdx.x = a slab of 8 V channels, blockIdx.y = a row block, a thread owns V fixed channels and walks rows -- its coefficients live in
+// registers for the whole kernel, the per-workgroup prologue is ONE channel per thread of the first 8 V threads.
+template <typename T, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply2d_kernel(const T* __restrict__ x, const T* __restrict__ res, long long R, int C, int rows_per_wg,
+                                                                BnAffine a, T* __restrict__ y) {
+    constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
+    __shared__ float ss[2 * SLAB];                // scale | shift of this slab
+    const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    const bool lead = blockIdx.y == 0;
+    if (threadIdx.x < SLAB) {
+        const int c = slab * SLAB + threadIdx.x;
+        float sc = 0.f, sh = 0.f;
+        if (c < C) {
+            double m, var;
+            if (a.sums) {
+                float s1 = a.sums[c], s2 = a.sums[C + c];
+                for (int k = 1; k < a.ncopies; ++k) { s1 += a.sums[2 * k * C + c]; s2 += a.sums[(2 * k + 1) * C + c]; }
+                m = (double)s1 * a.inv_r;
+                var = fma(-m, m, (double)s2 * a.inv_r);
+                if (var < 0) var = 0;
+            } else {
+                m = a.running_mean[c];
+                var = a.running_var[c];
+            }
+            const float rs = 1.0f / sqrtf((float)var + a.eps);
+            sc = a.gamma[c] * rs;
+            sh = a.beta[c] - (float)m * sc;
+            if (lead) {
+                if (a.mean) { a.mean[c] = (float)m; a.rstd[c] = rs; }
+                a.scale[c] = sc;
+                a.shift[c] = sh;
+                if (a.sums && a.running_mean) {
+                    const double unbiased = (a.R > 1) ? var * (double)a.R / (double)(a.R - 1) : var;
+                    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+                    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+                }
+                if (a.bwd_sums) { a.bwd_sums[c] = 0.f; a.bwd_sums[C + c] = 0.f; }
+            }
+        }
+        ss[threadIdx.x] = sc;
+        ss[SLAB + threadIdx.x] = sh;
+    }
+    if (lead && slab == 0 && threadIdx.x == 0 && a.num_batches && a.sums) a.num_batches[0] += 1;
+    __syncthreads();
+    const int ch0 = slab * SLAB + g * V;
+    if (ch0 >= C) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = ss[g * V + k]; sh[k] = ss[SLAB + g * V + k]; }
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    auto one = [&](float (&v)[V], const float (&r)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float t = v[k] * sc[k] + sh[k];
+            if (RES) t += r[k];
+            v[k] = RELU ? fmaxf(t, 0.f) : t;
+        }
+    };
+    long long r = r0 + rl;
+    for (; r + 3LL * BN_RLANES < r1; r += 4LL * BN_RLANES) {             // four rows (4 .. 8 independent 16-byte loads) in flight per lane
+        float v[4][V], q[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Elem<T>::load(x + (r + (long long)u * BN_RLANES) * C + ch0, v[u]);
+            if (RES) Elem<T>::load(res + (r + (long long)u * BN_RLANES) * C + ch0, q[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            one(v[u], q[u]);
+            Elem<T>::store(y + (r + (long long)u * BN_RLANES) * C + ch0, v[u]);
+        }
+    }
+    for (; r < r1; r += BN_RLANES) {
+        float v[V], q[V];
+        Elem<T>::load(x + r * C + ch0, v);
+        if (RES) Elem<T>::load(res + r * C + ch0, q);
+        one(v, q);
+        Elem<T>::store(y + r * C + ch0, v);
+    }
+}
+
+template <typename T, int MASK, bool DRES>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2d_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, long long R, int C,
+                                                                    int rows_per_wg, const float* __restrict__ gamma, const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ sums,
+                                                                    T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ fwd_sums_clear,
+                                                                    int fwd_sums_copies, float* __restrict__ param_grads) {
+    constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
+    __shared__ float cs[5 * SLAB];                // P | Q | S | scale | shift of this slab:  dx = P dz + Q x + S
+    const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    if (threadIdx.x < SLAB) {
+        const int c = slab * SLAB + threadIdx.x;
+        float P = 0.f, Q = 0.f, S = 0.f, sc = 0.f, sh = 0.f;
+        if (c < C) {
+            // dx = gamma rstd (dz - s1/R - xhat s2/R),  xhat = (x - mean) rstd
+            const float inv_r = 1.f / (float)R, rs = rstd[c], gr = gamma[c] * rs;
+            const float a = sums[c] * inv_r, b = sums[C + c] * inv_r * rs;
+            P = gr;
+            Q = -gr * b;
+            S = gr * (b * mean[c] - a);
+            sc = scale[c];
+            sh = shift[c];
+        }
+        cs[threadIdx.x] = P; cs[SLAB + threadIdx.x] = Q; cs[2 * SLAB + threadIdx.x] = S; cs[3 * SLAB + threadIdx.x] = sc; cs[4 * SLAB + threadIdx.x] = sh;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {       // (`sums` is only read by this launch; these are other buffers)
+        if (fwd_sums_clear)
+            for (int c = threadIdx.x; c < 2 * C * fwd_sums_copies; c += BN_THREADS) fwd_sums_clear[c] = 0.f;
+        if (param_grads)
+            for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) param_grads[c] = sums[c];
+    }
+    __syncthreads();
+    const int ch0 = slab * SLAB + g * V;
+    if (ch0 >= C) return;
+    float P[V], Q[V], S[V], sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        P[k] = cs[g * V + k]; Q[k] = cs[SLAB + g * V + k]; S[k] = cs[2 * SLAB + g * V + k];
+        sc[k] = MASK == BN_MASK_FROM_X ? cs[3 * SLAB + g * V + k] : 0.f;
+        sh[k] = MASK == BN_MASK_FROM_X ? cs[4 * SLAB + g * V + k] : 0.f;
+    }
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    // in place: xv becomes dx, gv becomes dz
+    auto one = [&](float (&xv)[V], float (&gv)[V], const float (&yv)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            bool on = true;
+            if (MASK == BN_MASK_FROM_X) on = xv[k] * sc[k] + sh[k] > 0.f;
+            if (MASK == BN_MASK_FROM_Y) on = yv[k] > 0.f;
+            const float dz = on ? gv[k] : 0.f;
+            xv[k] = fmaf(P[k], dz, fmaf(Q[k], xv[k], S[k]));
+            gv[k] = dz;
+        }
+    };
+    long long r = r0 + rl;
+    for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {                   // two rows (4 .. 6 independent 16-byte loads) in flight per lane
+        float xa[V], ga[V], ya[V], xb[V], gb[V], yb[V];
+        Elem<T>::load(x + r * C + ch0, xa);
+        Elem<T>::load(dy + r * C + ch0, ga);
+        Elem<T>::load(x + (r + BN_RLANES) * C + ch0, xb);
+        Elem<T>::load(dy + (r + BN_RLANES) * C + ch0, gb);
+        if (MASK == BN_MASK_FROM_Y) {
+            Elem<T>::load(y + r * C + ch0, ya);
+            Elem<T>::load(y + (r + BN_RLANES) * C + ch0, yb);
+        }
+        one(xa, ga, ya);
+        one(xb, gb, yb);
+        Elem<T>::store(dx + r * C + ch0, xa);
+        Elem<T>::store(dx + (r + BN_RLANES) * C + ch0, xb);
+        if (DRES) {
+            Elem<T>::store(dres + r * C + ch0, ga);
+            Elem<T>::store(dres + (r + BN_RLANES) * C + ch0, gb);
+        }
+    }
+    for (; r < r1; r += BN_RLANES) {
+        float xv[V], gv[V], yv[V];
+        Elem<T>::load(x + r * C + ch0, xv);
+        Elem<T>::load(dy + r * C + ch0, gv);
+        if (MASK == BN_MASK_FROM_Y) Elem<T>::load(y + r * C + ch0, yv);
+        one(xv, gv, yv);
+        Elem<T>::store(dx + r * C + ch0, xv);
+        if (DRES) Elem<T>::store(dres + r * C + ch0, gv);
+    }
+}
+
 static inline bool bn_shape_ok(long long R, int C) { return R > 0 && C > 0 && C % 8 == 0 && R < (1LL << 40); }
 static inline unsigned stream_grid(long long nvec) {
     const long long want = (nvec + BN_THREADS - 1) / BN_THREADS;
@@ -272,6 +446,28 @@ static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* g
     nrb = (R + rpw - 1) / rpw;
     *rows_per_wg = (int)rpw;
     *grid = dim3((unsigned)nslab, (unsigned)nrb);
+}
+
+// blocking of the 2-D apply kernels: enough workgroups to fill the chip several times over on the large tensors (they are HBM-bound and
+// run 8 workgroups per CU), >= 128 rows (four per lane) each
+static inline void apply_blocking(long long R, int C, int* rows_per_wg, dim3* grid, int slab_width) {
+    const int nslab = (C + slab_width - 1) / slab_width;
+    static const long long target = [] { const char* e = getenv("EPI_BN_2D_WGS"); const long long v = e ? atoll(e) : 2048; return v >= 64 ? v : 2048; }();
+    long long nrb = target / nslab;
+    const long long max_rb = (R + 127) / 128;
+    if (nrb > max_rb) nrb = max_rb;
+    if (nrb < 1) nrb = 1;
+    long long rpw = (R + nrb - 1) / nrb;
+    rpw = (rpw + BN_RLANES - 1) / BN_RLANES * BN_RLANES;
+    nrb = (R + rpw - 1) / rpw;
+    *rows_per_wg = (int)rpw;
+    *grid = dim3((unsigned)nslab, (unsigned)nrb);
+}
+// EPI_BN_2D: bit 0 forward apply, bit 1 backward apply on the 2-D kernels (default 3 = both; 0 = the grid-stride kernels)
+static int g_bn_2d = -1;
+static inline int bn_2d_mode() {
+    if (g_bn_2d < 0) { const char* e = getenv("EPI_BN_2D"); g_bn_2d = e ? atoi(e) & 3 : 3; }
+    return g_bn_2d;
 }
 
 }  // namespace epi
@@ -313,6 +509,17 @@ static int bn_act_fwd_impl(const void* x, const void* residual, long long R, int
     const T* xs = (const T*)x;
     const T* rs = (const T*)residual;
     T* ys = (T*)y;
+    if (bn_2d_mode() & 1) {        // 2-D partition: per-channel coefficients in registers (EPI_BN_2D: see bn_2d_mode)
+        int rpw = 0;
+        dim3 g2;
+        apply_blocking(R, C, &rpw, &g2, 8 * V);
+        if (relu && residual) hipLaunchKernelGGL((bn_apply2d_kernel<T, true, true>), g2, block, 0, st, xs, rs, R, C, rpw, a, ys);
+        else if (relu) hipLaunchKernelGGL((bn_apply2d_kernel<T, true, false>), g2, block, 0, st, xs, rs, R, C, rpw, a, ys);
+        else if (residual) hipLaunchKernelGGL((bn_apply2d_kernel<T, false, true>), g2, block, 0, st, xs, rs, R, C, rpw, a, ys);
+        else hipLaunchKernelGGL((bn_apply2d_kernel<T, false, false>), g2, block, 0, st, xs, rs, R, C, rpw, a, ys);
+        EPI_CHECK_LAUNCH();
+        return EPI_OK;
+    }
     if (relu && residual) hipLaunchKernelGGL((bn_apply_kernel<T, true, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
     else if (relu) hipLaunchKernelGGL((bn_apply_kernel<T, true, false>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
     else if (residual) hipLaunchKernelGGL((bn_apply_kernel<T, false, true>), grid, block, lds, st, xs, rs, nvec, C, a, ys);
@@ -361,6 +568,18 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long lo
     const long long nvec = R * (C / V);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     T *dxs = (T*)dx, *drs = (T*)dres;
+    if (bn_2d_mode() & 2) {
+        int rpw2 = 0;
+        dim3 g2;
+        apply_blocking(R, C, &rpw2, &g2, 8 * V);
+#define EPI_BN_APP2(M, D) hipLaunchKernelGGL((bn_bwd_apply2d_kernel<T, M, D>), g2, block, 0, st, dys, xs, ys, R, C, rpw2, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, epi_bn_sum_copies(C), param_grads)
+        if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP2(BN_MASK_NONE, true); else EPI_BN_APP2(BN_MASK_NONE, false); }
+        else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP2(BN_MASK_FROM_X, true); else EPI_BN_APP2(BN_MASK_FROM_X, false); }
+        else { if (dres) EPI_BN_APP2(BN_MASK_FROM_Y, true); else EPI_BN_APP2(BN_MASK_FROM_Y, false); }
+#undef EPI_BN_APP2
+        EPI_CHECK_LAUNCH();
+        return EPI_OK;
+    }
 #define EPI_BN_APP(M, D) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, D>), grid, block, 0, st, dys, xs, ys, nvec, R, C, gamma, sc, sh, mean, rstd, dbeta_dgamma, dxs, drs, fwd_sums_clear, epi_bn_sum_copies(C), param_grads)
     if (mask == BN_MASK_NONE) { if (dres) EPI_BN_APP(BN_MASK_NONE, true); else EPI_BN_APP(BN_MASK_NONE, false); }
     else if (mask == BN_MASK_FROM_X) { if (dres) EPI_BN_APP(BN_MASK_FROM_X, true); else EPI_BN_APP(BN_MASK_FROM_X, false); }

@@ -385,9 +385,26 @@ void* pending_slab_alloc(size_t bytes, const Tensor& like) {
 // leaf (no upstream node reads the gradient), has no gradient yet (AccumulateGrad will adopt the tensor, not add to it), and carries
 // no tensor hooks / post-accumulate hooks (those run inside the pass; the bucketed all-reduce, which hooks the LAST gradient of each
 // bucket, flushes explicitly for the others).
+// Parameters whose post-accumulate hooks were all REMOVED again: torch keeps the (now empty) hook object on the tensor for good, so
+// post_acc_grad_hooks(w) stays non-null and the rule below would keep every such gradient on the main stream, unsplit-only and ungrouped.
+// distributed.BucketedGradSync hooks every parameter during its first step (to learn which gradient completes each bucket) and
+// declares the others hook-free afterwards.  Held weakly; an entry whose tensor died is dropped.
+std::vector<c10::weak_intrusive_ptr<c10::TensorImpl>> g_hook_free;
+void declare_hook_free(const std::vector<Tensor>& tensors) {
+    g_hook_free.clear();
+    for (const Tensor& t : tensors)
+        if (t.defined()) g_hook_free.emplace_back(c10::weak_intrusive_ptr<c10::TensorImpl>(t.getIntrusivePtr()));
+}
+bool declared_hook_free(const Tensor& w) {
+    const c10::TensorImpl* key = w.unsafeGetTensorImpl();
+    for (const auto& e : g_hook_free)
+        if (e._unsafe_get_target() == key && !e.expired()) return true;
+    return false;
+}
+
 bool gradient_consumed_after_backward(const Tensor& w) {
     if (!w.defined() || !w.is_leaf() || w.grad().defined()) return false;
-    if (torch::autograd::impl::post_acc_grad_hooks(w) != nullptr) return false;
+    if (torch::autograd::impl::post_acc_grad_hooks(w) != nullptr && !declared_hook_free(w)) return false;
     if (!torch::autograd::impl::hooks(w).empty()) return false;
     auto acc = torch::autograd::impl::try_get_grad_accumulator(w);
     // (post hooks of the accumulator: torch.nn.parallel.DistributedDataParallel registers its reducer there)
@@ -1227,6 +1244,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
     m.def("wgrad_stream_mode", &wgrad_stream_mode,
           "weight gradients on a second HIP stream: 0 off, 1 on, 2 on with the lowest stream priority; returns the previous setting");
+    m.def("declare_hook_free", &declare_hook_free,
+          "parameters whose post-accumulate hooks were all removed again (torch keeps the empty hook object): their gradients may stay on the "
+          "second stream / in a grouped launch / unreduced until the end of the pass; replaces the previous declaration");
     m.def("wgrad_group_mode", &wgrad_group_mode,
           "grouped weight-gradient launches: 0 one launch per layer, 1 one per autograd node, 2 one per ResNet stage; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");

@@ -116,10 +116,20 @@ class BucketedGradSync:
         self._launched = set()
         self._last = {}
         self._learning = True
+        self._declare_hook_free([])
         for bi, (_, plist, _) in enumerate(self.buckets):
             for p in plist:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
         self.zero_grad()
+
+    def _declare_hook_free(self, params):
+        """Tell the C++ glue which parameters carry no live hook (csrc/torch_glue.cpp declare_hook_free): a removed post-accumulate hook
+        leaves its empty holder on the tensor, which the glue would otherwise read as "somebody consumes this gradient inside the pass"
+        and keep the weight gradient on the main stream, one launch per layer -- measured 8.0 instead of 7.05 ms/step on the forced
+        bucket path before this declaration existed."""
+        if any(p.is_cuda for _, plist, _ in self.buckets for p in plist):
+            from . import hip
+            hip.glue().declare_hook_free(list(params))
 
     def _make_bucket(self, plist, grad_dtype):
         total = sum(p.numel() for p in plist)
@@ -228,6 +238,8 @@ class BucketedGradSync:
             for h in self._hooks:
                 h.remove()
             self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(bi)) for bi, p in self._last.items()]
+            last = {id(p) for p in self._last.values()}
+            self._declare_hook_free([p for _, plist, _ in self.buckets for p in plist if id(p) not in last])
 
     def total_bytes(self):
         return sum(f.numel() * f.element_size() for f, _, _ in self.buckets)
