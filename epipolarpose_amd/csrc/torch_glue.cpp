@@ -276,7 +276,8 @@ struct ReduceTable {
     std::vector<EpiSlabReduce> uploaded;
     hipEvent_t upload_done = nullptr;
 };
-ReduceTable g_reduce_tables[2];
+constexpr int REDUCE_TABLE_SLOTS = 10;   // 0: begin_early_step, 1: the end of the pass, 2 ..: the asynchronous flushes of a pass, in order
+ReduceTable g_reduce_tables[REDUCE_TABLE_SLOTS];
 
 // sum the registered slabs with one launch on `stream`; leaves the arena bookkeeping alone
 void launch_pending_rows(hipStream_t stream, int slot) {
@@ -322,6 +323,8 @@ void launch_pending_rows(hipStream_t stream, int slot) {
 }
 
 std::vector<const void*> g_seen_weights;     // weights whose gradient this backward pass has already produced once (shared weights)
+struct FlushTickets;
+void reset_flush_ordinal();
 
 void flush_pending_reduces() {
     side_group_flush();              // weight gradients still waiting for their grouped launch
@@ -339,10 +342,53 @@ void flush_pending_reduces() {
         launch_pending_rows(stream, 1);
     }
     side_join();                     // the main stream waits for everything on the weight-gradient stream: unsplit gradients, slabs, the sum
+    reset_flush_ordinal();
     P.target = std::max(P.target, P.wanted);
     if (P.arena.defined() && P.target > (size_t)P.arena.numel()) P.arena = Tensor();            // regrown by the next pass (stream-ordered free)
     P.used = 0;
     P.wanted = 0;
+}
+
+// ---- asynchronous flush (the bucketed gradient path, distributed.BucketedGradSync) --------------------------------------------------
+// A bucket hook used to call flush_pending_reduces(): the grouped weight gradients went out and the MAIN stream joined the second one --
+// four stalls of ~100 us per ResNet-50 backward pass, 5.4 % of the step (profiles/r03_bucket_path_overhead_a_*.txt).  Here nothing
+// waits: the pending group and the slab sums registered so far are enqueued on the second stream and an event marks their end; the
+// caller lets the main stream wait for that event when it LAUNCHES the bucket -- one bucket of backward later, when the event has
+// normally fired long ago.  Returns a ticket for wait_flush_ticket(), or -1 when the flush was synchronous (second stream off).
+struct FlushTickets {
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+    int ordinal = 0;                 // asynchronous flushes of the current pass so far (selects the cached reduce table)
+};
+FlushTickets g_tickets;
+void reset_flush_ordinal() { g_tickets.ordinal = 0; }
+
+int64_t flush_pending_async() {
+    if (side_mode() == 0) { flush_pending_reduces(); return -1; }
+    side_group_flush();
+    PendingReduces& P = g_pend;
+    SideStream& S = g_side;
+    if (!S.dirty && P.rows.empty()) return -1;                 // nothing in flight anywhere: the gradients are final already
+    const int dev = P.rows.empty() ? S.device : (int)P.dev.index();
+    hipStream_t main_stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev).stream();
+    hipStream_t side = side_fork(dev, main_stream);             // behind everything enqueued so far on either stream
+    if (!P.rows.empty()) launch_pending_rows(side, std::min(2 + g_tickets.ordinal, REDUCE_TABLE_SLOTS - 1));
+    g_tickets.ordinal += 1;
+    if (g_tickets.events.empty()) {
+        g_tickets.events.resize(32);
+        for (auto& e : g_tickets.events) TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "flush ticket: event");
+    }
+    const size_t idx = g_tickets.next++ % g_tickets.events.size();
+    TORCH_CHECK(hipEventRecord(g_tickets.events[idx], side) == hipSuccess, "flush ticket: record");
+    end_of_pass_callback();                                     // the join (and the arena bookkeeping) still happen at the end of the pass
+    return (int64_t)idx;
+}
+
+void wait_flush_ticket(int64_t ticket, int64_t device_index) {
+    if (ticket < 0) return;
+    TORCH_CHECK((size_t)ticket < g_tickets.events.size(), "flush ticket: unknown ticket");
+    hipStream_t main_stream = c10::hip::getCurrentHIPStream((c10::DeviceIndex)device_index).stream();
+    TORCH_CHECK(hipStreamWaitEvent(main_stream, g_tickets.events[(size_t)ticket], 0) == hipSuccess, "flush ticket: wait");
 }
 
 // Optimizer work INSIDE the backward pass (optim.FusedAdam.enable_step_in_backward): called from a tensor hook at a point of the
@@ -779,8 +825,9 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
             end_of_pass_callback();
             return out;
         }
+        // (a gradient somebody reads inside the pass -- a hooked parameter -- is computed right here on the main stream with its own
+        //  reduction; whoever reads it flushes what ELSE it needs: the bucket hooks do, asynchronously.  Round 2 joined the streams here.)
         const bool may_defer = slab_bytes && defer_enabled() && after_pass;
-        if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();      // e.g. a gradient somebody reads inside the pass
         void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
         // second stream: only a launch whose result is complete by the end-of-pass join (an arena-less split would reduce right away)
         const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
@@ -1116,7 +1163,6 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
             const size_t slab_bytes = epi_gemm_tn_workspace_bytes(M, Cout, Cin, 1);
             const bool after_pass = gradient_consumed_after_backward(w);
             const bool may_defer = slab_bytes && defer_enabled() && after_pass;
-            if (slab_bytes && defer_enabled() && !may_defer) flush_pending_reduces();
             void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
             const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
             const Tensor xin = x, dyin = dy, dwout = dw;
@@ -1222,6 +1268,37 @@ std::tuple<bool, std::vector<Tensor>> adam_prepare(const std::vector<Tensor>& pa
     return std::make_tuple(changed, keep);
 }
 
+// distributed.BucketedGradSync._launch without its Python loop (~170 parameters per step: 0.3 ms of host time inside finish(), during
+// which the GPU had nothing queued): move every gradient of a bucket into its slice of the flat buffer with ONE multi-tensor copy and
+// re-point .grad at the slice.  views[i]: the parameter-strided view of params[i] inside the flat buffer.
+void pack_bucket(const std::vector<Tensor>& params, const std::vector<Tensor>& views) {
+    TORCH_CHECK(params.size() == views.size(), "pack_bucket: list sizes");
+    std::vector<Tensor> dst, src;
+    dst.reserve(params.size());
+    src.reserve(params.size());
+    for (size_t i = 0; i < params.size(); ++i) {
+        Tensor g = params[i].grad();
+        const Tensor& v = views[i];
+        if (!g.defined()) {
+            v.zero_();                                   // parameter without a gradient this step
+        } else if (g.data_ptr() != v.data_ptr()) {
+            bool fast = g.strides() == v.strides();
+            if (!fast && g.sizes() == v.sizes()) {
+                // same memory order, only the strides of extent-1 dimensions differ (a 1x1 convolution weight's gradient comes back
+                // "contiguous", the parameter is "channels_last"): re-stride the alias so that the multi-tensor copy keeps its fast path
+                bool same_order = true;
+                for (int64_t d = 0; d < g.dim(); ++d)
+                    if (g.size(d) > 1 && g.stride(d) != v.stride(d)) { same_order = false; break; }
+                if (same_order) { g = g.as_strided(g.sizes(), v.strides(), g.storage_offset()); fast = true; }
+            }
+            if (fast) { dst.push_back(v); src.push_back(g); }
+            else v.copy_(g);                             // genuinely different layout: its own strided copy
+        }
+    }
+    if (!dst.empty()) at::_foreach_copy_(dst, src);
+    for (size_t i = 0; i < params.size(); ++i) params[i].mutable_grad() = views[i];
+}
+
 // optimizer.zero_grad(set_to_none=True) for a parameter list without a Python loop (~170 parameters + their bf16 training copies)
 void clear_grads(const std::vector<Tensor>& tensors) {
     for (const Tensor& t : tensors)
@@ -1240,6 +1317,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("residual_unit", &residual_unit, "a whole BasicBlock / Bottleneck (conv-bn-relu stages + shortcut) as one autograd node");
     m.def("begin_early_step", &begin_early_step,
           "inside a backward pass: sum the pending weight-gradient slabs on the second stream and return that stream (0: second stream off)");
+    m.def("flush_pending_async", &flush_pending_async,
+          "enqueue the pending grouped weight gradients and slab sums on the second stream without joining; returns a ticket (-1: already final)");
+    m.def("wait_flush_ticket", &wait_flush_ticket, "the main stream of the device waits for the event behind a flush_pending_async ticket");
     m.def("flush_pending_reduces", &flush_pending_reduces,
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
     m.def("wgrad_stream_mode", &wgrad_stream_mode,
@@ -1250,6 +1330,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("wgrad_group_mode", &wgrad_group_mode,
           "grouped weight-gradient launches: 0 one launch per layer, 1 one per autograd node, 2 one per ResNet stage; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");
+    m.def("pack_bucket", &pack_bucket, "gradient bucket packing of distributed.BucketedGradSync in one call (multi-tensor copy + .grad re-pointing)");
     m.def("clear_grads", &clear_grads, "drop the .grad of every tensor in the list (zero_grad(set_to_none=True))");
     m.def("adam_prepare", &adam_prepare, "FusedAdam pointer table refresh (no Python loop over the parameters)");
     m.def("timing_enable", &timing_enable, "record HIP events around every epi_* launch made by this extension");

@@ -114,6 +114,8 @@ class BucketedGradSync:
         # A launch that finds a gradient missing (the graph changed) is deferred to finish(), which is always correct.
         self._hooks = []
         self._launched = set()
+        self._deferred = []        # complete buckets whose launch waits for the next hook (GPU: see _launch_from_hook)
+        self._pipeline = os.environ.get("EPI_BUCKET_PIPELINE", "1") != "0"
         self._last = {}
         self._learning = True
         self._declare_hook_free([])
@@ -143,15 +145,41 @@ class BucketedGradSync:
             off += p.numel()
         self.buckets.append((flat, plist, views))
 
-    def _launch(self, bi):
+    def _launch_from_hook(self, bi):
+        """Inside backward: bucket ``bi`` is complete.  On the GPU the gradients of this bucket may still be in flight on the second
+        stream (grouped weight gradients, deferred slab sums: csrc/torch_glue.cpp), so the bucket is not packed now: everything
+        pending is enqueued there behind an event (no stream waits for anything) and the bucket is launched at the NEXT hook -- one
+        bucket of backward later, when its event has long fired -- or by finish().  (Joining the streams at every hook instead cost
+        5.4 % of the step, profiles/r03_bucket_path_overhead_a_join_per_bucket.txt.)"""
+        flat = self.buckets[bi][0]
+        if not flat.is_cuda or not self._pipeline:
+            self._launch(bi)
+            return
+        from . import hip
+        ticket = hip.glue().flush_pending_async()
+        self._deferred.append((bi, ticket))
+        while len(self._deferred) > 1:
+            b, t = self._deferred.pop(0)
+            hip.glue().wait_flush_ticket(t, flat.device.index)
+            self._launch(b, flushed=True)
+
+    def _launch(self, bi, flushed=False):
         flat, plist, views = self.buckets[bi]
-        if flat.is_cuda:
+        if flat.is_cuda and not flushed:
             # split weight gradients are summed by ONE launch at the end of backward (csrc/torch_glue.cpp); a bucket that leaves
             # earlier needs the sums of what has been computed so far now
             from . import hip
             hip.glue().flush_pending_reduces()
         if BUCKET_PACK == "cat" and self._pack_cat(flat, plist, views):
             self._finish_launch(bi, flat, plist, views)
+            return
+        if flat.is_cuda and BUCKET_PACK == "foreach":
+            from . import hip
+            hip.glue().pack_bucket(plist, views)         # the loop below, in C++ (0.3 ms of Python per step otherwise)
+            self._launched.add(bi)
+            if self.world > 1:
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                self._handles.append(dist.all_reduce(flat, op=op, async_op=True))
             return
         dst, src = [], []
         for p, v in zip(plist, views):
@@ -206,23 +234,32 @@ class BucketedGradSync:
                 self._pending[bi] -= 1
                 if self._pending[bi] == 0:
                     self._last[bi] = param
-                    self._launch(bi)
+                    self._launch_from_hook(bi)
             elif all(p.grad is not None for p in self.buckets[bi][1]):
-                self._launch(bi)             # the learned last arrival, and indeed every gradient is here
+                self._launch_from_hook(bi)   # the learned last arrival, and indeed every gradient is here
         return hook
 
     def zero_grad(self):
         """Call before backward(): drops every ``.grad`` (autograd then hands gradients over instead of accumulating)."""
-        for _, plist, _ in self.buckets:
-            for p in plist:
-                p.grad = None
+        if self.buckets and self.buckets[0][0].is_cuda:
+            from . import hip
+            hip.glue().clear_grads([p for _, plist, _ in self.buckets for p in plist])
+        else:
+            for _, plist, _ in self.buckets:
+                for p in plist:
+                    p.grad = None
         self._pending = {bi: len(plist) for bi, (_, plist, _) in enumerate(self.buckets)}
         self._handles = []
         self._launched = set()
+        self._deferred = []
 
     def finish(self):
         """Wait for the in-flight all-reduces; gradients become the mean over ranks.  Call between backward() and
         optimizer.step()."""
+        # (backward() has returned: the end-of-pass callback of the glue has joined the streams, every gradient is final)
+        for b, _ in self._deferred:                   # complete buckets still waiting for their turn
+            self._launch(b, flushed=True)
+        self._deferred = []
         for bi in range(len(self.buckets)):           # buckets whose hook did not fire / found a gradient missing
             if bi not in self._launched:
                 self._launch(bi)
