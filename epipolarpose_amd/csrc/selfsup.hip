@@ -521,6 +521,18 @@ EPI_HD __forceinline__ double fast_rcp(double v) {
 #endif
 }
 
+// 1 / sqrt(x): hardware estimate + two Newton steps
+EPI_HD __forceinline__ double fast_rsq(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(v);
+    r = r * fma(-0.5 * v * r, r, 1.5);
+    r = r * fma(-0.5 * v * r, r, 1.5);
+    return r;
+#else
+    return 1.0 / sqrt(v);
+#endif
+}
+
 EPI_HD __forceinline__ void solve_sym3(const double (&n)[6], const double (&r)[3], double (&x)[3]) {
     // n = (n00, n01, n02, n11, n12, n22); adjugate / determinant
     const double c00 = n[3] * n[5] - n[4] * n[4], c01 = n[2] * n[4] - n[1] * n[5], c02 = n[1] * n[4] - n[2] * n[3];
@@ -593,6 +605,128 @@ EPI_HD __forceinline__ int tri_iterative_ne(const double (&u)[NV][2], const doub
     return all_front ? 1 : code;
 }
 
+// Mixed precision (round 3): the same iteration with float64 where it is needed and float32 everywhere else.
+//   * round 1 (all weights 1) is the plain least-squares solve: normal equations and solve in float64 -> x0, depths d0;
+//   * every later round only MOVES the solution by a few millimetres (the cumulative re-weighting shifts it between the views'
+//     individually consistent points), so it is solved for the correction:  N dx = sum_v s_v g_v  with  g_v = A_v^T (b_v - A_v x0)
+//     (computed once in float64: the cancellation happens there) and N = sum_v s_v G_v in float32.  cond(N) ~ 1e4 costs 1e-3 of |dx|
+//     ~ mm, i.e. ~1e-3 mm, inside the 1e-2 mm envelope of the fp32-storage path;
+//   * the reference's stopping rule |d_new - d_old| <= 3e-5 mm on depths of ~5000 mm (triangulation.py:161) is evaluated on the depth
+//     DIFFERENCE p_v . (dx_new - dx_old), which float32 resolves to ~1e-7 mm -- the number of rounds, and with it the result of the
+//     cumulative re-weighting, is the reference's.
+// ~300 float64 + ~110 float32 operations per further round instead of ~150 float64 per round.
+EPI_HD __forceinline__ float fast_rcpf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(v);
+    return fmaf(fmaf(-v, r, 1.0f), r, r);
+#else
+    return 1.0f / v;
+#endif
+}
+
+// (TI: the type the inputs are held in -- float for the fp32-storage kernel, so that no float64 copy of the 4 x 14 inputs occupies
+//  112 registers for the whole solve; every use converts)
+template <int NV, typename TI>
+EPI_HD __forceinline__ int tri_iterative_mixed(const TI (&uu)[NV][2], const TI (&PP)[NV][12], int nv, double tol, int max_iter,
+                                               double (&x)[3]) {
+    struct { const TI (&a)[NV][2]; EPI_HD __forceinline__ double operator()(int v, int q) const { return (double)a[v][q]; } } uw{uu};
+    struct { const TI (&a)[NV][12]; EPI_HD __forceinline__ double operator()(int v, int k) const { return (double)a[v][k]; } } Pw{PP};
+    x[0] = x[1] = x[2] = 0;
+    if (max_iter <= 0) return 1;
+    double n[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double a0 = uw(v, q) * Pw(v, 8) - Pw(v, 4 * q), a1 = uw(v, q) * Pw(v, 9) - Pw(v, 4 * q + 1), a2 = uw(v, q) * Pw(v, 10) - Pw(v, 4 * q + 2);
+                const double b = Pw(v, 4 * q + 3) - uw(v, q) * Pw(v, 11);                                     // triangulation.py:138-148
+                n[0] = fma(a0, a0, n[0]); n[1] = fma(a0, a1, n[1]); n[2] = fma(a0, a2, n[2]);
+                n[3] = fma(a1, a1, n[3]); n[4] = fma(a1, a2, n[4]); n[5] = fma(a2, a2, n[5]);
+                r[0] = fma(a0, b, r[0]); r[1] = fma(a1, b, r[1]); r[2] = fma(a2, b, r[2]);
+            }
+        }
+    }
+    solve_sym3(n, r, x);                                                                                   // round 1, :155 with unit weights
+    // per view: Gram block and residual right-hand side at x0 (float32 from here on), depth row, depth at x0
+    float G[NV][6], g[NV][3], pz[NV][3], d[NV], dn[NV], s[NV];
+    bool conv = true;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool on = v < nv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) G[v][k] = 0.f;
+        g[v][0] = g[v][1] = g[v][2] = 0.f;
+        s[v] = on ? 1.f : 0.f;
+        double d0 = 1.0;
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double a0 = uw(v, q) * Pw(v, 8) - Pw(v, 4 * q), a1 = uw(v, q) * Pw(v, 9) - Pw(v, 4 * q + 1), a2 = uw(v, q) * Pw(v, 10) - Pw(v, 4 * q + 2);
+                const double e = (Pw(v, 4 * q + 3) - uw(v, q) * Pw(v, 11)) - (a0 * x[0] + a1 * x[1] + a2 * x[2]);
+                const float f0 = (float)a0, f1 = (float)a1, f2 = (float)a2, fe = (float)e;
+                G[v][0] = fmaf(f0, f0, G[v][0]); G[v][1] = fmaf(f0, f1, G[v][1]); G[v][2] = fmaf(f0, f2, G[v][2]);
+                G[v][3] = fmaf(f1, f1, G[v][3]); G[v][4] = fmaf(f1, f2, G[v][4]); G[v][5] = fmaf(f2, f2, G[v][5]);
+                g[v][0] = fmaf(f0, fe, g[v][0]); g[v][1] = fmaf(f1, fe, g[v][1]); g[v][2] = fmaf(f2, fe, g[v][2]);
+            }
+            d0 = Pw(v, 8) * x[0] + Pw(v, 9) * x[1] + Pw(v, 10) * x[2] + Pw(v, 11);                             // :158-159
+            if (!(fabs(d0 - 1.0) <= tol)) conv = false;                                                    // :161 against the initial d = 1 (:151)
+        }
+        pz[v][0] = on ? (float)Pw(v, 8) : 0.f; pz[v][1] = on ? (float)Pw(v, 9) : 0.f; pz[v][2] = on ? (float)Pw(v, 10) : 0.f;
+        d[v] = dn[v] = (float)d0;
+    }
+    float dx[3] = {0.f, 0.f, 0.f};
+    if (!conv) {
+        const float dref = d[0];                                                                           // keeps the cumulative weights O(1)
+        for (int it = 1; it < max_iter; ++it) {                                                            // :153
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v < nv) {
+                    const float w = dref * fast_rcpf(dn[v]);                                               // :166-169 (cumulative), common factor dref
+                    s[v] *= w * w;
+                    d[v] = dn[v];
+                }
+            }
+            float nn[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nn[k] = fmaf(s[v], G[v][k], nn[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rr[k] = fmaf(s[v], g[v][k], rr[k]);
+            }
+            const float c00 = nn[3] * nn[5] - nn[4] * nn[4], c01 = nn[2] * nn[4] - nn[1] * nn[5], c02 = nn[1] * nn[4] - nn[2] * nn[3];
+            const float c11 = nn[0] * nn[5] - nn[2] * nn[2], c12 = nn[1] * nn[2] - nn[0] * nn[4], c22 = nn[0] * nn[3] - nn[1] * nn[1];
+            const float inv = fast_rcpf(nn[0] * c00 + nn[1] * c01 + nn[2] * c02);
+            const float nx0 = (c00 * rr[0] + c01 * rr[1] + c02 * rr[2]) * inv, nx1 = (c01 * rr[0] + c11 * rr[1] + c12 * rr[2]) * inv,
+                        nx2 = (c02 * rr[0] + c12 * rr[1] + c22 * rr[2]) * inv;                             // :155
+            const float m0 = nx0 - dx[0], m1 = nx1 - dx[1], m2 = nx2 - dx[2];
+            dx[0] = nx0; dx[1] = nx1; dx[2] = nx2;
+            conv = true;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v < nv) {
+                    const float step = pz[v][0] * m0 + pz[v][1] * m1 + pz[v][2] * m2;                      // d_new - d_old, :158-162
+                    dn[v] = d[v] + step;
+                    if (!(fabsf(step) <= (float)tol)) conv = false;
+                }
+            }
+            if (conv) break;                                                                               // :163
+        }
+    }
+    x[0] += (double)dx[0]; x[1] += (double)dx[1]; x[2] += (double)dx[2];
+    bool all_front = true;
+    int code = 0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+            if (!(dn[v] > 0)) all_front = false;
+            if (dn[v] <= 0) code -= (1 << v);                                                              // :178-179
+        }
+    }
+    return all_front ? 1 : code;
+}
+
 // Homogeneous DLT for fp32-storage bulk batches: the right-singular vector of the smallest singular value of the 2V x 4 system
 // M is the eigenvector of the smallest eigenvalue of the 4 x 4 Gram matrix M^T M -- found by inverse iteration on its (shifted)
 // LDL^T factorisation instead of a Jacobi SVD of M.  The eigenvalue gap is enormous (lambda_4 / lambda_3 = noise^2), three
@@ -623,19 +757,20 @@ EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (
     scale2 = g[0][0] + g[1][1] + g[2][2] + g[3][3];
     const double shift = 1e-14 * scale2;                 // keeps the factorisation regular when the matches are exact (lambda_4 = 0)
     // LDL^T of (G + shift I), unit lower triangular L stored in the lower part
-    double L[4][4], D[4];
+    double L[4][4], D[4], Dv[4];                     // Dv: the pivots, D: their reciprocals
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         double dj = g[j][j] + shift;
 #pragma unroll
-        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * D[k];
-        D[j] = dj;
-        const double inv = 1.0 / dj;
+        for (int k = 0; k < j; ++k) dj -= L[j][k] * L[j][k] * Dv[k];
+        Dv[j] = dj;
+        D[j] = fast_rcp(dj);                             // (stored inverted: every later use divides)
+        const double inv = D[j];
 #pragma unroll
         for (int i = j + 1; i < 4; ++i) {
             double t = g[j][i];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k] * D[k];
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k] * Dv[k];
             L[i][j] = t * inv;
         }
     }
@@ -651,7 +786,7 @@ EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (
             y[i] = t;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] /= D[i];
+        for (int i = 0; i < 4; ++i) y[i] *= D[i];
 #pragma unroll
         for (int i = 3; i >= 0; --i) {                  // L^T z = y
             double t = y[i];
@@ -659,11 +794,12 @@ EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (
             for (int k = i + 1; k < 4; ++k) t -= L[k][i] * y[k];
             y[i] = t;
         }
-        const double nrm = 1.0 / sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+        const double nrm = fast_rsq(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) hv[i] = y[i] * nrm;
     }
-    x[0] = hv[0] / hv[3]; x[1] = hv[1] / hv[3]; x[2] = hv[2] / hv[3];                                      // triangulation.py:24
+    const double iw = fast_rcp(hv[3]);
+    x[0] = hv[0] * iw; x[1] = hv[1] * iw; x[2] = hv[2] * iw;                                               // triangulation.py:24
     const double mx = fmax(fabs(x[0]), fmax(fabs(x[1]), fabs(x[2])));
     return (mx <= 1.0e16) ? 1 : 0;                                                                         // :25
 }
@@ -690,23 +826,26 @@ template <typename S, int METHOD> struct TriCompute { typedef double type; };
 template <> struct TriCompute<float, TRI_LS> { typedef float type; };
 
 template <typename S, int NV, int METHOD>
-__global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ kps, int kstride, const S* __restrict__ Pm,
+__global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TRI_DLT) ? 4 : 1) void triangulate_kernel(const S* __restrict__ kps, int kstride, const S* __restrict__ Pm,
                                                           int G, int V, int J, double tol, int max_iter, S* __restrict__ X,
                                                           int* __restrict__ status) {
     typedef typename TriCompute<S, METHOD>::type T;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)G * J) return;
     const int g = (int)(t / J), j = (int)(t - (long long)g * J);
-    T u[NV][2], P[NV][12], x[3];
+    // inputs stay in the storage type for the mixed-precision iterative solver (it converts at every use: 56 registers instead of 112)
+    typedef typename std::conditional<METHOD == TRI_ITER && std::is_same<S, float>::value, float, T>::type TIN;
+    TIN u[NV][2], P[NV][12];
+    T x[3];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (v < V) {
             const long long s = (long long)v * G + g;                  // img_utils.py:197-202
             const S* kp = kps + (s * J + j) * kstride;
-            u[v][0] = (T)kp[0]; u[v][1] = (T)kp[1];
+            u[v][0] = (TIN)kp[0]; u[v][1] = (TIN)kp[1];
             const S* pp = Pm + s * 12;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) P[v][k] = (T)pp[k];
+            for (int k = 0; k < 12; ++k) P[v][k] = (TIN)pp[k];
         } else {
             u[v][0] = u[v][1] = 0;
 #pragma unroll
@@ -723,7 +862,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const S* __restrict__ 
         if constexpr (std::is_same<S, float>::value) st = tri_dlt_gram<NV>(u, P, V, x);       // bulk fp32 storage: Gram + inverse iteration
         else st = tri_dlt<NV>(u, P, V, x);
     } else if constexpr (METHOD == TRI_ITER && std::is_same<S, float>::value) {
-        st = tri_iterative_ne<NV>(u, P, V, tol, max_iter, x);                                 // bulk fp32 storage: 3 x 3 normal equations
+        st = tri_iterative_mixed<NV, TIN>(u, P, V, tol, max_iter, x);                           // bulk fp32 storage: float64 first round, float32 corrections
     } else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
     X[3 * t] = (S)x[0]; X[3 * t + 1] = (S)x[1]; X[3 * t + 2] = (S)x[2];
     if (status) status[t] = st;

@@ -51,6 +51,29 @@ def test_device_triangulators_match_reference_golden(golden, hostlib, noise):
             np.testing.assert_array_equal(st.astype(bool), g[tag + "/eigen_status"])
 
 
+@pytest.mark.parametrize("noise", [0, 2])
+def test_bulk_variants_match_reference_golden(golden, hostlib, noise):
+    """The fp32-storage (bulk) variants of csrc/selfsup.hip compiled for the host and fed the golden float64 inputs: the mixed-precision
+    iterative solver (float64 first round, float32 corrections with the stopping rule on the depth difference) must land within the fp32
+    path's 1e-2 mm of the live reference AND reproduce its status codes; the normal-equation and Gram variants are float64 throughout."""
+    g = golden("triangulation")
+    u, ps = g["u/noise%d" % noise], g["P"]
+    worst = 0.0
+    for va, vb in ((0, 1), (0, 3), (1, 2)):
+        for grp in range(3):
+            tag = "noise%d/v%d%d/g%d" % (noise, va, vb, grp)
+            x, st = _tri(hostlib, 3, u[va, grp], u[vb, grp], ps[va], ps[vb])
+            worst = max(worst, float(np.abs(x - g[tag + "/iter_x"]).max()))
+            np.testing.assert_allclose(x, g[tag + "/iter_x"], atol=5e-3)
+            np.testing.assert_array_equal(st, g[tag + "/iter_status"])
+            x, st = _tri(hostlib, 5, u[va, grp], u[vb, grp], ps[va], ps[vb])
+            np.testing.assert_allclose(x, g[tag + "/iter_x"], atol=1e-5)
+            np.testing.assert_array_equal(st, g[tag + "/iter_status"])
+            x, st = _tri(hostlib, 4, u[va, grp], u[vb, grp], ps[va], ps[vb])
+            np.testing.assert_allclose(x, g[tag + "/eigen_x"], atol=1e-4)
+    print("mixed-precision iterative solver: worst |x - reference| = %.2e mm (noise %d px)" % (worst, noise))
+
+
 def test_device_status_codes_behind_cameras(golden, hostlib):
     g = golden("triangulation")
     x, st = _tri(hostlib, 0, g["behind/u0"], g["behind/u1"], g["P"][0], g["P"][1])
