@@ -46,6 +46,8 @@ def parse_args():
                     "into the flat buckets, no collective) to price its overhead on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ss-leg", action="store_true", help="skip the extra configs[2] (self-supervised) measurement that rides along")
+    ap.add_argument("--no-loader-leg", action="store_true", help="skip the extra measurement with the GPU input pipeline in the step "
+                    "(synthetic uint8 frames in HBM -> augmentation draws, crop, occlusion, normalisation -> the same training step)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     return ap.parse_args()
 
@@ -394,6 +396,45 @@ def main():
                                % (args.views, args.batch), "value": round(args.batch * world * args.steps / ss_elapsed, 2), "unit": "images/s",
                    "ms_per_step": round(ss_elapsed / args.steps * 1e3, 3), "final_loss": round(float(ss_loss.item()), 6)}
 
+    # the same step fed by the GPU input pipeline: uint8 BGR frames resident in HBM, per batch the reference's augmentation
+    # draws + label arithmetic on the host and ONE crop / occlusion / normalisation launch (dataset/synthetic_frames.py); rides along like the SS leg
+    loader_line = None
+    if args.workload == "fs" and not use_graph and not args.no_loader_leg and args.batch % args.views == 0:
+        from epipolarpose_amd.dataset.synthetic_frames import FramePatchLoader, SyntheticFrames
+        n_grp = args.batch // args.views
+        frames = SyntheticFrames(n_group=2 * n_grp, n_view=args.views, num_joints=args.joints, seed=7 + rank, device=device)
+        loader = FramePatchLoader(frames, groups_per_batch=n_grp, patch=args.image, augment=True, occlusion=True, seed=3 + rank,
+                                  dtype=torch.float32 if args.fp32 else torch.bfloat16)
+        groups = [list(range(n_grp)), list(range(n_grp, 2 * n_grp))]
+
+        def loader_step(i):
+            data, lab, wt, _ = loader.batch(groups[i % 2])
+            return train_step(model, criterion, optimizer, data, lab, wt, autocast=not args.fp32, grad_sync=grad_sync)
+        for i in range(2):
+            loader_step(i)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(3):
+            loader.batch(groups[i % 2])
+        host_batch = (time.perf_counter() - th) / 3.0
+        torch.cuda.synchronize()
+        barrier()
+        tl = time.perf_counter()
+        for i in range(args.steps):
+            l_loss = loader_step(i)
+        torch.cuda.synchronize()
+        barrier()
+        l_elapsed = time.perf_counter() - tl
+        if world > 1:
+            t = torch.tensor([l_elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            l_elapsed = float(t.item())
+        loader_line = {"workload": "configs[1] fed by the GPU input pipeline: %d uint8 1000x1000 frames in HBM, augmentation + occlusion + crop + "
+                                   "normalisation per step, batch=%d/GPU" % (2 * args.batch, args.batch),
+                       "value": round(args.batch * world * args.steps / l_elapsed, 2), "unit": "images/s",
+                       "ms_per_step": round(l_elapsed / args.steps * 1e3, 3), "host_ms_per_batch_pipeline_only": round(host_batch * 1e3, 3),
+                       "final_loss": round(float(l_loss.item()), 6)}
+
     if rank == 0:
         global_batch = args.batch * world
         elem = 4 if args.fp32 else 2
@@ -420,6 +461,7 @@ def main():
                        "host_blocked_in_hip_ms_per_step": round(max(0.0, host_elapsed / args.steps - host_burst) * 1e3, 3)},
             "roofline": roofline,
             "workload_ss": ss_line,
+            "workload_loader": loader_line,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, scenes)

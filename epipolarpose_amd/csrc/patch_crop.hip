@@ -24,7 +24,38 @@ struct PatchArgs {
     void* out;
     int out_bf16, out_nhwc;
     int B, PH, PW;
+    // synthetic occlusion (lib/utils/augmentation.py:61-114), applied to the uint8 RGB patch before the colour stage (img_utils.py:271-272)
+    const unsigned char* occ_bank;     // RGBA bytes of every occluder image, or null
+    const long long* occ_offset;       // [N] byte offset of occluder n
+    const int* occ_hw;                 // [N][2] (height, width) at native size
+    const int* occ_place;              // [B][max_occ][5]: occluder index (-1: end of the sample's list), pasted width, height, x0, y0 (top-left in the patch)
+    int max_occ;
 };
+
+// One pixel of occluder image `src` [sh][sw][4] resized to (dw, dh) <= (sw, sh) by box-filter averaging (cv2.resize INTER_AREA restated with
+// exact integer arithmetic; the test oracle restates the same rule): destination pixel (px, py) covers [px*sw, (px+1)*sw) x [py*sh, (py+1)*sh) in
+// units of 1/dw x 1/dh source pixels.
+__device__ __forceinline__ void occluder_pixel(const unsigned char* __restrict__ src, int sh, int sw, int dh, int dw, int px, int py, int (&rgba)[4]) {
+    if (dw == sw && dh == sh) {
+        const unsigned char* q = src + ((long long)py * sw + px) * 4;
+        rgba[0] = q[0]; rgba[1] = q[1]; rgba[2] = q[2]; rgba[3] = q[3];
+        return;
+    }
+    long long acc[4] = {0, 0, 0, 0};
+    const int ylo = py * sh, yhi = ylo + sh, xlo = px * sw, xhi = xlo + sw;
+    for (int ky = ylo / dh; ky <= (yhi - 1) / dh; ++ky) {
+        const int wy = min(yhi, (ky + 1) * dh) - max(ylo, ky * dh);
+        for (int kx = xlo / dw; kx <= (xhi - 1) / dw; ++kx) {
+            const int w = wy * (min(xhi, (kx + 1) * dw) - max(xlo, kx * dw));
+            const unsigned char* q = src + ((long long)ky * sw + kx) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += (long long)w * q[c];
+        }
+    }
+    const long long den = (long long)sh * sw;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) rgba[c] = (int)((2 * acc[c] + den) / (2 * den));
+}
 
 __device__ __forceinline__ int round_half_even(double v) { return (int)__double2ll_rn(v); }   // cvRound / saturate_cast<int>(double)
 
@@ -91,12 +122,36 @@ __global__ __launch_bounds__(256) void patch_crop_kernel(PatchArgs p) {
                 for (int c = 0; c < 3; ++c) acc[c] += (int)px[c] * w[k1 * 2 + k2];
             }
         }
-    float o[3];
+    int rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {            // output channel c = RGB; source channel 2 - c (frames are BGR: img_utils.py:269)
-        int v = (acc[2 - c] + (1 << 14)) >> 15;
-        v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        float f = (float)v;
+        const int v = (acc[2 - c] + (1 << 14)) >> 15;
+        rgb[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+    if (p.occ_bank) {
+        // paste_over (augmentation.py:84-114), occluder after occluder: float32 alpha blend, the assignment into the uint8 image truncates.
+        // Separate roundings for every product and sum, as NumPy evaluates them (no fused multiply-add).
+        const int* pl = p.occ_place + (long long)b * p.max_occ * 5;
+        for (int k = 0; k < p.max_occ; ++k) {
+            const int idx = pl[5 * k];
+            if (idx < 0) break;
+            const int dw = pl[5 * k + 1], dh = pl[5 * k + 2], ox = x - pl[5 * k + 3], oy = y - pl[5 * k + 4];
+            if ((unsigned)ox >= (unsigned)dw || (unsigned)oy >= (unsigned)dh) continue;
+            int rgba[4];
+            occluder_pixel(p.occ_bank + p.occ_offset[idx], p.occ_hw[2 * idx], p.occ_hw[2 * idx + 1], dh, dw, ox, oy, rgba);
+            const float alpha = __fdiv_rn((float)rgba[3], 255.f), rest = __fsub_rn(1.f, alpha);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t1 = alpha * (float)rgba[c], t2 = rest * (float)rgb[c];
+                asm volatile("" : "+v"(t1), "+v"(t2));              // two rounded products, then a rounded sum: keep the compiler from fusing them
+                rgb[c] = (int)(t1 + t2);
+            }
+        }
+    }
+    float o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float f = (float)rgb[c];
         if (p.color_scale) f = fminf(fmaxf(f * p.color_scale[3 * b + c], 0.f), 255.f);      // img_utils.py:276
         if (p.normalize) f = (f - p.mean[c]) / p.inv_std_is_std[c];                          // :277-278
         o[c] = f;
@@ -118,7 +173,16 @@ __global__ __launch_bounds__(256) void patch_crop_kernel(PatchArgs p) {
 extern "C" int epi_crop_patches(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
                                 const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
                                 int patch_h, int patch_w, void* out, int out_dtype, int out_layout, epi_stream_t stream) {
+    return epi_crop_patches_occluded(frames, frame_offset, frame_hw, trans, do_flip, color_scale, mean_host, std_host, B, patch_h, patch_w, nullptr, nullptr,
+                                     nullptr, nullptr, 0, out, out_dtype, out_layout, stream);
+}
+
+extern "C" int epi_crop_patches_occluded(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
+                                         const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
+                                         int patch_h, int patch_w, const void* occ_bank, const long long* occ_offset, const int* occ_hw,
+                                         const int* occ_place, int max_occ, void* out, int out_dtype, int out_layout, epi_stream_t stream) {
     if (!frames || !frame_offset || !frame_hw || !trans || !out || B <= 0 || patch_h <= 0 || patch_w <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (occ_bank && (!occ_offset || !occ_hw || !occ_place || max_occ <= 0)) return EPI_ERR_INVALID_ARGUMENT;
     if ((out_dtype != EPI_F32 && out_dtype != EPI_BF16) || (out_layout != EPI_NCHW && out_layout != EPI_NHWC)) return EPI_ERR_UNSUPPORTED;
     if ((mean_host == nullptr) != (std_host == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
     epi::PatchArgs a = {};
@@ -126,6 +190,7 @@ extern "C" int epi_crop_patches(const void* frames, const long long* frame_offse
     a.color_scale = color_scale; a.normalize = mean_host ? 1 : 0;
     for (int c = 0; c < 3; ++c) { a.mean[c] = mean_host ? mean_host[c] : 0.f; a.inv_std_is_std[c] = std_host ? std_host[c] : 1.f; }
     a.out = out; a.out_bf16 = out_dtype == EPI_BF16; a.out_nhwc = out_layout == EPI_NHWC; a.B = B; a.PH = patch_h; a.PW = patch_w;
+    a.occ_bank = (const unsigned char*)occ_bank; a.occ_offset = occ_offset; a.occ_hw = occ_hw; a.occ_place = occ_place; a.max_occ = occ_bank ? max_occ : 0;
     const dim3 grid((unsigned)((patch_h * patch_w + 255) / 256), (unsigned)B);
     hipLaunchKernelGGL(epi::patch_crop_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     EPI_CHECK_LAUNCH();

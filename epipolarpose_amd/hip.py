@@ -95,6 +95,8 @@ _SIGNATURES = {
     "epi_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "epi_crop_patches": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i, _i, _i, _vp,
                               _i, _i, _vp]),
+    "epi_crop_patches_occluded": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _i, _i, _i, _vp,
+                                       _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "epi_evaluate_poses": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -879,10 +881,12 @@ def evaluate_poses(pred_img, gt_img, pelvis_z, fl, c_p, root, j14):
 
 
 def crop_patches(frames, frame_offset, frame_hw, trans, patch_h, patch_w, do_flip=None, color_scale=None, mean=None, std=None,
-                 dtype=torch.float32, channels_last=False):
+                 dtype=torch.float32, channels_last=False, occluders=None, placements=None):
     """Batched crop + warp + normalise (``epi_crop_patches``).  frames: uint8 CUDA tensor holding the BGR frames back to back;
     frame_offset int64 [B]; frame_hw int32 [B, 2]; trans float64 [B, 2, 3] (forward affine frame -> patch).  -> [B, 3, ph, pw]
-    (logical NCHW; channels_last memory when asked), RGB order.  Reference: img_utils.py:114-127,265-279."""
+    (logical NCHW; channels_last memory when asked), RGB order.  Reference: img_utils.py:114-127,265-279.
+    ``occluders`` = (bank uint8 CUDA bytes of the RGBA occluder images, offsets int64 [N], hw int32 [N, 2]) and ``placements`` int32
+    [B, max_occ, 5] (index | -1, pasted w, h, x0, y0) add the synthetic-occlusion stage (augmentation.py:61-114, ``epi_crop_patches_occluded``)."""
     lib = load()
     _dev(frames, torch.uint8, "frames")
     frame_offset = _dev(frame_offset, torch.int64, "frame_offset").contiguous()
@@ -897,6 +901,19 @@ def crop_patches(frames, frame_offset, frame_hw, trans, patch_h, patch_w, do_fli
                       memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     m3 = (ctypes.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
     s3 = (ctypes.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+    if occluders is not None and placements is not None:
+        bank, occ_off, occ_hw = occluders
+        _dev(bank, torch.uint8, "occluder bank")
+        occ_off = _dev(occ_off, torch.int64, "occluder offsets").contiguous()
+        occ_hw = _dev(occ_hw, torch.int32, "occluder sizes").contiguous()
+        placements = _dev(placements, torch.int32, "placements").contiguous()
+        if placements.dim() != 3 or placements.shape[0] != b or placements.shape[2] != 5:
+            raise ValueError("placements must be int32 [B, max_occ, 5]")
+        _check(lib.epi_crop_patches_occluded(_ptr(frames), _ptr(frame_offset), _ptr(frame_hw), _ptr(trans), _ptr(do_flip), _ptr(color_scale), m3, s3,
+                                             b, patch_h, patch_w, _ptr(bank), _ptr(occ_off), _ptr(occ_hw), _ptr(placements), placements.shape[1],
+                                             _ptr(out), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32,
+                                             EPI_NHWC if channels_last else EPI_NCHW, _stream()), "epi_crop_patches_occluded")
+        return out
     _check(lib.epi_crop_patches(_ptr(frames), _ptr(frame_offset), _ptr(frame_hw), _ptr(trans), _ptr(do_flip), _ptr(color_scale), m3, s3, b,
                                 patch_h, patch_w, _ptr(out), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32,
                                 EPI_NHWC if channels_last else EPI_NCHW, _stream()), "epi_crop_patches")

@@ -1,0 +1,87 @@
+"""Synthetic-occlusion augmentation -- mirror of the reference's ``lib/utils/augmentation.py``.
+
+The reference pastes segmented Pascal-VOC objects over the person patch (``load_occluders`` :9-58, ``occlude_with_objects`` :61-81,
+``paste_over`` :84-114, ``resize_by_factor`` :117-123).  There is no Pascal VOC on the build / GPU boxes, so ``load_occluders`` falls back
+to procedural RGBA occluders with the reference's alpha convention (255 inside the object, 192 on the ring its 8 x 8 erosion removes,
+0 outside) and the same half-size down-scaling; everything downstream is the reference's pipeline: the random draws are made on the host
+in the reference's order (``draw_occlusion``), the resize (box-filter average = ``cv2.resize(INTER_AREA)`` restated) and the float32
+alpha blend with uint8 truncation run inside the batched crop kernel (``epi_crop_patches_occluded``, csrc/patch_crop.hip).
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+MAX_OCCLUDERS = 7            # occlude_with_objects draws count = randint(1, 8)
+
+
+def _procedural_occluder(rng):
+    """One RGBA object: a filled super-ellipse with a textured colour; alpha 255 inside, 192 on the border ring (load_occluders :44-49
+    erodes the mask with an 8 x 8 ellipse and sets the removed ring to 192), 0 outside; then halved like ``resize_by_factor(.., 0.5)`` (:52)."""
+    h, w = int(rng.integers(80, 260)), int(rng.integers(80, 260))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    p = rng.uniform(1.5, 4.0)
+    r = (np.abs((xx - (w - 1) / 2) / (w / 2)) ** p + np.abs((yy - (h - 1) / 2) / (h / 2)) ** p) ** (1.0 / p)
+    inside = r <= 1.0
+    ring = inside & (r > 1.0 - 8.0 / min(h, w))
+    base = rng.integers(30, 226, size=3).astype(np.float64)
+    stripes = 25.0 * np.sin(xx * rng.uniform(0.05, 0.4) + yy * rng.uniform(0.05, 0.4) + rng.uniform(0, 6.28))
+    noise = rng.normal(0, 8.0, size=(h, w))
+    rgb = np.clip(base[None, None, :] + (stripes + noise)[:, :, None], 0, 255)
+    alpha = np.where(ring, 192, np.where(inside, 255, 0))
+    img = np.concatenate([rgb, alpha[:, :, None]], axis=2).astype(np.uint8)
+    # half size, as the reference stores its occluders: 2 x 2 box average (rounded half up)
+    h2, w2 = h // 2, w // 2
+    q = img[:2 * h2, :2 * w2].reshape(h2, 2, w2, 2, 4).astype(np.int32).sum(axis=(1, 3))
+    return ((q + 2) // 4).astype(np.uint8)
+
+
+def load_occluders(pascal_voc_root_path=None, count=16, seed=0):
+    """augmentation.py:9-58.  Without a Pascal-VOC tree (none on the boxes) -> ``count`` procedural occluders, seeded."""
+    if pascal_voc_root_path and os.path.isdir(os.path.join(str(pascal_voc_root_path), "Annotations")):
+        raise NotImplementedError("reading Pascal VOC needs cv2 / PIL, which are not in this image; procedural occluders are used instead")
+    rng = np.random.default_rng(seed)
+    return [_procedural_occluder(rng) for _ in range(count)]
+
+
+class OccluderBank:
+    """The occluder images in device memory, as ``epi_crop_patches_occluded`` reads them."""
+
+    def __init__(self, occluders, device):
+        self.hw_host = np.array([[o.shape[0], o.shape[1]] for o in occluders], np.int32)
+        sizes = [o.size for o in occluders]
+        self.offset_host = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        flat = np.concatenate([np.ascontiguousarray(o, dtype=np.uint8).reshape(-1) for o in occluders])
+        self.bank = torch.from_numpy(flat).to(device)
+        self.offset = torch.from_numpy(self.offset_host).to(device)
+        self.hw = torch.from_numpy(self.hw_host).to(device)
+        self.count = len(occluders)
+
+    def tensors(self):
+        return self.bank, self.offset, self.hw
+
+
+def draw_occlusion(patch_hw, bank_hw, np_rng=np.random, py_rng=random):
+    """The random draws of ``occlude_with_objects`` (augmentation.py:61-81) in the reference's order, turned into what the kernel needs:
+    int32 [MAX_OCCLUDERS, 5] rows (occluder index | -1, pasted width, pasted height, x0, y0)."""
+    out = np.full((MAX_OCCLUDERS, 5), -1, np.int32)
+    width_height = np.asarray([patch_hw[1], patch_hw[0]])
+    im_scale_factor = min(width_height) / 256
+    count = np_rng.randint(1, 8)
+    for k in range(count):
+        idx = py_rng.choice(range(len(bank_hw)))
+        factor = np_rng.uniform(0.2, 1.0) * im_scale_factor
+        center = np_rng.uniform([0, 0], width_height)
+        h, w = int(bank_hw[idx][0]), int(bank_hw[idx][1])
+        if factor <= 1.0:                                    # resize_by_factor :121: new size = round(size * factor), INTER_AREA
+            w, h = (int(v) for v in np.round(np.array([w, h]) * factor).astype(int))
+        if w < 1 or h < 1:
+            continue
+        c = np.round(center).astype(np.int32)                # paste_over :101-103
+        out[k] = (idx, w, h, int(c[0]) - w // 2, int(c[1]) - h // 2)
+    # rows skipped above would end the kernel's list early: compact
+    keep = out[out[:, 0] >= 0]
+    out[:] = -1
+    out[:len(keep)] = keep
+    return out

@@ -159,3 +159,78 @@ def generate_patch_image_cv(cvimg, c_x, c_y, bb_width, bb_height, patch_width, p
 def convert_cvimg_to_tensor(cvimg, occlusion_aug=True):
     """img_utils.py:130-138: HWC -> CHW float32 (no colour reordering there)."""
     return np.transpose(np.asarray(cvimg), (2, 0, 1)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Augmentation parameters and the per-sample pipeline (img_utils.py:17-39, 246-298), batched: host-side draws and label
+# arithmetic (a few hundred bytes per sample), image work on the device.
+# ------------------------------------------------------------------------------------------------------------------
+import random as _random  # noqa: E402
+
+
+class _AugmentConfig(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def get_default_augment_config():
+    """img_utils.py:17-26."""
+    config = _AugmentConfig()
+    config.scale_factor = 0.25
+    config.rot_factor = 30
+    config.color_factor = 0.2
+    config.do_flip_aug = False
+    config.rot_aug_rate = 0.6       # possibility to rot aug
+    config.flip_aug_rate = 0.5      # possibility to flip aug
+    return config
+
+
+def do_augmentation(np_rng=np.random, py_rng=_random):
+    """img_utils.py:29-39: -> (scale, rot, do_flip, color_scale).  Draws from the ``numpy.random`` / ``random`` module states like the
+    reference (pass a ``numpy.random.RandomState`` / ``random.Random`` pair for a private, seeded stream); the calls are made in the
+    reference's order: the rotation's ``random()`` gate before its ``randn()``, no flip draw while ``do_flip_aug`` is off."""
+    aug_config = get_default_augment_config()
+    scale = np.clip(np_rng.randn(), -1.0, 1.0) * aug_config.scale_factor + 1.0
+    rot = np.clip(np_rng.randn(), -2.0, 2.0) * aug_config.rot_factor if py_rng.random() <= aug_config.rot_aug_rate else 0
+    do_flip = aug_config.do_flip_aug and py_rng.random() <= aug_config.flip_aug_rate
+    c_up = 1.0 + aug_config.color_factor
+    c_low = 1.0 - aug_config.color_factor
+    color_scale = [py_rng.uniform(c_low, c_up), py_rng.uniform(c_low, c_up), py_rng.uniform(c_low, c_up)]
+    return scale, rot, do_flip, color_scale
+
+
+def patch_affines_batch(c_x, c_y, bb_width, bb_height, patch_width, patch_height, scale, rot):
+    """``gen_trans_from_patch_cv(..., inv=False)`` (img_utils.py:72-105) for a whole batch: float64 [B, 2, 3].  The three-point affine in
+    closed form (the patch-side triple is axis aligned) with the reference's float32 roundings of the points, vectorised."""
+    c_x, c_y, bb_width, bb_height, scale, rot = (np.asarray(v, np.float64) for v in (c_x, c_y, bb_width, bb_height, scale, rot))
+    rad = np.pi * rot / 180
+    sn, cs = np.sin(rad), np.cos(rad)
+    f32 = lambda v: np.asarray(v, np.float64).astype(np.float32).astype(np.float64)
+    hh = f32((bb_height * scale * 0.5).astype(np.float32))      # np.array([0, src_height * scale * 0.5], dtype=np.float32)
+    hw = f32((bb_width * scale * 0.5).astype(np.float32))
+    down = np.stack([f32(0.0 * cs - hh * sn), f32(0.0 * sn + hh * cs)], axis=1)              # rotate_2d, rounded to float32
+    right = np.stack([f32(hw * cs - 0.0 * sn), f32(hw * sn + 0.0 * cs)], axis=1)
+    center = np.stack([c_x, c_y], axis=1)
+    s0, s1, s2 = f32(center), f32(center + down), f32(center + right)
+    dcx, dcy, dhw, dhh = f32(patch_width * 0.5), f32(patch_height * 0.5), f32(patch_width * 0.5), f32(patch_height * 0.5)
+    ex, ey = (s2 - s0) / dhw, (s1 - s0) / dhh                   # images of the patch axes in the frame
+    inv = np.zeros((len(c_x), 2, 3))
+    inv[:, :, 0], inv[:, :, 1] = ex, ey
+    inv[:, :, 2] = s0 - ex * dcx - ey * dcy
+    lin = np.linalg.inv(inv[:, :, :2])
+    out = np.zeros_like(inv)
+    out[:, :, :2] = lin
+    out[:, :, 2] = -np.einsum("bij,bj->bi", lin, inv[:, :, 2])
+    return out
+
+
+def patch_labels_batch(joints, joints_vis, trans, bb_width, scale, patch_width, patch_height, rect_3d_width, depth_in_image=False):
+    """Steps 4-5 of get_single_patch_sample (img_utils.py:281-296) + generate_joint_location_label (integral_loss.py:170-177), batched:
+    joints [B, J, 3] (u, v in the frame, root-relative depth in mm) -> (label f32 [B, 3J], weight f32 [B, 3J])."""
+    joints = np.asarray(joints, np.float64)
+    xy = np.einsum("bij,bkj->bki", trans[:, :, :2], joints[:, :, :2]) + trans[:, None, :, 2]
+    ref = np.asarray(bb_width if depth_in_image else rect_3d_width, np.float64) * np.asarray(scale, np.float64)
+    z = joints[:, :, 2] / np.reshape(ref, (-1, 1)) * patch_width
+    label = np.stack([xy[:, :, 0] / patch_width - 0.5, xy[:, :, 1] / patch_height - 0.5, z / patch_width], axis=2)
+    b = len(joints)
+    return label.reshape(b, -1).astype(np.float32), np.asarray(joints_vis, np.float64).reshape(b, -1).astype(np.float32)

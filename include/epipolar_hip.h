@@ -385,6 +385,18 @@ int epi_maxpool3x3s2_bwd(const void* dy, const void* pos, void* dx, int B, int H
 int epi_crop_patches(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
                      const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
                      int patch_h, int patch_w, void* out, int out_dtype, int out_layout, epi_stream_t stream);
+/* The same with the synthetic-occlusion augmentation (lib/utils/augmentation.py:61-114 occlude_with_objects / paste_over, applied to the
+ * uint8 RGB patch between the warp and the colour stage, img_utils.py:271-272):
+ *   occ_bank    device bytes of N RGBA occluder images (alpha 255 inside, 192 on the border ring, 0 outside, as load_occluders builds them),
+ *               occluder n at occ_bank + occ_offset[n], native size occ_hw[n] = (h, w)
+ *   occ_place   [B][max_occ][5] int32 per sample, in pasting order: occluder index (-1 ends the list), pasted width and height (<= native:
+ *               cv2.resize INTER_AREA restated as an exact box-filter average), top-left corner (x0, y0) in the patch (may be outside)
+ * The random draws (count, choice, scale, centre) stay with the caller (dataset/synthetic_frames.py, in the reference's order).  The
+ * reference's occluders come from Pascal VOC (not on the boxes): the bank holds whatever RGBA images the caller supplies. */
+int epi_crop_patches_occluded(const void* frames, const long long* frame_offset, const int* frame_hw, const double* trans,
+                              const int* do_flip, const float* color_scale, const float* mean_host, const float* std_host, int B,
+                              int patch_h, int patch_w, const void* occ_bank, const long long* occ_offset, const int* occ_hw,
+                              const int* occ_place, int max_occ, void* out, int out_dtype, int out_layout, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pose evaluation -- replaces the per-sample loop of H36M_Integral.evaluate

@@ -104,3 +104,129 @@ def normalized_patch(cvimg, c_x, c_y, bb_width, bb_height, patch_width, patch_he
         if mean is not None and std is not None:
             out[c] = (out[c] - np.float32(mean[c])) / np.float32(std[c])
     return out, trans
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Augmentation parameters, synthetic occlusion and the whole per-sample pipeline (round 3)
+#   lib/utils/img_utils.py:17-39 (get_default_augment_config, do_augmentation), :246-298 (get_single_patch_sample),
+#   lib/utils/augmentation.py:61-123 (occlude_with_objects, paste_over, resize_by_factor).
+# The reference pastes Pascal-VOC objects (load_occluders, :9-58: needs that dataset); here the occluders are whatever RGBA
+# images the caller supplies (epipolarpose_amd/dataset/synthetic_frames.py makes procedural ones with the reference's alpha
+# convention: 255 inside, 192 on the eroded border ring, 0 outside).
+# ``cv2.resize(..., INTER_AREA)`` is third-party code that is not installed: restated as the exact box-filter average over the
+# source area each destination pixel covers (integer arithmetic: coverage in units of 1 / (dst_w * dst_h) source pixels, rounded
+# half up) -- **parity unpinned** like the warpAffine layer.  Up-scaling (factor > 1: patches larger than 256 px) is not restated:
+# the occluder is pasted at its native size.
+# ------------------------------------------------------------------------------------------------------------------
+def do_augmentation(np_rng, py_rng, scale_factor=0.25, rot_factor=30, color_factor=0.2, do_flip_aug=False, rot_aug_rate=0.6,
+                    flip_aug_rate=0.5):
+    """img_utils.py:29-39 with the generators made explicit: ``np_rng`` stands for the ``numpy.random`` module state (``randn``),
+    ``py_rng`` for the ``random`` module state (``random``, ``uniform``); the calls are made in the reference's order (a
+    conditional expression evaluates its condition first, ``and`` short-circuits)."""
+    scale = np.clip(np_rng.randn(), -1.0, 1.0) * scale_factor + 1.0
+    rot = np.clip(np_rng.randn(), -2.0, 2.0) * rot_factor if py_rng.random() <= rot_aug_rate else 0
+    do_flip = do_flip_aug and py_rng.random() <= flip_aug_rate
+    c_up, c_low = 1.0 + color_factor, 1.0 - color_factor
+    color_scale = [py_rng.uniform(c_low, c_up), py_rng.uniform(c_low, c_up), py_rng.uniform(c_low, c_up)]
+    return scale, rot, do_flip, color_scale
+
+
+def resize_area(im, new_size):
+    """uint8 [h, w, C] -> uint8 [nh, nw, C], (nw, nh) = new_size <= (w, h): box-filter average, exact integer arithmetic."""
+    im = np.asarray(im, np.uint8)
+    sh, sw, ch = im.shape
+    dw, dh = int(new_size[0]), int(new_size[1])
+    assert 1 <= dw <= sw and 1 <= dh <= sh
+
+    def weights(s, d):
+        # destination pixel i covers [i*s, (i+1)*s) in units of 1/d source pixels; source pixel k covers [k*d, (k+1)*d)
+        w = np.zeros((d, s), np.int64)
+        for i in range(d):
+            lo, hi = i * s, (i + 1) * s
+            for k in range(lo // d, (hi - 1) // d + 1):
+                w[i, k] = min(hi, (k + 1) * d) - max(lo, k * d)
+        return w
+    wy, wx = weights(sh, dh), weights(sw, dw)                      # rows sum to sh / sw
+    acc = np.einsum("ik,kjc,lj->ilc", wy, im.astype(np.int64), wx)
+    den = sh * sw
+    return ((2 * acc + den) // (2 * den)).astype(np.uint8)
+
+
+def resize_by_factor(im, factor):
+    """augmentation.py:117-123 for factor <= 1 (INTER_AREA); factor > 1 returns the image unchanged (see the section header)."""
+    new_size = tuple(np.round(np.array([im.shape[1], im.shape[0]]) * factor).astype(int))
+    if factor > 1.0 or new_size[0] < 1 or new_size[1] < 1:
+        return im.copy() if factor > 1.0 else im[:0, :0].copy()
+    return resize_area(im, new_size)
+
+
+def paste_over(im_src, im_dst, center):
+    """augmentation.py:84-114: alpha-blend the RGBA ``im_src`` onto the uint8 RGB ``im_dst`` in place (float32 arithmetic, the
+    assignment into the uint8 array truncates)."""
+    width_height_src = np.asarray([im_src.shape[1], im_src.shape[0]])
+    width_height_dst = np.asarray([im_dst.shape[1], im_dst.shape[0]])
+    center = np.round(center).astype(np.int32)
+    raw_start_dst = center - width_height_src // 2
+    raw_end_dst = raw_start_dst + width_height_src
+    start_dst = np.clip(raw_start_dst, 0, width_height_dst)
+    end_dst = np.clip(raw_end_dst, 0, width_height_dst)
+    region_dst = im_dst[start_dst[1]:end_dst[1], start_dst[0]:end_dst[0]]
+    start_src = start_dst - raw_start_dst
+    end_src = width_height_src + (end_dst - raw_end_dst)
+    region_src = im_src[start_src[1]:end_src[1], start_src[0]:end_src[0]]
+    color_src = region_src[..., 0:3]
+    alpha = region_src[..., 3:].astype(np.float32) / 255
+    im_dst[start_dst[1]:end_dst[1], start_dst[0]:end_dst[0]] = (alpha * color_src + (1 - alpha) * region_dst)
+
+
+def draw_occlusion(im_shape, n_occluders, np_rng, py_rng):
+    """The random draws of occlude_with_objects (augmentation.py:61-81) in the reference's order: -> list of (occluder index,
+    scale factor, centre [x, y] float64).  ``py_rng.choice`` over ``range(n)`` consumes the generator exactly as
+    ``random.choice(list of n)`` does."""
+    width_height = np.asarray([im_shape[1], im_shape[0]])
+    im_scale_factor = min(width_height) / 256
+    count = np_rng.randint(1, 8)
+    out = []
+    for _ in range(count):
+        idx = py_rng.choice(range(n_occluders))
+        random_scale_factor = np_rng.uniform(0.2, 1.0)
+        center = np_rng.uniform([0, 0], width_height)
+        out.append((idx, random_scale_factor * im_scale_factor, center))
+    return out
+
+
+def occlude_with_objects(im, occluders, np_rng, py_rng):
+    """augmentation.py:61-81."""
+    result = im.copy()
+    for idx, factor, center in draw_occlusion(im.shape, len(occluders), np_rng, py_rng):
+        paste_over(im_src=resize_by_factor(occluders[idx], factor), im_dst=result, center=center)
+    return result
+
+
+def single_patch_sample(cvimg, center_x, center_y, width, height, joints, joints_vis, patch_width, patch_height, rect_3d_width, mean, std,
+                        do_augment, np_rng, py_rng, occluders=None, depth_in_image=False):
+    """img_utils.py:246-298 (get_single_patch_sample) without the flip branch's joint swapping (``do_flip_aug`` is False in
+    get_default_augment_config): -> (img_patch f32 [3, ph, pw], label f32 [3J], label_weight f32 [3J], scale, rot)."""
+    if do_augment:
+        scale, rot, do_flip, color_scale = do_augmentation(np_rng, py_rng)
+    else:
+        scale, rot, do_flip, color_scale = 1.0, 0, False, [1.0, 1.0, 1.0]
+    assert not do_flip
+    patch, trans = generate_patch_image(cvimg, center_x, center_y, width, height, patch_width, patch_height, do_flip, scale, rot)
+    image = patch[:, :, ::-1]
+    if occluders:
+        image = occlude_with_objects(image, occluders, np_rng, py_rng)
+    out = np.transpose(image, (2, 0, 1)).astype(np.float32)
+    for c in range(3):
+        out[c] = np.clip(out[c] * np.float32(color_scale[c]), 0, 255)
+        if mean is not None and std is not None:
+            out[c] = (out[c] - np.float32(mean[c])) / np.float32(std[c])
+    joints = np.array(joints, np.float64)
+    for n_jt in range(len(joints)):
+        joints[n_jt, 0:2] = trans @ np.array([joints[n_jt, 0], joints[n_jt, 1], 1.0])
+        joints[n_jt, 2] = joints[n_jt, 2] / ((width if depth_in_image else rect_3d_width) * scale) * patch_width
+    label = joints.copy()                                            # integral_loss.py:170-177
+    label[:, 0] = label[:, 0] / patch_width - 0.5
+    label[:, 1] = label[:, 1] / patch_height - 0.5
+    label[:, 2] = label[:, 2] / patch_width
+    return out, label.reshape(-1).astype(np.float32), np.asarray(joints_vis, np.float64).reshape(-1).astype(np.float32), scale, rot

@@ -447,7 +447,74 @@ def gen_trajectory():
     save("trajectory.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------------
+# 9. input pipeline: the reference's do_augmentation, paste_over, occlude_with_objects and
+#    get_single_patch_sample executed live.  Third-party stand-ins (no cv2 here, see ref_shims.py): cv2.imread -> a synthetic frame,
+#    cv2.warpAffine and cv2.resize(INTER_AREA) -> the restatements of oracle/imgproc.py (the unpinned OpenCV layer); everything else --
+#    the order of the random draws, the affine, the alpha blend with its uint8 truncation, colour scaling, normalisation, the label
+#    arithmetic -- is the reference's own code.
+# --------------------------------------------------------------------------------------------------
+def gen_pipeline():
+    import importlib
+    import random
+    from oracle import imgproc as o_img
+    from epipolarpose_amd.dataset.synthetic_frames import render_frame
+    from epipolarpose_amd.utils.augmentation import load_occluders
+    aug = importlib.import_module("lib.utils.augmentation")
+    iu = REF.img_utils
+    cv2 = sys.modules["cv2"]
+    out = {}
+    random.seed(11)
+    np.random.seed(11)
+    draws = [iu.do_augmentation() for _ in range(64)]
+    out["aug/seed"] = np.int64(11)
+    out["aug/draws"] = np.array([[d[0], d[1], float(d[2])] + list(d[3]) for d in draws])
+    rng = np.random.default_rng(3)
+    for t in range(8):
+        src = rng.integers(0, 256, (int(rng.integers(5, 40)), int(rng.integers(5, 40)), 4)).astype(np.uint8)
+        dst = rng.integers(0, 256, (48, 64, 3)).astype(np.uint8)
+        center = rng.uniform(-10, 70, 2)
+        res = dst.copy()
+        aug.paste_over(src, res, center)
+        out["paste/%d/src" % t], out["paste/%d/dst" % t], out["paste/%d/center" % t], out["paste/%d/out" % t] = src, dst, center, res
+    occluders = load_occluders(seed=5, count=6)
+    aug.resize_by_factor = o_img.resize_by_factor                    # cv2.resize stand-in
+    im = rng.integers(0, 256, (256, 256, 3)).astype(np.uint8)
+    random.seed(21)
+    np.random.seed(21)
+    out["occlude/im"], out["occlude/seed"] = im, np.int64(21)
+    out["occlude/out"] = aug.occlude_with_objects(im, occluders)
+    # get_single_patch_sample on two synthetic frames, with and without occluders
+    sc = SyntheticScenes(n_group=2, n_view=2, num_joints=17, seed=31, augment=False)
+    frames = {}
+    cv2.imread = lambda path, flags=None: frames[path]
+    cv2.IMREAD_COLOR, cv2.IMREAD_IGNORE_ORIENTATION = 1, 128
+    cv2.INTER_LINEAR = 1
+    cv2.warpAffine = lambda img, trans, dsize, flags=None: o_img.warp_affine_linear(np.ascontiguousarray(img), trans, dsize)
+    mean, std = np.array([123.675, 116.280, 103.530]), np.array([58.395, 57.120, 57.375])
+    label_func = REF.integral_loss.get_label_func()
+    from epipolarpose_amd.synthetic import project
+    for i in range(sc.batch_size):
+        v, g = divmod(i, 2)
+        uv, xc = project(sc.world[g], sc.cams[v])
+        joints = np.concatenate([uv, xc[:, 2:3] - xc[0, 2]], axis=1)
+        frames["f%d" % i] = render_frame(uv, 1000, seed=500 + i)
+        for occ in (False, True):
+            random.seed(40 + i)
+            np.random.seed(40 + i)
+            img, label, weight, scale, rot = iu.get_single_patch_sample(
+                "f%d" % i, sc.meta["center_x"][i], sc.meta["center_y"][i], sc.meta["width"][i], sc.meta["height"][i], joints.copy(),
+                np.ones((17, 3)), [], None, 256, 256, 2000., 2000., mean, std, True, label_func, occluder=occluders if occ else None)
+            tag = "sample/%d/occ%d" % (i, int(occ))
+            out[tag + "/img_crc"] = np.uint32(zlib.crc32(np.ascontiguousarray(img, np.float32).tobytes()))
+            out[tag + "/img_sub"] = np.ascontiguousarray(img, np.float32)[:, ::8, ::8].copy()
+            out[tag + "/label"], out[tag + "/weight"] = label.astype(np.float32), weight.astype(np.float32)
+            out[tag + "/scale_rot"] = np.array([scale, rot], np.float64)
+    out["sample/seed_base"] = np.int64(40)
+    save("pipeline.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation", "network_big", "refiner", "trajectory"]
+    which = sys.argv[1:] or ["integral", "triangulation", "geometry", "maxpreds", "network", "evaluation", "network_big", "refiner", "trajectory", "pipeline"]
     for w in which:
         globals()["gen_" + w]()
