@@ -29,6 +29,8 @@ _LIB_ALIASES = {
     "refiner.model": "epipolarpose_amd.refiner.model",
     "refiner.utils": "epipolarpose_amd.refiner.utils",
     "refiner.main": "epipolarpose_amd.refiner.main",
+    "refiner.data": "epipolarpose_amd.refiner.data",
+    "lib.utils.augmentation": "epipolarpose_amd.utils.augmentation",
     "lib.dataset": "epipolarpose_amd.dataset",
     "lib.dataset.h36m": "epipolarpose_amd.dataset.synthetic",
 }

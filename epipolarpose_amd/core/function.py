@@ -170,8 +170,16 @@ def eval_integral(epoch, preds_in_patch_with_score, val_loader, final_output_pat
     meta = {"center_x": np.array([r["center_x"] for r in db], dtype=np.float64), "center_y": np.array([r["center_y"] for r in db], dtype=np.float64),
             "width": np.array([r["width"] for r in db], dtype=np.float64), "height": np.array([r["height"] for r in db], dtype=np.float64),
             "scale": np.ones(n), "rot": np.zeros(n)}
-    kps = hip.decode_to_image(torch.from_numpy(xyz.astype(np.float32)).to(dev), hip.DeviceMeta(meta, dev), 256.0, 256.0, 2000.0)
-    preds_in_img = np.concatenate([kps.cpu().numpy(), p[:, :, 3:4]], axis=2)
+    xyz32 = xyz.astype(np.float32)
+    if np.array_equal(xyz32.astype(np.float64), xyz):
+        # predictions that come from validate_integral are float32 values (the soft-argmax output): the device decode is lossless
+        kps = hip.decode_to_image(torch.from_numpy(xyz32).to(dev), hip.DeviceMeta(meta, dev), 256.0, 256.0, 2000.0).cpu().numpy()
+    else:
+        # genuinely float64 predictions: the reference decodes them in float64 (function.py:122-128) -- so do we, on the host
+        from ..utils.img_utils import trans_coords_from_patch_to_org_3d
+        kps = np.stack([trans_coords_from_patch_to_org_3d(p[i, :, :3].copy(), meta["center_x"][i], meta["center_y"][i], meta["width"][i],
+                                                          meta["height"][i], 256, 256, 2000., 2000.) for i in range(n)])
+    preds_in_img = np.concatenate([kps, p[:, :, 3:4]], axis=2)
     name_value, perf = imdb.evaluate(preds_in_img.copy(), final_output_path, debug=debug)
     for name, value in name_value:
         logger.info('Epoch[%d] Validation-%s %f', epoch, name, value)

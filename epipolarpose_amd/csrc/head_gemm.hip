@@ -61,6 +61,8 @@ struct GemmGather {        // maps GEMM row m / K tile to an NHWC source pixel
     int Hs, Ws, Cs;        // source tensor [n][Hs][Ws][Cs]
     int stride;            // source pixel = (i*stride + dy[tap], j*stride + dx[tap]); k = tap*Cs + c
     int dy[16], dx[16];
+    int pitch;             // elements between consecutive source pixels; 0 = Cs.  pitch < Cs: a tap reads Cs CONTIGUOUS elements that span
+                           // several pixels (the space-to-depth stem: 4 pixels x 16 channels per tap)
 };
 struct GemmScatter {       // maps GEMM row m to an output row
     int enabled;           // 0: row m
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * (AP * 1024);
         const void* src;
         if (MODE != A_PLAIN) {       // K tiles never straddle a tap (Cs % 64 == 0) and K has no tail in the gather modes
-            const unsigned eoff = (unsigned)(a_pix[ps] + g_shift) * (unsigned)p.ga.Cs + (unsigned)g_c0;
+            const unsigned eoff = (unsigned)(a_pix[ps] + g_shift) * (unsigned)(p.ga.pitch ? p.ga.pitch : p.ga.Cs) + (unsigned)g_c0;
             src = ((a_mask[ps] >> g_tap) & 1) ? reinterpret_cast<const void*>(a_ptr[ps] + eoff) : reinterpret_cast<const void*>(zero_src);
         } else {
             const bool ok = a_mask[ps] && (k0 + a_chunk[ps] < k_end);          // K tail (K % 8 == 0): zero-filled chunks
@@ -1250,7 +1252,7 @@ static PatchPlan patch_plan(int M, int N, int Cs, int W, size_t workspace_bytes)
 }
 static bool patch_eligible(const GemmArgs& a, bool out_f32, int nphase) {
     if (patch_mode() == 0 || out_f32 || nphase != 1 || !a.ga.enabled || a.ph.enabled || a.sc.enabled || a.bias || !a.coalesce) return false;
-    if (a.ga.stride != 1 || a.ga.Hg != a.ga.Hs || a.ga.Wg != a.ga.Ws || a.ga.Cs % GBK || a.K != PATCH_TAPS * a.ga.Cs) return false;
+    if (a.ga.stride != 1 || a.ga.Hg != a.ga.Hs || a.ga.Wg != a.ga.Ws || a.ga.Cs % GBK || a.K != PATCH_TAPS * a.ga.Cs || a.ga.pitch) return false;
     for (int t = 0; t < PATCH_TAPS; ++t)
         if (a.ga.dy[t] < -1 || a.ga.dy[t] > 1 || a.ga.dx[t] < -1 || a.ga.dx[t] > 1) return false;
     return (long long)a.M * a.ga.Cs < (1LL << 31) && gemm_tile_override() == 0;
@@ -2400,4 +2402,151 @@ extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, 
 extern "C" int epi_conv2d_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                        int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, nullptr, workspace, workspace_bytes, stream, true);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The 7x7 / stride-2 / pad-3 stem convolution on 3 input channels (pose3d_resnet.py:99,186) on the SAME implicit-GEMM kernels.
+// Three channels cannot feed a 16-byte DMA chunk, so the image is first rewritten space-to-depth: with P = the image zero-padded
+// by 3 (top / left), s2d[a][b][(dy*2 + dx)*3 + c] = P[2a + dy][2b + dx][c] (12 channels, padded to 16 = 32 bytes per pixel), and
+//     y[oh][ow][co] = sum_{kh,kw,c} P[2oh + kh][2ow + kw][c] w[co][c][kh][kw]
+//                   = sum_{a,b < 4} sum_{ch < 16} s2d[oh + a][ow + b][ch] w8[co][a][b][ch]           (kh = 2a + dy, kw = 2b + dx; w8 = 0 for kh, kw = 7)
+// -- a 4 x 4 stride-1 convolution whose four horizontal taps of one row are 64 CONTIGUOUS elements starting at pixel (oh + a, ow):
+// the gather GEMM with 4 vertical taps, 64 elements per tap and a pixel pitch of 16 (GemmGather::pitch), K = 256 (147 real products,
+// 1.7x the MFMA work of a kernel that is bound by writing its 67 MB of output anyway).  The weight gradient is the TN kernel's
+// column gather with the same geometry (ldb = the pixel pitch).  No input gradient (the image needs none).
+// ---------------------------------------------------------------------------------------------------------------
+namespace epi {
+
+// x [B][3][H][W] (NCHW) or [B][H][W][3] (NHWC), f32 or bf16 -> s2d [B][H/2 + 3][W/2 + 3][16] bf16.  One thread = one s2d pixel.
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const T* __restrict__ x, int B, int H, int W, unsigned short* __restrict__ out) {
+    const int Hs = H / 2 + 3, Ws = W / 2 + 3;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * Hs * Ws) return;
+    const int b = (int)(t % Ws);
+    const long long r = t / Ws;
+    const int a = (int)(r % Hs), n = (int)(r / Hs);
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ih = 2 * a + dy - 3, iw = 2 * b + dx - 3;
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const long long src = NHWC ? (((long long)n * H + ih) * W + iw) * 3 + c : (((long long)n * 3 + c) * H + ih) * W + iw;
+                    v[(dy * 2 + dx) * 3 + c] = Elem<T>::load1(x + src);
+                }
+            }
+        }
+    uint4v o0, o1;
+    o0.x = pack_bf16x2(v[0], v[1]); o0.y = pack_bf16x2(v[2], v[3]); o0.z = pack_bf16x2(v[4], v[5]); o0.w = pack_bf16x2(v[6], v[7]);
+    o1.x = pack_bf16x2(v[8], v[9]); o1.y = pack_bf16x2(v[10], v[11]); o1.z = 0u; o1.w = 0u;
+    uint4v* q = reinterpret_cast<uint4v*>(out + t * 16);
+    q[0] = o0;
+    q[1] = o1;
+}
+
+// w [Cout][3][7][7] (contiguous) or channels_last memory [Cout][7][7][3], bf16 -> wp [Cout][4][4][16] bf16 (zero where kh or kw = 7, ch >= 12)
+__global__ void stem_pack_weight_kernel(const unsigned short* __restrict__ w, int Cout, int channels_last, unsigned short* __restrict__ wp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Cout * 256) return;
+    const int ch = t & 15, b = (t >> 4) & 3, a = (t >> 6) & 3, co = t >> 8;
+    unsigned short v = 0;
+    if (ch < 12) {
+        const int c = ch % 3, dx = (ch / 3) & 1, dy = ch / 6, kh = 2 * a + dy, kw = 2 * b + dx;
+        if (kh < 7 && kw < 7) v = channels_last ? w[((co * 7 + kh) * 7 + kw) * 3 + c] : w[((co * 3 + c) * 7 + kh) * 7 + kw];
+    }
+    wp[t] = v;
+}
+
+// dwp [Cout][4][4][16] f32 -> dw [Cout][3][7][7] (contiguous or channels_last memory), f32 or bf16
+__global__ void stem_unpack_weight_grad_kernel(const float* __restrict__ dwp, int Cout, int channels_last, int out_bf16, void* __restrict__ dw) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Cout * 147) return;
+    int co, c, kh, kw;
+    if (channels_last) { c = t % 3; kw = (t / 3) % 7; kh = (t / 21) % 7; co = t / 147; }
+    else { kw = t % 7; kh = (t / 7) % 7; c = (t / 49) % 3; co = t / 147; }
+    const float v = dwp[co * 256 + (kh >> 1) * 64 + (kw >> 1) * 16 + ((kh & 1) * 2 + (kw & 1)) * 3 + c];
+    if (out_bf16) reinterpret_cast<unsigned short*>(dw)[t] = f32_to_bf16(v);
+    else reinterpret_cast<float*>(dw)[t] = v;
+}
+
+}  // namespace epi
+
+extern "C" size_t epi_stem7x7s2_s2d_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return 0;
+    return (size_t)B * (H / 2 + 3) * (W / 2 + 3) * 16 * sizeof(unsigned short);
+}
+
+extern "C" int epi_stem7x7s2_s2d(const void* x, int x_dtype, int x_layout, int B, int H, int W, void* s2d, epi_stream_t stream) {
+    if (!x || !s2d || B <= 0 || H <= 0 || W <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if ((H & 1) || (W & 1) || (x_dtype != EPI_F32 && x_dtype != EPI_BF16) || (x_layout != EPI_NCHW && x_layout != EPI_NHWC)) return EPI_ERR_UNSUPPORTED;
+    if ((long long)B * (H / 2 + 3) * (W / 2 + 3) * 16 >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;      // 32-bit element offsets in the gather
+    const long long total = (long long)B * (H / 2 + 3) * (W / 2 + 3);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_dtype == EPI_F32) {
+        if (x_layout == EPI_NHWC) hipLaunchKernelGGL((epi::stem_s2d_kernel<float, true>), grid, block, 0, st, (const float*)x, B, H, W, (unsigned short*)s2d);
+        else hipLaunchKernelGGL((epi::stem_s2d_kernel<float, false>), grid, block, 0, st, (const float*)x, B, H, W, (unsigned short*)s2d);
+    } else {
+        if (x_layout == EPI_NHWC) hipLaunchKernelGGL((epi::stem_s2d_kernel<unsigned short, true>), grid, block, 0, st, (const unsigned short*)x, B, H, W, (unsigned short*)s2d);
+        else hipLaunchKernelGGL((epi::stem_s2d_kernel<unsigned short, false>), grid, block, 0, st, (const unsigned short*)x, B, H, W, (unsigned short*)s2d);
+    }
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_stem7x7s2_pack_weight(const void* w_bf16, int channels_last, int Cout, void* wp, epi_stream_t stream) {
+    if (!w_bf16 || !wp || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(epi::stem_pack_weight_kernel, dim3((unsigned)((Cout * 256 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)w_bf16, Cout, channels_last ? 1 : 0, (unsigned short*)wp);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" int epi_stem7x7s2_unpack_weight_grad(const float* dwp, int Cout, int channels_last, void* dw, int dw_dtype, epi_stream_t stream) {
+    if (!dwp || !dw || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (dw_dtype != EPI_F32 && dw_dtype != EPI_BF16) return EPI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(epi::stem_unpack_weight_grad_kernel, dim3((unsigned)((Cout * 147 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dwp, Cout,
+                       channels_last ? 1 : 0, dw_dtype == EPI_BF16 ? 1 : 0, dw);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+extern "C" size_t epi_stem7x7s2_workspace_bytes(int B, int H, int W, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    return std::max(epi_gemm_workspace_bytes(B * (H / 2) * (W / 2), Cout, 256, 1), epi_gemm_tn_workspace_bytes(B * (H / 2) * (W / 2), Cout, 256, 1));
+}
+
+// y [B][H/2][W/2][Cout] bf16 (raw, pre-BatchNorm) from s2d (epi_stem7x7s2_s2d) and wp (epi_stem7x7s2_pack_weight); bn_sums / bn_sums_done as
+// epi_conv2d_fwd.  Cout % 8 == 0.
+extern "C" int epi_stem7x7s2_fwd(const void* s2d, const void* wp, void* y, int B, int H, int W, int Cout, float* bn_sums, int* bn_sums_done,
+                                 void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (bn_sums_done) *bn_sums_done = 0;
+    if (!s2d || !wp || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if ((H & 1) || (W & 1) || Cout % 8) return EPI_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)s2d; a.Bt = (const unsigned short*)wp; a.C = y;
+    a.M = B * (H / 2) * (W / 2); a.N = Cout; a.K = 256; a.ldb = 256; a.ldc = Cout;
+    a.ga.enabled = 1; a.ga.Hg = H / 2; a.ga.Wg = W / 2; a.ga.Hs = H / 2 + 3; a.ga.Ws = W / 2 + 3; a.ga.Cs = 64; a.ga.pitch = 16; a.ga.stride = 1;
+    for (int t = 0; t < 4; ++t) { a.ga.dy[t] = t; a.ga.dx[t] = 0; }
+    a.stats = bn_sums;
+    a.stats_copies = epi_bn_sum_copies(Cout);
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
+}
+
+// dwp [Cout][4][4][16] f32 = the packed weight gradient (epi_stem7x7s2_unpack_weight_grad turns it into the parameter's layout)
+extern "C" int epi_stem7x7s2_bwd_weight(const void* s2d, const void* dy, float* dwp, int B, int H, int W, int Cout, void* workspace,
+                                        size_t workspace_bytes, epi_stream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if ((H & 1) || (W & 1)) return EPI_ERR_UNSUPPORTED;
+    GemmTnArgs a = {};
+    a.A = (const unsigned short*)dy; a.B = (const unsigned short*)s2d; a.R = B * (H / 2) * (W / 2); a.I = Cout; a.J = 256; a.lda = Cout; a.ldb = 16;
+    a.gather = 1; a.Hg = H / 2; a.Wg = W / 2; a.Hs = H / 2 + 3; a.Ws = W / 2 + 3; a.Cs = 64; a.stride = 1; a.pad = 0; a.KW = 1;
+    return launch_tn(a, dwp, 0, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }

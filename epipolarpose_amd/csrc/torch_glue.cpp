@@ -906,6 +906,116 @@ Tensor conv_bn_act(Tensor x, Tensor w, c10::optional<Tensor> w_bwd, int64_t stri
                             training, momentum, eps, relu);
 }
 
+// ---- The stem: Conv2d(3, C, 7, stride 2, pad 3) -> BatchNorm -> ReLU (pose3d_resnet.py:99-103,186-188) as ONE autograd node ------------
+// The convolution runs on the implicit-GEMM kernels through the space-to-depth form of the image (epi_stem7x7s2_*: csrc/head_gemm.hip);
+// rounds 1-2 left it to MIOpen.  x: [B, 3, H, W] f32 or bf16, NCHW or channels_last; needs no gradient.  w: [C, 3, 7, 7] bf16 training copy
+// or fp32 master.  The weight gradient is a TN GEMM on the second stream followed by a 9 408-element re-ordering into the parameter's layout.
+struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
+    static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var,
+                          Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
+        TORCH_CHECK(x.is_cuda() && w.is_cuda(), "stem_conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
+        TORCH_CHECK(x.dim() == 4 && x.size(1) == 3 && w.dim() == 4 && w.size(1) == 3 && w.size(2) == 7 && w.size(3) == 7, "stem_conv_bn_act: shapes");
+        TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kBFloat16, "stem_conv_bn_act: image dtype");
+        const int B = (int)x.size(0), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)w.size(0);
+        const bool nhwc = x.is_contiguous(at::MemoryFormat::ChannelsLast);
+        if (!nhwc && !x.is_contiguous()) x = x.contiguous();
+        Tensor w16 = w.detach();
+        if (w16.scalar_type() != at::kBFloat16) w16 = w16.to(at::kBFloat16);
+        const bool w_cl = w16.is_contiguous(at::MemoryFormat::ChannelsLast);
+        if (!w_cl && !w16.is_contiguous()) w16 = w16.contiguous();
+        const auto bf = x.options().dtype(at::kBFloat16).memory_format(at::MemoryFormat::Contiguous);
+        const size_t s2d_bytes = epi_stem7x7s2_s2d_bytes(B, H, W);
+        TORCH_CHECK(s2d_bytes > 0, "stem_conv_bn_act: image extent must be even");
+        Tensor s2d = at::empty({(int64_t)(s2d_bytes / 2)}, bf);
+        Tensor wp = at::empty({(int64_t)Cout * 256}, bf);
+        const epi_stream_t st = current_stream(x);
+        check(epi_stem7x7s2_s2d(x.data_ptr(), x.scalar_type() == at::kFloat ? EPI_F32 : EPI_BF16, nhwc ? EPI_NHWC : EPI_NCHW, B, H, W, s2d.data_ptr(), st),
+              "epi_stem7x7s2_s2d");
+        check(epi_stem7x7s2_pack_weight(w16.data_ptr(), w_cl ? 1 : 0, Cout, wp.data_ptr(), st), "epi_stem7x7s2_pack_weight");
+        Tensor raw = at::empty({B, Cout, H / 2, W / 2}, x.options().dtype(at::kBFloat16).memory_format(at::MemoryFormat::ChannelsLast));
+        TORCH_CHECK(!training || sums_ws.numel() == 2 * (int64_t)Cout * epi_bn_sum_copies(Cout), "stem_conv_bn_act: sums_ws must be [epi_bn_sum_copies(C)][2C]");
+        if (training) {
+            int* fl = flags.data_ptr<int>();
+            if (fl[0]) sums_ws.zero_();
+            fl[0] = 1;
+            fl[1] = 0;
+        }
+        int sums_done = 0;
+        const double flops = 2.0 * B * (H / 2) * (W / 2) * (double)Cout * 147.0;
+        {
+            Tensor& ws = workspace(epi_stem7x7s2_workspace_bytes(B, H, W, Cout), raw);
+            ScopedTimer timer("stem_conv_fwd", flops, 2.0 * ((double)x.numel() + (double)raw.numel()), st);
+            check(epi_stem7x7s2_fwd(s2d.data_ptr(), wp.data_ptr(), raw.data_ptr(), B, H, W, Cout, training ? sums_ws.data_ptr<float>() : nullptr,
+                                    training ? &sums_done : nullptr, ws.data_ptr(), (size_t)ws.numel(), st), "epi_stem7x7s2_fwd");
+        }
+        BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
+        Tensor stats, y;
+        if (training && !sums_done) {
+            flags.data_ptr<int>()[0] = 0;
+            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, false);
+        } else {
+            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, training);
+        }
+        ctx->saved_data["training"] = training;
+        if (training) {
+            auto holder = c10::make_intrusive<SavedHolder>();
+            holder->stages.resize(1);
+            StageSaved& sv = holder->stages[0];
+            sv.x = s2d; sv.raw = raw; sv.stats = stats; sv.gamma = gamma; sv.sums_ws = sums_ws; sv.bwd_sums = bwd_sums; sv.flags = flags;
+            sv.relu = relu; sv.has_res = false; sv.w_f32 = w.scalar_type() != at::kBFloat16; sv.w = w;
+            sv.w_sizes = w.sizes().vec();
+            sv.w_strides = w.strides().vec();
+            sv.K = H; sv.S = W; sv.P = B;                    // (geometry of the image, reusing the integer slots)
+            ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        }
+        return y;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        TORCH_CHECK(ctx->saved_data["training"].toBool(), "stem_conv_bn_act: backward through inference-mode statistics is not supported");
+        auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
+        TORCH_CHECK(!holder->stages.empty(), "stem_conv_bn_act: backward called twice (the fused nodes free their activations in backward)");
+        g_side.jobs.clear();
+        const StageSaved& sv = holder->stages[0];
+        BnGrads g = bn_backward(grads[0], sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false);
+        const int H = sv.K, W = sv.S, B = sv.P, Cout = (int)sv.raw.size(1);
+        Tensor dw;
+        if (ctx->needs_input_grad(1)) {
+            dw = at::empty_strided(sv.w_sizes, sv.w_strides, sv.raw.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
+            const bool w_cl = dw.is_contiguous(at::MemoryFormat::ChannelsLast) && !dw.is_contiguous();
+            Tensor dwp = at::empty({(int64_t)Cout * 256}, sv.raw.options().dtype(at::kFloat).memory_format(at::MemoryFormat::Contiguous));
+            const double flops = 2.0 * B * (H / 2) * (W / 2) * (double)Cout * 147.0;
+            const size_t ws_bytes = epi_stem7x7s2_workspace_bytes(B, H, W, Cout);
+            const Tensor s2d = sv.x, dyin = g.dx, dwout = dw;
+            const bool w_f32 = sv.w_f32;
+            auto launch = [=](epi_stream_t st, Tensor& ws) {
+                check(epi_stem7x7s2_bwd_weight(s2d.data_ptr(), dyin.data_ptr(), dwp.data_ptr<float>(), B, H, W, Cout, ws.data_ptr(), (size_t)ws.numel(), st),
+                      "epi_stem7x7s2_bwd_weight");
+                check(epi_stem7x7s2_unpack_weight_grad(dwp.data_ptr<float>(), Cout, w_cl ? 1 : 0, dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, st),
+                      "epi_stem7x7s2_unpack_weight_grad");
+            };
+            if (side_mode() != 0 && first_gradient_of_pass(sv.w) && gradient_consumed_after_backward(sv.w)) {
+                g_side.jobs.push_back(SideStream::Job{sv.x, g.dx, dw, [=](epi_stream_t st) {
+                    launch(st, side_workspace(ws_bytes, s2d));
+                    g_side.keep.push_back(dwp);
+                    return EpiSlabReduce();
+                }, "stem_conv_bwd_weight", flops, 0.0});
+            } else {
+                ScopedTimer timer("stem_conv_bwd_weight", flops, 0.0, current_stream(sv.raw));
+                launch(current_stream(sv.raw), workspace(ws_bytes, sv.raw));
+            }
+        }
+        side_run_jobs();
+        holder->stages.clear();
+        return {Tensor(), dw, g.dgamma, g.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor stem_conv_bn_act(Tensor x, Tensor w, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var, Tensor num_batches, Tensor sums_ws,
+                        Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
+    return StemConvBnAct::apply(x, w, gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags, training, momentum, eps, relu);
+}
+
 // ---- A whole residual unit (BasicBlock / Bottleneck, pose3d_resnet.py:18-88) as ONE autograd node ------------------------------
 // tensors: STAGE_TENSORS per stage, main-path stages first, the downsample projection (if any) last; geometry: (stride, pad) per stage.
 // Every main-path stage has ReLU; the last one adds the shortcut before it; the projection has none.  In the backward pass the
@@ -1311,6 +1421,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "torch-autograd glue over the libepipolar_hip C ABI (no compute of its own)";
     m.def("bn_act", &bn_act, "fused BatchNorm (+residual) (+ReLU), NHWC bf16, autograd-aware");
     m.def("conv_bn_act", &conv_bn_act, "Conv2d -> BatchNorm (+residual) (+ReLU) as one autograd node, NHWC bf16");
+    m.def("stem_conv_bn_act", &stem_conv_bn_act, "Conv2d(3, C, 7, stride 2, pad 3) -> BatchNorm -> ReLU of the stem as one autograd node (space-to-depth implicit GEMM)");
     m.def("deconv_bn_act", &deconv_bn_act, "ConvTranspose2d(k4, s2, p1) -> BatchNorm -> ReLU as one autograd node, NHWC bf16");
     m.def("conv1x1_bias", &conv1x1_bias, "1x1 convolution (+ bias) on the NHWC view as one autograd node");
     m.def("maxpool3x3s2", &maxpool3x3s2, "MaxPool2d(kernel 3, stride 2, padding 1), NHWC bf16, autograd-aware");

@@ -28,8 +28,10 @@ def _memory_order_flat(t):
     return q.reshape(-1) if q.is_contiguous() else None
 
 
-def init_from_env(backend=None, set_device=True):
-    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local)."""
+def init_from_env(backend=None, set_device=True, timeout_minutes=120):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local).
+    ``timeout_minutes``: collective timeout -- generous by default, because rank 0 runs the whole validation and evaluation between
+    epochs while the other ranks wait in a barrier (scripts/train.py), which the default watchdog would kill on a full H36M validation."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -40,7 +42,8 @@ def init_from_env(backend=None, set_device=True):
             backend = "nccl" if torch.cuda.is_available() else "gloo"      # "nccl" IS RCCL on ROCm
         if backend == "nccl" and set_device:
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=timeout_minutes))
     return rank, world, local
 
 

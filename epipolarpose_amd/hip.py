@@ -74,6 +74,13 @@ _SIGNATURES = {
     "epi_deconv4x4s2_pack_phase_cl": (_i, [_vp, _i, _i, _vp, _vp]),
     "epi_deconv4x4s2_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_column_sums_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp]),
+    "epi_stem7x7s2_s2d_bytes": (_sz, [_i, _i, _i]),
+    "epi_stem7x7s2_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "epi_stem7x7s2_s2d": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "epi_stem7x7s2_pack_weight": (_i, [_vp, _i, _i, _vp, _vp]),
+    "epi_stem7x7s2_unpack_weight_grad": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "epi_stem7x7s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_stem7x7s2_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_split_bf16": (_i, [_vp, ctypes.c_longlong, _i, _vp, _i, _i, _vp, _vp]),
     "epi_conv2d_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_conv2d_bwd_data_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -726,6 +733,49 @@ def wgrad_group(jobs, dtype=torch.float32):
             keep.append(raw)
         torch.cuda.current_stream(dev).synchronize()
     return outs
+
+
+def stem_conv_fwd(x, weight, bn_sums=None):
+    """The 7x7 / stride-2 / pad-3 stem convolution (pose3d_resnet.py:99): x [B, 3, H, W] f32 or bf16 (NCHW or channels_last), weight
+    [Cout, 3, 7, 7] -> (y [B, Cout, H/2, W/2] channels_last bf16, s2d) on the implicit-GEMM kernel through the space-to-depth image
+    (``epi_stem7x7s2_*``); ``s2d`` is what the weight gradient reads."""
+    lib = load()
+    _dev(x, name="x")
+    b, _, h, w = x.shape
+    cout = weight.shape[0]
+    nhwc = x.is_contiguous(memory_format=torch.channels_last)
+    if not nhwc:
+        x = x.contiguous()
+    w16 = weight.detach().to(torch.bfloat16)
+    w_cl = w16.is_contiguous(memory_format=torch.channels_last) and not w16.is_contiguous()
+    if not w_cl:
+        w16 = w16.contiguous()
+    s2d = torch.empty(lib.epi_stem7x7s2_s2d_bytes(b, h, w) // 2, dtype=torch.bfloat16, device=x.device)
+    wp = torch.empty(cout * 256, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty((b, cout, h // 2, w // 2), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ws = _workspace(lib.epi_stem7x7s2_workspace_bytes(b, h, w, cout), x.device)
+    done = ctypes.c_int(0)
+    _check(lib.epi_stem7x7s2_s2d(_ptr(x), EPI_F32 if x.dtype == torch.float32 else EPI_BF16, EPI_NHWC if nhwc else EPI_NCHW, b, h, w, _ptr(s2d), _stream()),
+           "epi_stem7x7s2_s2d")
+    _check(lib.epi_stem7x7s2_pack_weight(_ptr(w16), 1 if w_cl else 0, cout, _ptr(wp), _stream()), "epi_stem7x7s2_pack_weight")
+    _check(lib.epi_stem7x7s2_fwd(_ptr(s2d), _ptr(wp), _ptr(y), b, h, w, cout, _ptr(bn_sums), ctypes.addressof(done) if bn_sums is not None else None,
+                                 _ptr(ws), ws.numel(), _stream()), "epi_stem7x7s2_fwd")
+    return y, s2d
+
+
+def stem_conv_bwd_weight(s2d, dy, image_hw, dtype=torch.float32):
+    """Weight gradient of the stem convolution from the space-to-depth image: dy [B, Cout, H/2, W/2] channels_last bf16 -> dW [Cout, 3, 7, 7]."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    b, cout = dy.shape[0], dy.shape[1]
+    h, w = image_hw
+    dwp = torch.empty(cout * 256, dtype=torch.float32, device=dy.device)
+    dw = torch.empty((cout, 3, 7, 7), dtype=dtype, device=dy.device)
+    ws = _workspace(lib.epi_stem7x7s2_workspace_bytes(b, h, w, cout), dy.device)
+    _check(lib.epi_stem7x7s2_bwd_weight(_ptr(s2d), _ptr(dy), _ptr(dwp), b, h, w, cout, _ptr(ws), ws.numel(), _stream()), "epi_stem7x7s2_bwd_weight")
+    _check(lib.epi_stem7x7s2_unpack_weight_grad(_ptr(dwp), cout, 0, _ptr(dw), EPI_BF16 if dtype == torch.bfloat16 else EPI_F32, _stream()),
+           "epi_stem7x7s2_unpack_weight_grad")
+    return dw
 
 
 def _cl_weight_bf16(weight):

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import hip
+from ..optim import sync_training_copy
 from .fused import HEAD_BACKEND, Conv1x1, Deconv4x4s2, deconv_bn_act, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
 
 BN_MOMENTUM = 0.1
@@ -32,6 +33,9 @@ POINTWISE_BACKEND = os.environ.get("EPI_1X1", "miopen")
 # MIOpen followed by the fused BatchNorm module (the round-1 path, kept for A/B measurements).
 CONV_BACKEND = os.environ.get("EPI_CONV", "hip")
 MAXPOOL_BACKEND = os.environ.get("EPI_MAXPOOL", "hip")       # "torch": the library max-pool (A/B switch)
+# Backend of the 7x7 stem convolution (EPI_STEM): "hip" (default, round 3) = the implicit-GEMM kernels on the space-to-depth image,
+# conv -> BatchNorm -> ReLU one C++ autograd node; "miopen" = nn.Conv2d through MIOpen + the fused BatchNorm module (rounds 1-2)
+STEM_BACKEND = os.environ.get("EPI_STEM", "hip")
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -172,8 +176,17 @@ class PoseResNet(nn.Module):
         layers = [self.layer1, self.layer2, self.layer3, self.layer4]
         return layers[n - 1], [self.conv1, self.bn1] + layers[:n]
 
+    def stem(self, x):
+        conv, bn = self.conv1, self.bn1
+        if (STEM_BACKEND == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and conv.out_channels % 8 == 0):
+            w = sync_training_copy(conv) if getattr(conv, "weight_lp", None) is not None else conv.weight
+            g, b, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
+            return hip.glue().stem_conv_bn_act(x, w, g, b, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, bn.training, bn.momentum, bn.eps, bn.relu)
+        return bn(conv(x))
+
     def features(self, x):
-        x = self.bn1(self.conv1(x))
+        x = self.stem(x)
         if x.is_cuda and x.shape[1] % 8 == 0 and MAXPOOL_BACKEND == "hip":      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
             x = hip.glue().maxpool3x3s2(x)
         else:

@@ -411,6 +411,29 @@ int epi_evaluate_poses(const double* pred_img, const double* gt_img, const doubl
                        double* per_joint, epi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Stem convolution (round 3): nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False) of pose3d_resnet.py:99,186 on the same
+ * implicit-GEMM kernels as every other convolution (rounds 1-2 left it to MIOpen: 3 input channels cannot feed a 16-byte DMA chunk).
+ * The image is rewritten space-to-depth -- s2d [B][H/2 + 3][W/2 + 3][16] bf16, 2 x 2 pixel blocks of the 3-zero-padded image as 12 (+4 zero)
+ * channels -- which turns the layer into a 4 x 4 stride-1 convolution whose four horizontal taps are 64 contiguous elements: a gather GEMM
+ * with K = 256 (csrc/head_gemm.hip, "stem").  H, W even.
+ *   epi_stem7x7s2_s2d            x [B,3,H,W] (EPI_NCHW) or [B,H,W,3] (EPI_NHWC), EPI_F32 | EPI_BF16 -> s2d (epi_stem7x7s2_s2d_bytes bytes)
+ *   epi_stem7x7s2_pack_weight    w bf16 [Cout,3,7,7] (contiguous, or channels_last memory [Cout][7][7][3]) -> wp [Cout][256] bf16
+ *   epi_stem7x7s2_fwd            -> y [B][H/2][W/2][Cout] bf16 (raw); bn_sums / bn_sums_done as epi_conv2d_fwd
+ *   epi_stem7x7s2_bwd_weight     s2d, dy [B][H/2][W/2][Cout] bf16 -> dwp [Cout][256] f32 (packed order)
+ *   epi_stem7x7s2_unpack_weight_grad   dwp -> dw in the parameter's layout, EPI_F32 | EPI_BF16
+ * workspace: epi_stem7x7s2_workspace_bytes.  No input gradient (the image needs none).
+ * ------------------------------------------------------------------------------------------------ */
+size_t epi_stem7x7s2_s2d_bytes(int B, int H, int W);
+size_t epi_stem7x7s2_workspace_bytes(int B, int H, int W, int Cout);
+int epi_stem7x7s2_s2d(const void* x, int x_dtype, int x_layout, int B, int H, int W, void* s2d, epi_stream_t stream);
+int epi_stem7x7s2_pack_weight(const void* w_bf16, int channels_last, int Cout, void* wp, epi_stream_t stream);
+int epi_stem7x7s2_unpack_weight_grad(const float* dwp, int Cout, int channels_last, void* dw, int dw_dtype, epi_stream_t stream);
+int epi_stem7x7s2_fwd(const void* s2d, const void* wp, void* y, int B, int H, int W, int Cout, float* bn_sums, int* bn_sums_done,
+                      void* workspace, size_t workspace_bytes, epi_stream_t stream);
+int epi_stem7x7s2_bwd_weight(const void* s2d, const void* dy, float* dwp, int B, int H, int W, int Cout, void* workspace,
+                             size_t workspace_bytes, epi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * fp32-grade verification mode (round 3; epipolarpose_amd/models/precise.py, csrc/precise.hip) -- NOT on the training hot path.
  * The training path computes bf16 x bf16 -> fp32 with bf16 activations, so against the reference's fp32 network
  * (lib/models/pose3d_resnet.py:185-201, lib/core/integral_loss.py:140-160) it can only be held to a bf16 yardstick.  These entry

@@ -84,6 +84,15 @@ def main(argv=None):
     torch.backends.cudnn.benchmark = config.CUDNN.BENCHMARK              # MIOpen find mode
     torch.backends.cudnn.deterministic = config.CUDNN.DETERMINISTIC
     torch.backends.cudnn.enabled = config.CUDNN.ENABLED
+    # GPUS (config / --gpus): the reference hands the id list to nn.DataParallel (train.py:93-94).  Here one PROCESS drives one GPU:
+    # a single process honours a single id; several ids need `python -m torch.distributed.run --nproc-per-node N scripts/train.py ...`
+    gpu_ids = [int(i) for i in str(getattr(config, 'GPUS', '') or '').replace(' ', '').split(',') if i != '']
+    if world == 1 and gpu_ids:
+        if len(gpu_ids) > 1:
+            logger.warning('GPUS lists %d devices but this is a single process (WORLD_SIZE=1): training on GPU %d only, with a per-GPU batch of '
+                           '%d images -- launch with torch.distributed.run --nproc-per-node %d for data parallelism', len(gpu_ids), gpu_ids[0],
+                           config.TRAIN.BATCH_SIZE, len(gpu_ids))
+        local = gpu_ids[0]
     torch.cuda.set_device(local)
 
     model = models.pose3d_resnet.get_pose_net(config, is_train=True).cuda()

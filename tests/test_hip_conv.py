@@ -462,3 +462,58 @@ def test_wgrad_group_vs_torch_fp32(dtype):
     single = hip.conv2d_bwd_weight(x, dy, k, stride, pad, dtype=dtype)
     alone = hip.wgrad_group([jobs[9]], dtype=dtype)[0]
     assert (alone.float() - single.float()).abs().max().item() <= 2e-3 * single.float().abs().max().item()
+
+
+@pytest.mark.parametrize("layout", ["nchw_f32", "nhwc_f32", "nhwc_bf16"])
+def test_stem_convolution_vs_torch_fp32(layout):
+    """The 7x7 / stride-2 / pad-3 convolution on 3 channels (pose3d_resnet.py:99) through the space-to-depth gather GEMM: forward and weight
+    gradient against torch's fp32 convolution of the bf16-rounded operands; then the whole stem node (conv -> BatchNorm -> ReLU) against fp32 autograd."""
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(17)
+    b, h, cout = 4, 64, 64
+    x = torch.randn((b, 3, h, h), generator=gen)
+    w = torch.randn((cout, 3, 7, 7), generator=gen) * (2.0 / 147) ** 0.5
+    xin = x.to(dev)
+    if layout.startswith("nhwc"):
+        xin = xin.contiguous(memory_format=torch.channels_last)
+    if layout.endswith("bf16"):
+        xin = xin.to(torch.bfloat16)
+    xr, wr = x.to(torch.bfloat16).float().to(dev), w.to(torch.bfloat16).float().to(dev).requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=2, padding=3)
+    y, s2d = hip.stem_conv_fwd(xin, w.to(dev))
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert (y.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    wcl = w.to(dev).contiguous(memory_format=torch.channels_last)                 # the model's weights are channels_last
+    y2, _ = hip.stem_conv_fwd(xin, wcl)
+    assert torch.equal(y2, y)
+    dy = _rand(tuple(ref.shape), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    ref.backward(dy.float())
+    dw = hip.stem_conv_bwd_weight(s2d, dy, (h, h))
+    assert (dw - wr.grad).abs().max().item() <= 3e-3 * wr.grad.abs().max().item() + 1e-5
+    # the node: conv -> BatchNorm (training) -> ReLU
+    gamma, beta = (torch.rand(cout, generator=gen) + 0.5).to(dev), (torch.randn(cout, generator=gen) * 0.1).to(dev)
+    bn = hip_bn_module(cout, gamma, beta, dev)
+    wp = torch.nn.Parameter(wcl.clone())
+    g_, b_, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
+    out = hip.glue().stem_conv_bn_act(xin, wp, g_, b_, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, True, 0.1, 1e-5, True)
+    wf, gf, bf_ = wr.detach().clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    refo = F.relu(F.batch_norm(F.conv2d(xr, wf, stride=2, padding=3), None, None, gf, bf_, True, 0.1, 1e-5))
+    assert (out.float() - refo).abs().max().item() <= 3e-2 * refo.abs().max().item()
+    dyo = _rand(tuple(refo.shape), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    out.backward(dyo)
+    refo.backward(dyo.float())
+    torch.cuda.synchronize()
+    for got, want, what in ((wp.grad, wf.grad, "dw"), (bn.weight.grad, gf.grad, "dgamma"), (bn.bias.grad, bf_.grad, "dbeta")):
+        got, want = got.float(), want.float()
+        assert float((got - want).norm()) <= 4e-2 * float(want.norm()) + 1e-6, (what, float((got - want).norm()), float(want.norm()))
+
+
+def hip_bn_module(c, gamma, beta, dev):
+    from epipolarpose_amd.models.fused import FusedBatchNormAct
+    bn = FusedBatchNormAct(c, momentum=0.1, relu=True).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    return bn

@@ -25,6 +25,33 @@ def _train(model, data, steps, early, boundary=None, late=None):
     return opt, fired
 
 
+def _conditioned_pose_net(seed, size=128, batch=16, steps=8, warm_up=None):
+    """A small PoseResNet-18 in a WELL-CONDITIONED state, and its data.  At random initialisation with a handful of samples per BatchNorm
+    channel in layer4 the network is chaotic: one bf16 rounding flip in the stem (the order of the statistics' atomics decides it) moves
+    the output by 2.6 % and deep-layer gradients by 50 %, so two runs of the SAME code end up 0.3 of a four-step update apart and
+    whether two runs agree is a coin toss (tools/debug_bucket_flake.py, tools/debug_fwd_bimodal.py; the run-to-run spread of the
+    four-step trajectory is 0.06-0.45 of the update there against 0.02-0.04 from the state made here).  128 x 128 images, 16 of them, and eight
+    plain steps first."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.EXTRA.NUM_LAYERS = 18
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = 4, 16, [size, size]
+    torch.manual_seed(seed)
+    base = get_pose_net(cfg, is_train=False).to(dev).train()
+    data = [torch.randn(batch, 3, size, size, device=dev) for _ in range(4)]
+    warm = copy.deepcopy(base)
+    if warm_up is not None:
+        warm_up(warm, [data[i % 4] for i in range(steps)])
+    else:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _train(warm, [data[i % 4] for i in range(steps)], steps, early=False)
+    base.load_state_dict(warm.state_dict())          # (the copy keeps the bf16 training copies; ``base`` stays a plain module)
+    return base, data
+
+
 def test_step_in_backward_is_bit_identical_on_a_deterministic_network():
     """Linear layers only (deterministic GEMMs, no atomics): the early update of layers 2 and 3 from the hook on layer 1's output +
     the late update of layer 1 in step() == one update of everything in step(), bit for bit, moments and step count included."""
@@ -49,16 +76,7 @@ def test_step_in_backward_on_the_pose_network():
     """PoseResNet-18 on the hand-written kernels (bf16 training copies, packed backward operands, deferred slab sums, weight gradients
     on the second stream): three steps with the update of layers 2-4 + head inside the backward pass against three plain steps.
     BatchNorm sums by atomics make two runs of the SAME code differ slightly, so the yardstick is that run-to-run difference."""
-    from epipolarpose_amd.core.config import default_config
-    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
-    dev = torch.device("cuda:0")
-    cfg = default_config()
-    cfg.MODEL.INIT_WEIGHTS = False
-    cfg.MODEL.EXTRA.NUM_LAYERS = 18
-    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = 4, 16, [64, 64]
-    torch.manual_seed(1)
-    base = get_pose_net(cfg, is_train=False).to(dev).train()
-    data = [torch.randn(8, 3, 64, 64, device=dev) for _ in range(3)]
+    base, data = _conditioned_pose_net(seed=1)
 
     def run(early):
         m = copy.deepcopy(base)
@@ -101,24 +119,23 @@ def test_bucketed_grad_sync_with_second_stream_and_deferred_sums():
     only the last gradient of each bucket keeps its hook, every other weight gradient runs on the second stream with deferred slab sums,
     and the hook must see finished gradients (it joins the stream and sums the slabs first).  Four steps with the bucket path against
     four plain steps, same yardstick as above (summed differences against the run-to-run difference)."""
-    from epipolarpose_amd.core.config import default_config
     from epipolarpose_amd.core.function import train_step
     from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
     from epipolarpose_amd.distributed import BucketedGradSync
-    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
     from epipolarpose_amd.optim import FusedAdam
     dev = torch.device("cuda:0")
-    cfg = default_config()
-    cfg.MODEL.INIT_WEIGHTS = False
-    cfg.MODEL.EXTRA.NUM_LAYERS = 18
     j = 4
-    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, 16, [64, 64]
-    torch.manual_seed(2)
-    base = get_pose_net(cfg, is_train=False).to(dev).train()
-    data = [torch.randn(8, 3, 64, 64, device=dev) for _ in range(4)]
-    gt = (torch.rand(8, 3 * j, device=dev) - 0.5) * 0.4
-    vis = torch.ones(8, 3 * j, device=dev)
+    torch.manual_seed(3)
+    gt = (torch.rand(16, 3 * j, device=dev) - 0.5) * 0.4
+    vis = torch.ones(16, 3 * j, device=dev)
     crit = SmoothL1JointLocationLoss(num_joints=j)
+
+    def warm_up(m, batches):
+        opt = FusedAdam(m, lr=1e-2)
+        for x in batches:
+            train_step(m, crit, opt, x, gt, vis)
+        torch.cuda.synchronize()
+    base, data = _conditioned_pose_net(seed=2, batch=16, warm_up=warm_up)
 
     def run(bucketed):
         m = copy.deepcopy(base)

@@ -143,9 +143,11 @@ def test_refiner_train_and_test_loops():
     model.apply(weight_init)
     opt = make_optimizer(model, lr=1e-3)
     args = SimpleNamespace(lr=1e-3, lr_decay=100000, lr_gamma=0.96)
-    step, lr_now, first = train(model, train_dl, opt, 0, 1e-3, TwoHeadMSE(), args)
+    step, lr_now = train(model, train_dl, opt, 0, 1e-3, TwoHeadMSE(), args)          # (the reference's 2-tuple, refiner/main.py:60)
+    first = train.last_avg_loss
     for _ in range(4):
-        step, lr_now, last = train(model, train_dl, opt, step, lr_now, TwoHeadMSE(), args)
+        step, lr_now = train(model, train_dl, opt, step, lr_now, TwoHeadMSE(), args)
+        last = train.last_avg_loss
     assert step == 20 and last < first
     err, err_align = test(model, test_dl)
     assert np.isfinite(err) and err_align <= err + 1e-6
