@@ -544,10 +544,12 @@ extern "C" int epi_bn_act_fwd_f32(const void* x, const void* residual, long long
                                   num_batches_tracked, mean, rstd, scale_shift, sums_ws, bwd_sums, y, stream);
 }
 
+// reduced: dy is already dz and dbeta_dgamma already holds the two sums (the *_bnred backward-data entries of csrc/head_gemm.hip):
+// the apply pass alone, without a mask
 template <typename T>
 static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
                            const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
-                           float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
+                           float* fwd_sums_clear, float* param_grads, epi_stream_t stream, bool reduced = false) {
     constexpr int V = Elem<T>::VEC;
     if (!dy || !x || !gamma || !mean || !rstd || !scale_shift || !dbeta_dgamma || !dx) return EPI_ERR_INVALID_ARGUMENT;
     if (dres && relu && !y) return EPI_ERR_INVALID_ARGUMENT;        // residual + ReLU: the mask comes from the saved output
@@ -556,15 +558,17 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long lo
     int rpw = 0;
     dim3 rgrid;
     reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
-    const int mask = !relu ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
+    const int mask = (!relu || reduced) ? BN_MASK_NONE : (y ? BN_MASK_FROM_Y : BN_MASK_FROM_X);
     const T *dys = (const T*)dy, *xs = (const T*)x, *ys = (const T*)y;
     const float *sc = scale_shift, *sh = scale_shift + C;
+    if (!reduced) {
 #define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
-    if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
-    else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
-    else EPI_BN_RED(BN_MASK_FROM_Y);
+        if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
+        else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
+        else EPI_BN_RED(BN_MASK_FROM_Y);
 #undef EPI_BN_RED
-    EPI_CHECK_LAUNCH();
+        EPI_CHECK_LAUNCH();
+    }
     const long long nvec = R * (C / V);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
     T *dxs = (T*)dx, *drs = (T*)dres;
@@ -593,6 +597,12 @@ extern "C" int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long
                               const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,
                               float* fwd_sums_clear, float* param_grads, epi_stream_t stream) {
     return bn_act_bwd_impl<unsigned short>(dy, x, y, R, C, gamma, mean, rstd, scale_shift, relu, dbeta_dgamma, dx, dres, fwd_sums_clear, param_grads, stream);
+}
+extern "C" int epi_bn_act_bwd_reduced(const void* dz, const void* x, long long R, int C, const float* gamma, const float* mean, const float* rstd,
+                                      const float* scale_shift, const float* dbeta_dgamma, void* dx, float* fwd_sums_clear, float* param_grads,
+                                      epi_stream_t stream) {
+    return bn_act_bwd_impl<unsigned short>(dz, x, nullptr, R, C, gamma, mean, rstd, scale_shift, 0, const_cast<float*>(dbeta_dgamma), dx, nullptr,
+                                           fwd_sums_clear, param_grads, stream, true);
 }
 extern "C" int epi_bn_act_bwd_f32(const void* dy, const void* x, const void* y, long long R, int C, const float* gamma, const float* mean,
                                   const float* rstd, const float* scale_shift, int relu, float* dbeta_dgamma, void* dx, void* dres,

@@ -79,6 +79,19 @@ struct GemmPhases {
     int dy[4][4], dx[4][4];   // source pixel of tap t = (i + dy, j + dx)
     long long bt_off[4];   // element offset of the phase's weight block [N][ntap * Cs] inside Bt
 };
+// BatchNorm-backward reduction fused into a backward-data epilogue.  The gradient this GEMM produces is the dy of a training-mode
+// BatchNorm (+ ReLU) whose backward pass starts with sum(dz) and sum(dz * xhat) over all rows, dz = dy * [output > 0]: the epilogue
+// has the bf16-rounded dy tile in registers, so it fetches the same tile of z (the raw convolution output that layer normalised) and
+// of the mask source, writes dz INSTEAD of dy and adds the two column sums of its tile to `sums` -- the separate reduction pass over
+// (dy, z, y) disappears and the apply pass needs neither the mask source nor a second output for the shortcut branch (dz is it).
+struct GemmBnRed {
+    const unsigned short* z;   // [rows / stride as C] raw forward output of the normalised layer; null: off
+    const unsigned short* y;   // mask source: the gradient passes where y > 0 (residual + ReLU layers); null: where scale*z + shift > 0
+    const float* bn;           // [mean | rstd | scale | shift], N floats each
+    float* sums;               // [2N] += (sum dz | sum dz * xhat), xhat = (z - mean) * rstd
+    int relu;                  // 0: no mask at all
+};
+
 struct GemmArgs {
     const unsigned short* A;
     const unsigned short* Bt;
@@ -96,6 +109,7 @@ struct GemmArgs {
     int coalesce;          // bf16 result with N % 8 == 0, ldc % 8 == 0: LDS-staged 128-byte row segments
     int patch_px;          // conv_patch_kernel: pixels of the staged patch (256 + 2W + 2, rounded up to 8)
     int chunks_per_split;  // conv_patch_kernel: 64-channel chunks per blockIdx.y
+    GemmBnRed br;          // unsplit bf16 launches on the coalesced epilogue only (launch_gemm decides and reports)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -131,9 +145,61 @@ __device__ __forceinline__ uint4v add_bf16x8(uint4v a, uint4v b) {
     return r;
 }
 
+// ---- GemmBnRed: per-lane state of the eight columns n .. n + 7 a lane copies in the coalesced epilogues ----
+struct BnRedCols { float mu[8], rs[8], sc[8], sh[8]; };
+__device__ __forceinline__ void bnred_cols(const GemmBnRed& br, int N, int n, BnRedCols& c) {
+    const bool ok = n < N;                       // (N % 8 == 0 on this path: all eight columns or none)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float4v zero = float4v{0.f, 0.f, 0.f, 0.f};
+        const float4v mu = ok ? *reinterpret_cast<const float4v*>(br.bn + n + 4 * h) : zero;
+        const float4v rs = ok ? *reinterpret_cast<const float4v*>(br.bn + N + n + 4 * h) : zero;
+        const float4v sc = ok ? *reinterpret_cast<const float4v*>(br.bn + 2 * N + n + 4 * h) : zero;
+        const float4v sh = ok ? *reinterpret_cast<const float4v*>(br.bn + 3 * N + n + 4 * h) : zero;
+        c.mu[4 * h] = mu.x; c.mu[4 * h + 1] = mu.y; c.mu[4 * h + 2] = mu.z; c.mu[4 * h + 3] = mu.w;
+        c.rs[4 * h] = rs.x; c.rs[4 * h + 1] = rs.y; c.rs[4 * h + 2] = rs.z; c.rs[4 * h + 3] = rs.w;
+        c.sc[4 * h] = sc.x; c.sc[4 * h + 1] = sc.y; c.sc[4 * h + 2] = sc.z; c.sc[4 * h + 3] = sc.w;
+        c.sh[4 * h] = sh.x; c.sh[4 * h + 1] = sh.y; c.sh[4 * h + 2] = sh.z; c.sh[4 * h + 3] = sh.w;
+    }
+}
+// o: eight bf16 gradients of one row (element `off` of the output onwards).  Returns dz (o with the masked elements cleared) and
+// accumulates s += dz, q += dz * xhat.  Same arithmetic as bn_bwd_reduce_kernel (csrc/bn_nhwc.hip) on the same bf16-rounded values.
+__device__ __forceinline__ uint4v bnred_apply(const GemmBnRed& br, uint4v o, uint4v zv, uint4v yv, const BnRedCols& c, float (&s)[8], float (&q)[8]);
+__device__ __forceinline__ uint4v bnred_row(const GemmBnRed& br, uint4v o, long long off, const BnRedCols& c, float (&s)[8], float (&q)[8]) {
+    const uint4v zv = *reinterpret_cast<const uint4v*>(br.z + off);
+    uint4v yv = uint4v{0u, 0u, 0u, 0u};
+    if (br.relu && br.y) yv = *reinterpret_cast<const uint4v*>(br.y + off);
+    return bnred_apply(br, o, zv, yv, c, s, q);
+}
+// (zv, yv: the z / y elements of the same positions, fetched by the caller -- ahead of time where it has the registers)
+__device__ __forceinline__ uint4v bnred_apply(const GemmBnRed& br, uint4v o, uint4v zv, uint4v yv, const BnRedCols& c, float (&s)[8], float (&q)[8]) {
+    unsigned int ow[4] = {o.x, o.y, o.z, o.w};
+    const unsigned int zw[4] = {zv.x, zv.y, zv.z, zv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = 2 * k + h;
+            const unsigned int keep = h ? 0xffff0000u : 0x0000ffffu;
+            const float g = __uint_as_float(h ? (ow[k] & 0xffff0000u) : (ow[k] << 16));
+            const float xv = __uint_as_float(h ? (zw[k] & 0xffff0000u) : (zw[k] << 16));
+            bool on = true;
+            if (br.relu) on = br.y ? (__uint_as_float(h ? (yw[k] & 0xffff0000u) : (yw[k] << 16)) > 0.f) : (xv * c.sc[e] + c.sh[e] > 0.f);
+            const float dz = on ? g : 0.f;
+            s[e] += dz;
+            q[e] = fmaf(dz, (xv - c.mu[e]) * c.rs[e], q[e]);
+            if (!on) ow[k] &= ~keep;
+        }
+    }
+    uint4v r; r.x = ow[0]; r.y = ow[1]; r.z = ow[2]; r.w = ow[3];
+    return r;
+}
+
 enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
 
-template <bool OUT_F32, typename Cfg, int MODE>
+// RED: the instantiation with the fused BatchNorm-backward reduction (GemmBnRed) in the coalesced epilogue -- a separate one, so that the
+// registers its epilogue needs (column parameters, the z / y tiles in flight) never enter the allocation of the other launches
+template <bool OUT_F32, typename Cfg, int MODE, bool RED = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel(GemmArgs p) {
     constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM, AP = Cfg::AP, BP = Cfg::BP;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
@@ -380,12 +446,24 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             return ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
         };
         // residual-junction addend: requested NOW, consumed after the LDS round trip below (its latency hides behind the park)
+        constexpr bool AD_EARLY = !(RED && TM >= 4);       // (the 256-row tile with the fused reduction: no registers for 16 rows of addend)
+        constexpr bool RED_EARLY = RED && !OUT_F32 && TM <= 2;   // z / y of all rows requested here too: their latency hides behind the park
         uint4v ad[TM * 4];
-        if (p.addend) {
+        if (AD_EARLY && p.addend) {
 #pragma unroll
             for (int it = 0; it < TM * 4; ++it) {
                 const long long orow = out_row(it);
                 ad[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
+            }
+        }
+        uint4v zpre[RED_EARLY ? TM * 4 : 1], ypre[RED_EARLY ? TM * 4 : 1];
+        if (RED_EARLY) {
+            const bool use_y = p.br.relu && p.br.y;
+#pragma unroll
+            for (int it = 0; it < TM * 4; ++it) {
+                const long long orow = out_row(it);
+                zpre[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.br.z + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
+                ypre[it] = (orow >= 0 && use_y) ? *reinterpret_cast<const uint4v*>(p.br.y + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
             }
         }
 #pragma unroll
@@ -412,8 +490,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         float ssum[8], ssq[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+        constexpr bool red = RED && !OUT_F32;          // fused BatchNorm-backward reduction (GemmBnRed): the two sums reuse the statistics' route
+        BnRedCols rcols;
+        if (red) bnred_cols(p.br, p.N, n, rcols);
 #pragma unroll
         for (int it = 0; it < TM * 4; ++it) {
+            // (RED: at most four rows' z / y tiles in flight per lane -- the scheduler would otherwise hoist all TM*4 loads to the top)
+            if (red && !RED_EARLY && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
             const int row = it * 8 + (lane >> 3), sw = row & 15;
             const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
             const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
@@ -429,10 +512,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                 }
             }
             uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-            if (p.addend) o = add_bf16x8(o, ad[it]);
+            if (p.addend) o = add_bf16x8(o, AD_EARLY ? ad[it] : *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n));
+            if (red) o = RED_EARLY ? bnred_apply(p.br, o, zpre[it], ypre[it], rcols, ssum, ssq) : bnred_row(p.br, o, orow * p.ldc + n, rcols, ssum, ssq);
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
         }
-        if (p.stats) {
+        if (p.stats || red) {
             // reduce over the 8 row lanes, combine the workgroup's WM wave rows through LDS (a region behind the park slices), then
             // ONE contiguous fp32 atomic per column and workgroup: what serialises in L2 is the number of (instruction, 128-byte
             // line) pairs per line -- M-tiles x 1 this way, against M-tiles x WM x 16 with per-wave strided atomics (measured: 9 ns each)
@@ -455,7 +539,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
 #pragma unroll
                 for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
                 const int which = t / GBN, col = n0 + (t % GBN);
-                if (col < p.N) atomicAdd(p.stats + (long long)((m0 / GBM) % p.stats_copies) * 2 * p.N + which * p.N + col, v);
+                float* dst = red ? p.br.sums : p.stats + (long long)((m0 / GBM) % p.stats_copies) * 2 * p.N;
+                if (col < p.N) atomicAdd(dst + which * p.N + col, v);
             }
         }
         return;
@@ -737,7 +822,7 @@ __device__ unsigned long long epi_patch_trace[64 * 96];
 
 // SINGLE: the workgroup covers ONE 64-channel chunk (64-channel layers, or one chunk per split) -- no second patch buffer, no
 // patch pieces in the per-step DMA group, and (narrow tiles) two workgroups per CU: one's prologue / epilogue under the other's loop
-template <typename Cfg, int NB, bool SINGLE>
+template <typename Cfg, int NB, bool SINGLE, bool RED = false>
 __global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kernel(GemmArgs p) {      // (waves per SIMD)
     constexpr int TM = Cfg::TM, GBN = Cfg::BN, BP = Cfg::BP, NW = Cfg::NW, BB = Cfg::B_BYTES;
     constexpr int NPATCH = SINGLE ? 1 : 2, GROUP = BP + (SINGLE ? 0 : 1);
@@ -940,8 +1025,12 @@ __global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kerne
     float ssum[8], ssq[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+    constexpr bool red = RED;                          // fused BatchNorm-backward reduction (GemmBnRed), as in head_gemm_kernel
+    BnRedCols rcols;
+    if (red) bnred_cols(p.br, p.N, n, rcols);
 #pragma unroll
     for (int it = 0; it < TM * 4; ++it) {
+        if (red && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
         const int row = it * 8 + (lane >> 3), sw = row & 15;
         const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
         const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
@@ -958,9 +1047,10 @@ __global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kerne
         }
         uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
         if (p.addend) o = add_bf16x8(o, ad[it]);
+        if (red) o = bnred_row(p.br, o, orow * p.ldc + n, rcols, ssum, ssq);
         *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
     }
-    if (p.stats) {
+    if (p.stats || red) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -980,7 +1070,8 @@ __global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kerne
 #pragma unroll
             for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
             const int which = t / GBN, col = n0 + (t % GBN);
-            if (col < p.N) atomicAdd(p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N + which * p.N + col, v);
+            float* dst = red ? p.br.sums : p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N;
+            if (col < p.N) atomicAdd(dst + which * p.N + col, v);
         }
     }
 #ifdef EPI_PATCH_TRACE
@@ -1173,26 +1264,26 @@ extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
     return need;
 }
 
-template <bool OUT_F32, typename Cfg, int MODE>
+template <bool OUT_F32, typename Cfg, int MODE, bool RED = false>
 static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
     // staging ring; the epilogue reuses it for the waves' output slices and, behind them, the BatchNorm-statistics combine area
     const size_t lds = std::max((size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES,
                                 (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
     if (lds > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE, RED>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
     const dim3 grid((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)nphase);
-    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg, MODE>), grid, dim3(Cfg::THREADS), lds, st, a);
+    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg, MODE, RED>), grid, dim3(Cfg::THREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
-template <bool OUT_F32, typename Cfg>
+template <bool OUT_F32, typename Cfg, bool RED = false>
 static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
-    if (a.ph.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_PHASED>(a, pl, nphase, st);
-    if (a.ga.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_GATHER>(a, pl, nphase, st);
-    return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN>(a, pl, nphase, st);
+    if (a.ph.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_PHASED, RED>(a, pl, nphase, st);
+    if (a.ga.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_GATHER, RED>(a, pl, nphase, st);
+    return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN, RED>(a, pl, nphase, st);
 }
 
 #ifdef EPI_PATCH_TRACE
@@ -1257,20 +1348,35 @@ static bool patch_eligible(const GemmArgs& a, bool out_f32, int nphase) {
         if (a.ga.dy[t] < -1 || a.ga.dy[t] > 1 || a.ga.dx[t] < -1 || a.ga.dx[t] > 1) return false;
     return (long long)a.M * a.ga.Cs < (1LL << 31) && gemm_tile_override() == 0;
 }
-template <typename Cfg, int NB, bool SINGLE = false>
-static int launch_patch(const GemmArgs& a, const PatchPlan& pl, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Cfg, NB, SINGLE>),
+template <typename Cfg, int NB, bool SINGLE = false, bool RED = false>
+static int launch_patch_red(const GemmArgs& a, const PatchPlan& pl, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<Cfg, NB, SINGLE, RED>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return EPI_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv_patch_kernel<Cfg, NB, SINGLE>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), pl.lds, st, a);
+    hipLaunchKernelGGL((conv_patch_kernel<Cfg, NB, SINGLE, RED>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), pl.lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
+}
+template <typename Cfg, int NB, bool SINGLE = false>
+static int launch_patch(const GemmArgs& a, const PatchPlan& pl, hipStream_t st) {
+    return a.br.z ? launch_patch_red<Cfg, NB, SINGLE, true>(a, pl, st) : launch_patch_red<Cfg, NB, SINGLE, false>(a, pl, st);
 }
 
 // stats_done (may be null): set to 1 when a.stats was accumulated by the GEMM launch itself (unsplit bf16 result), else 0 --
 // the caller then computes the statistics with its own pass
-static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr) {
+// red_done (may be null): likewise for a.br (GemmBnRed): 1 when the launch masked the gradient and accumulated the two BatchNorm-backward
+// sums, 0 when the result is the plain gradient (split launches, fp32 results, uncoalesced rows) and the caller runs its reduction pass
+static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, size_t workspace_bytes, hipStream_t st, int* stats_done = nullptr,
+                       int* red_done = nullptr) {
     if (stats_done) *stats_done = 0;
+    if (red_done) *red_done = 0;
+    // EPI_BN_BWD_FUSE=0: never (A/B measurements)
+    static const bool fuse_red = [] { const char* e = getenv("EPI_BN_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    GemmBnRed want_red = a.br;
+    a.br = GemmBnRed{};
+    if (!fuse_red || !red_done || !want_red.z || !want_red.bn || !want_red.sums || a.stats || a.bias ||
+        ((reinterpret_cast<uintptr_t>(want_red.z) | reinterpret_cast<uintptr_t>(want_red.y)) & 15u))
+        want_red.z = nullptr;
     if (a.addend && (out_f32 || (reinterpret_cast<uintptr_t>(a.addend) & 15u))) return EPI_ERR_UNSUPPORTED;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
     // BatchNorm statistics from the GEMM epilogue (on; EPI_FUSE_BN_STATS=0 keeps the separate statistics pass: 8.46 vs 8.49 ms/step,
@@ -1286,7 +1392,11 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
     // short K, wide N, plain operands, bf16 result: the A-stationary kernel (the final 1x1 convolution forward)
-    if (!out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
+    // (a launch that carries the fused BatchNorm-backward reduction stays on the generic kernel: the A-stationary kernel has no registers left
+    //  to request a slice's z / y ahead of its MFMAs, and with them requested at their use it ran 84 .. 92 us instead of 19 .. 20 us --
+    //  profiles/r03_bn_bwd_fused_reduction.txt)
+    if (!want_red.z &&
+        !out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
         const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);
         // BatchNorm statistics from THIS kernel's epilogue are off by default (EPI_FUSE_BN_STATS_ASTAT=1 turns them on): in the step trace the
@@ -1316,6 +1426,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             a.chunks_per_split = pp.cps;
             if (pp.nsplit > 1) a.slabs = (float*)workspace;
             else if (want_stats) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
+            else if (want_red.z) { a.br = want_red; *red_done = 1; }
             int rc;
             if (pp.cfg == PATCH_NARROW && pp.single) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3, true>(a, pp, st) : launch_patch<PatchNarrow, 2, true>(a, pp, st);
             else if (pp.cfg == PATCH_NARROW) rc = pp.nb == 3 ? launch_patch<PatchNarrow, 3>(a, pp, st) : launch_patch<PatchNarrow, 2>(a, pp, st);
@@ -1345,8 +1456,14 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     }
     a.k_per_split = pl.kps;
     if (want_stats && pl.nsplit == 1 && a.coalesce && !a.bias) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
+    if (want_red.z && pl.nsplit == 1 && a.coalesce && !pl.pipe && (pl.cfg == CFG_BIG || pl.cfg == CFG_SMALL || pl.cfg == CFG_TALL)) {
+        a.br = want_red;
+        *red_done = 1;
+    }
     int rc;
-    if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
+    if (a.br.z) rc = pl.cfg == CFG_BIG ? launch_gemm_cfg<false, CfgBig, true>(a, pl, nphase, st)
+                   : (pl.cfg == CFG_TALL ? launch_gemm_cfg<false, CfgTall, true>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall, true>(a, pl, nphase, st));
+    else if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
     else if (pl.cfg == CFG_HALF) rc = launch_gemm_cfg<false, CfgHalf>(a, pl, nphase, st);
     else if (pl.cfg == CFG_QUARTER) rc = launch_gemm_cfg<false, CfgQuarter>(a, pl, nphase, st);
@@ -1366,6 +1483,26 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
         EPI_CHECK_LAUNCH();
     }
     return EPI_OK;
+}
+
+static GemmBnRed bnred_args(const EpiBnReduce* r) {
+    GemmBnRed b = {};
+    if (r && r->z && r->bn && r->sums) {
+        b.z = (const unsigned short*)r->z; b.y = (const unsigned short*)r->y; b.bn = r->bn; b.sums = r->sums; b.relu = r->relu ? 1 : 0;
+    }
+    return b;
+}
+
+// epi_gemm_bf16 with bf16 C whose rows are the gradient of a BatchNorm(+ReLU) output (the final 1x1 convolution's backward-data):
+// see EpiBnReduce (include/epipolar_hip.h).  *red_done = 1: C holds dz and red->sums the two column sums; 0: C is the plain product.
+extern "C" int epi_gemm_bf16_bnred(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int M, int N, int K, const EpiBnReduce* red,
+                                   int* red_done, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!red_done) return EPI_ERR_INVALID_ARGUMENT;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)A; a.Bt = (const unsigned short*)Bt; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.br = bnred_args(red);
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, nullptr, red_done);
 }
 
 extern "C" int epi_gemm_bf16(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int c_dtype, int M, int N, int K,
@@ -1422,7 +1559,9 @@ extern "C" int epi_deconv4x4s2_fwd_f32(const void* x, const void* w_phase, void*
 // w_bwd: [Cin][16 taps * Cout] packed by epi_deconv4x4s2_pack_weight (tap = kh*4 + kw).
 // workspace: epi_gemm_workspace_bytes(B*H*W, Cin, 16*Cout, 1).
 static int deconv4x4s2_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
-                                    void* workspace, size_t workspace_bytes, epi_stream_t stream, bool out_f32) {
+                                    void* workspace, size_t workspace_bytes, epi_stream_t stream, bool out_f32,
+                                    const EpiBnReduce* red = nullptr, int* red_done = nullptr) {
+    if (red_done) *red_done = 0;
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return EPI_ERR_INVALID_ARGUMENT;
     if (Cout % GBK || Cin % 4) return EPI_ERR_UNSUPPORTED;
     GemmArgs a = {};
@@ -1431,11 +1570,18 @@ static int deconv4x4s2_bwd_data_impl(const void* dy, const void* w_bwd, void* dx
     a.ga.enabled = 1; a.ga.Hg = H; a.ga.Wg = W; a.ga.Hs = 2 * H; a.ga.Ws = 2 * W; a.ga.Cs = Cout; a.ga.stride = 2;
     for (int kh = 0; kh < 4; ++kh)
         for (int kw = 0; kw < 4; ++kw) { a.ga.dy[4 * kh + kw] = kh - 1; a.ga.dx[4 * kh + kw] = kw - 1; }   // oh = 2*ih - 1 + kh
-    return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    a.br = bnred_args(red);
+    return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream, nullptr, red_done);
 }
 extern "C" int epi_deconv4x4s2_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
                                         void* workspace, size_t workspace_bytes, epi_stream_t stream) {
     return deconv4x4s2_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, workspace, workspace_bytes, stream, false);
+}
+// the same with the fused BatchNorm-backward reduction of the layer that produced this deconvolution's input (EpiBnReduce)
+extern "C" int epi_deconv4x4s2_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                                              const EpiBnReduce* red, int* red_done, void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!red_done) return EPI_ERR_INVALID_ARGUMENT;
+    return deconv4x4s2_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, workspace, workspace_bytes, stream, false, red, red_done);
 }
 extern "C" int epi_deconv4x4s2_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
                                             void* workspace, size_t workspace_bytes, epi_stream_t stream) {
@@ -2356,7 +2502,8 @@ extern "C" int epi_conv2d_fwd_f32(const void* x, const void* w, void* y, int B, 
 
 static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
-                               epi_stream_t stream, bool out_f32) {
+                               epi_stream_t stream, bool out_f32, const EpiBnReduce* red = nullptr, int* red_done = nullptr) {
+    if (red_done) *red_done = 0;
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
@@ -2366,6 +2513,7 @@ static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int
     GemmArgs a = {};
     a.A = (const unsigned short*)dy; a.Bt = (const unsigned short*)w_bwd; a.C = dx; a.N = Cin; a.ldc = Cin;
     a.addend = (const unsigned short*)addend;
+    a.br = bnred_args(red);
     if (stride == 1) {
         a.M = B * H * W; a.K = KH * KW * Cout; a.ldb = KH * KW * Cout;
         if (KH == 1 && KW == 1 && pad == 0) {
@@ -2376,7 +2524,7 @@ static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int
             for (int kh = 0; kh < KH; ++kh)
                 for (int kw = 0; kw < KW; ++kw) { a.ga.dy[kh * KW + kw] = pad - kh; a.ga.dx[kh * KW + kw] = pad - kw; }
         }
-        return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream);
+        return launch_gemm(a, out_f32, 1, workspace, workspace_bytes, (hipStream_t)stream, nullptr, red_done);
     }
     // stride 2: dx pixel (2i + py, 2j + px) gathers dy pixels (i + dy_t, j + dx_t) over the taps of its parity phase
     if ((H & 1) || (W & 1) || Cout % GBK) return EPI_ERR_UNSUPPORTED;
@@ -2392,12 +2540,19 @@ static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int
         a.ph.bt_off[p] = L.bt_off[p];
         for (int t = 0; t < 4; ++t) { a.ph.dy[p][t] = L.dy[p][t]; a.ph.dx[p][t] = L.dx[p][t]; }
     }
-    return launch_gemm(a, out_f32, 4, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_gemm(a, out_f32, 4, workspace, workspace_bytes, (hipStream_t)stream, nullptr, red_done);
 }
 extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                    int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
                                    epi_stream_t stream) {
     return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, addend, workspace, workspace_bytes, stream, false);
+}
+// the same with the fused BatchNorm-backward reduction of the layer that produced this convolution's input (EpiBnReduce): dx becomes dz
+extern "C" int epi_conv2d_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                         int KW, int stride, int pad, const void* addend, const EpiBnReduce* red, int* red_done,
+                                         void* workspace, size_t workspace_bytes, epi_stream_t stream) {
+    if (!red_done) return EPI_ERR_INVALID_ARGUMENT;
+    return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, addend, workspace, workspace_bytes, stream, false, red, red_done);
 }
 extern "C" int epi_conv2d_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                        int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {

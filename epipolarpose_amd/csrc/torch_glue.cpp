@@ -23,6 +23,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/epipolar_hip.h"
@@ -625,13 +626,119 @@ Tensor bn_forward(const Tensor& x, const Tensor& residual, const BnBuffers& b, b
 struct BnGrads { Tensor dx, dres, dgamma, dbeta; };
 
 // dy: gradient of the fused output; x: the raw BatchNorm input saved by the forward; y: saved output (relu && residual) or undefined
+// ---- The BatchNorm-backward reduction done by the backward-data GEMM that PRODUCES the layer's dy (EpiBnReduce, include/epipolar_hip.h) ----
+// A node that ends in a BatchNorm publishes a link for its output tensor at forward time; the node that consumes that tensor claims it.
+// In the backward pass the consumer runs first: if it is the only consumer, its backward-data epilogue masks the gradient, accumulates
+// sum(dz) and sum(dz * xhat) into the producer's accumulator and records WHICH tensor it handed to autograd (TensorImpl + version).
+// The producer skips its reduction pass only when exactly that tensor arrives unchanged -- a gradient that autograd summed with another
+// consumer's (a new tensor, or an in-place add that bumps the version) takes the ordinary path on a fresh accumulator, which is still
+// right because masking is idempotent: mask * (mask * g1 + g2) = mask * (g1 + g2).
+struct BnLink : torch::CustomClassHolder {
+    Tensor raw, ymask, stats, bwd_sums, flags;      // ymask: the saved output of a residual + ReLU layer (mask = y > 0), else undefined
+    bool relu = false;
+    c10::weak_intrusive_ptr<c10::TensorImpl> y{c10::intrusive_ptr<c10::TensorImpl>()};   // identity of the forward output
+    int consumers = 0;
+    bool reduced = false;
+    c10::TensorImpl* dz_impl = nullptr;
+    uint32_t dz_version = 0;
+    void* key = nullptr;                            // its entry in g_links
+};
+// by the data pointer of the forward output; WEAK: a link (and the activations it references) lives exactly as long as the producing
+// node's saved state -- a training-mode forward under no_grad leaves nothing behind
+std::unordered_map<void*, c10::weak_intrusive_ptr<BnLink>> g_links;
+int g_bn_fuse = -1;
+bool bn_fuse_enabled() {
+    if (g_bn_fuse < 0) { const char* e = getenv("EPI_BN_BWD_FUSE"); g_bn_fuse = (e && e[0] == '0') ? 0 : 1; }
+    return g_bn_fuse != 0;
+}
+int64_t g_bn_fused = 0, g_bn_refused = 0;         // BatchNorm backward passes that found their reduction done / done but unusable
+std::vector<int64_t> bn_bwd_fuse_counts(bool reset) {
+    std::vector<int64_t> out{g_bn_fused, g_bn_refused};
+    if (reset) g_bn_fused = g_bn_refused = 0;
+    return out;
+}
+int bn_bwd_fuse_mode(int mode) {                // test / measurement hook: returns the previous setting; a negative mode only queries
+    const int prev = bn_fuse_enabled() ? 1 : 0;
+    if (mode >= 0) g_bn_fuse = mode ? 1 : 0;
+    return prev;
+}
+c10::intrusive_ptr<BnLink> link_publish(const Tensor& y, const Tensor& raw, const Tensor& ymask, const Tensor& stats, const Tensor& bwd_sums,
+                                        const Tensor& flags, bool relu) {
+    if (!bn_fuse_enabled()) return c10::intrusive_ptr<BnLink>();
+    if (g_links.size() > 4096)                                     // (entries of forward passes whose backward never ran)
+        for (auto it = g_links.begin(); it != g_links.end();) it = it->second.expired() ? g_links.erase(it) : std::next(it);
+    auto link = c10::make_intrusive<BnLink>();
+    link->raw = raw; link->ymask = ymask; link->stats = stats; link->bwd_sums = bwd_sums; link->flags = flags; link->relu = relu;
+    link->y = c10::weak_intrusive_ptr<c10::TensorImpl>(y.getIntrusivePtr());
+    link->key = y.data_ptr();
+    g_links.insert_or_assign(link->key, c10::weak_intrusive_ptr<BnLink>(link));
+    return link;
+}
+c10::intrusive_ptr<BnLink> link_claim(const Tensor& x) {
+    if (!bn_fuse_enabled() || g_links.empty()) return c10::intrusive_ptr<BnLink>();
+    auto it = g_links.find(x.data_ptr());
+    if (it == g_links.end()) return c10::intrusive_ptr<BnLink>();
+    auto link = it->second.lock();
+    if (!link) { g_links.erase(it); return c10::intrusive_ptr<BnLink>(); }
+    auto alive = link->y.lock();
+    if (!alive || alive.get() != x.unsafeGetTensorImpl() || link->raw.sizes() != x.sizes()) return c10::intrusive_ptr<BnLink>();
+    link->consumers += 1;
+    return link;
+}
+void link_retire(const c10::intrusive_ptr<BnLink>& link) {          // the producer's backward has run (or the pass is over)
+    if (!link) return;
+    auto it = g_links.find(link->key);
+    if (it != g_links.end() && it->second._unsafe_get_target() == link.get()) g_links.erase(it);
+}
+// the consumer's side: fills `red` when the reduction may be fused into its backward-data launch
+bool link_reduce_args(const c10::intrusive_ptr<BnLink>& link, EpiBnReduce* red) {
+    if (!link || !bn_fuse_enabled() || link->consumers != 1 || link->reduced || !link->raw.defined() || link->flags.data_ptr<int>()[1] != 0)
+        return false;
+    red->z = link->raw.data_ptr();
+    red->y = (link->relu && link->ymask.defined()) ? link->ymask.data_ptr() : nullptr;
+    red->bn = link->stats.data_ptr<float>();
+    red->sums = link->bwd_sums.data_ptr<float>();
+    red->relu = link->relu ? 1 : 0;
+    return true;
+}
+void link_mark_reduced(const c10::intrusive_ptr<BnLink>& link, const Tensor& dz) {
+    link->reduced = true;
+    link->dz_impl = dz.unsafeGetTensorImpl();
+    link->dz_version = dz._version();
+}
+// the producer's side.  0: nothing was fused; 1: `dy` is the dz a consumer produced and the accumulator holds its sums;
+// 2: a consumer accumulated into bwd_sums but `dy` is not its tensor any more -- reduce again, on a fresh accumulator
+int link_state(const c10::intrusive_ptr<BnLink>& link, const Tensor& dy) {
+    if (!link || !link->reduced) return 0;
+    return (dy.unsafeGetTensorImpl() == link->dz_impl && dy._version() == link->dz_version && nhwc_bf16(dy)) ? 1 : 2;
+}
+
+// pre: 0 / 1 / 2 as link_state
 BnGrads bn_backward(Tensor dy, const Tensor& x, const Tensor& y, const Tensor& stats, const Tensor& weight, Tensor sums_ws, Tensor bwd_sums,
-                    Tensor flags, bool relu, bool has_res) {
+                    Tensor flags, bool relu, bool has_res, int pre = 0) {
     if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
     const int64_t B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
     int* fl = flags.data_ptr<int>();
+    if (pre == 2) g_bn_refused += 1;
+    if (pre == 1) {         // dy is dz, the sums are in: the apply pass alone (3 passes over the tensor instead of 5 .. 8)
+        g_bn_fused += 1;
+        BnGrads g;
+        g.dx = at::empty_like(x);
+        if (has_res) g.dres = dy;                       // the gradient of the shortcut input IS dz
+        Tensor pg = at::empty({2 * C}, stats.options());
+        const float* sp = stats.data_ptr<float>();
+        ScopedTimer timer("bn_bwd_apply", 0.0, 2.0 * (double)x.numel() * 3, current_stream(x));
+        check(epi_bn_act_bwd_reduced(dy.data_ptr(), x.data_ptr(), B * H * W, (int)C, weight.data_ptr<float>(), sp, sp + C, sp + 2 * C,
+                                     bwd_sums.data_ptr<float>(), g.dx.data_ptr(), sums_ws.data_ptr<float>(), pg.data_ptr<float>(), current_stream(x)),
+              "epi_bn_act_bwd_reduced");
+        fl[0] = 0;
+        fl[1] = 1;
+        g.dbeta = pg.slice(0, 0, C);
+        g.dgamma = pg.slice(0, C, 2 * C);
+        return g;
+    }
     // bwd_sums was cleared by this layer's forward pass; a second backward without a forward in between gets a fresh accumulator
-    Tensor sums = fl[1] ? at::zeros({2 * C}, stats.options()) : bwd_sums;
+    Tensor sums = (fl[1] || pre == 2) ? at::zeros({2 * C}, stats.options()) : bwd_sums;
     BnGrads g;
     g.dx = at::empty_like(x);
     if (has_res) g.dres = at::empty_like(x);
@@ -789,9 +896,15 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
 
 struct StageGrads { Tensor dx, dw, dgamma, dbeta, dres; };
 
-// dy: gradient of the stage output; addend: added to dx in the backward-data epilogue (the other branch of a residual junction)
-StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, bool need_dw, const Tensor& addend) {
-    BnGrads g = bn_backward(dy, sv.raw, sv.y, sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, sv.has_res);
+// dy: gradient of the stage output; addend: added to dx in the backward-data epilogue (the other branch of a residual junction).
+// pre: state of dy (link_state: 1 = already dz with the sums in the accumulator).  feeds / feeds_link: the BatchNorm stage whose output
+// this stage consumed -- inside the same node (feeds) or in the producing node (feeds_link): its reduction is fused into this stage's
+// backward-data launch where the library can (*fed = true: dx is that layer's dz).
+StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, bool need_dw, const Tensor& addend, int pre = 0,
+                          const StageSaved* feeds = nullptr, const c10::intrusive_ptr<BnLink>& feeds_link = c10::intrusive_ptr<BnLink>(),
+                          bool* fed = nullptr) {
+    if (fed) *fed = false;
+    BnGrads g = bn_backward(dy, sv.raw, sv.y, sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, sv.has_res, pre);
     const Tensor& x = sv.x;
     const int K = sv.K, S = sv.S, P = sv.P;
     const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)sv.raw.size(1);
@@ -805,9 +918,30 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
         Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
         ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
                           2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)sv.wb.numel()), current_stream(x));
-        check(epi_conv2d_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
-                                  addend.defined() ? addend.data_ptr() : nullptr, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
-              "epi_conv2d_bwd_data");
+        EpiBnReduce red = {};
+        bool want = false;
+        if (fed && bn_fuse_enabled()) {
+            if (feeds && feeds->raw.defined() && feeds->raw.sizes() == x.sizes() && !feeds->has_res && feeds->flags.data_ptr<int>()[1] == 0) {
+                red.z = feeds->raw.data_ptr(); red.y = nullptr; red.bn = feeds->stats.data_ptr<float>();
+                red.sums = feeds->bwd_sums.data_ptr<float>(); red.relu = feeds->relu ? 1 : 0;
+                want = true;
+            } else if (feeds_link) {
+                want = link_reduce_args(feeds_link, &red);
+            }
+        }
+        int red_done = 0;
+        if (want)
+            check(epi_conv2d_bwd_data_bnred(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                                            addend.defined() ? addend.data_ptr() : nullptr, &red, &red_done, ws.data_ptr(), (size_t)ws.numel(),
+                                            current_stream(x)), "epi_conv2d_bwd_data_bnred");
+        else
+            check(epi_conv2d_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
+                                      addend.defined() ? addend.data_ptr() : nullptr, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
+                  "epi_conv2d_bwd_data");
+        if (red_done) {
+            *fed = true;
+            if (!feeds && feeds_link) link_mark_reduced(feeds_link, out.dx);
+        }
     }
     if (need_dw) {
         out.dw = at::empty_strided(sv.w_sizes, sv.w_strides, x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
@@ -868,7 +1002,12 @@ struct SavedHolder : torch::CustomClassHolder {
     std::vector<StageSaved> stages;
     bool has_downsample = false;
     int n_main = 0;
+    c10::intrusive_ptr<BnLink> in_link, out_link;      // the BatchNorm that produced this node's input / this node's own last BatchNorm
 };
+// publish the node's output (the last main-path stage of `holder`)
+void publish_output(const c10::intrusive_ptr<SavedHolder>& holder, const Tensor& y, const StageSaved& sv) {
+    holder->out_link = link_publish(y, sv.raw, sv.y, sv.stats, sv.bwd_sums, sv.flags, sv.relu);
+}
 
 struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, c10::optional<Tensor> w_bwd_opt, int64_t stride, int64_t pad, Tensor gamma,
@@ -879,9 +1018,13 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
         const Tensor residual = (residual_opt.has_value() && residual_opt->defined()) ? *residual_opt : Tensor();
         auto holder = c10::make_intrusive<SavedHolder>();
         holder->stages.resize(1);
+        if (training && x.requires_grad() && nhwc_bf16(x)) holder->in_link = link_claim(x);
         Tensor y = stage_forward(x, sp, residual, training, momentum, eps, x.requires_grad(), &holder->stages[0]);
         ctx->saved_data["training"] = training;
-        if (training) ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        if (training) {
+            publish_output(holder, y, holder->stages[0]);
+            ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        }
         return y;
     }
 
@@ -890,10 +1033,15 @@ struct ConvBnAct : public torch::autograd::Function<ConvBnAct> {
         auto holder = c10::static_intrusive_pointer_cast<SavedHolder>(ctx->saved_data["holder"].toCapsule());
         TORCH_CHECK(!holder->stages.empty(), "conv_bn_act: backward called twice (the fused nodes free their activations in backward)");
         g_side.jobs.clear();                         // (left-overs of a pass that aborted inside a node)
-        StageGrads g = stage_backward(grads[0], holder->stages[0], ctx->needs_input_grad(0), ctx->needs_input_grad(1), Tensor());
+        bool fed = false;
+        StageGrads g = stage_backward(grads[0], holder->stages[0], ctx->needs_input_grad(0), ctx->needs_input_grad(1), Tensor(),
+                                      link_state(holder->out_link, grads[0]), nullptr, holder->in_link, &fed);
+        link_retire(holder->out_link);
         side_run_jobs();
         side_group_flush();
         holder->stages.clear();                      // release the saved activations now, not when the graph is torn down
+        holder->in_link.reset();
+        holder->out_link.reset();
         return {g.dx, g.dw, Tensor(), Tensor(), Tensor(), g.dgamma, g.dbeta, g.dres, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
                 Tensor(), Tensor(), Tensor(), Tensor()};
     }
@@ -1036,6 +1184,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         holder->has_downsample = has_downsample;
         holder->n_main = n_main;
         const bool x_grad = x.requires_grad();
+        if (training && x_grad) holder->in_link = link_claim(x);
         Tensor out = x;
         for (int i = 0; i + 1 < n_main; ++i)
             out = stage_forward(out, stage(i, true), Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i]);
@@ -1043,7 +1192,10 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         if (has_downsample) shortcut = stage_forward(x, stage(n_total - 1, false), Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1]);
         Tensor y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1]);
         ctx->saved_data["training"] = training;
-        if (training) ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        if (training) {
+            publish_output(holder, y, holder->stages[n_main - 1]);
+            ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
+        }
         return y;
     }
 
@@ -1057,7 +1209,12 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         std::vector<StageGrads> g(n_total);
         // input slots: 0 = x, then STAGE_TENSORS per stage (w at +0, gamma at +2, beta at +3)
         auto need_w = [&](int i) { return ctx->needs_input_grad(1 + i * STAGE_TENSORS); };
-        g[n_main - 1] = stage_backward(grads[0], holder->stages[n_main - 1], true, need_w(n_main - 1), Tensor());
+        // every stage's backward-data launch also does the BatchNorm-backward reduction of the stage in front of it (the first stage's: of
+        // the node that produced x) where the library can -- `fed` says whether the next call receives dz with the sums in place
+        bool fed = false;
+        g[n_main - 1] = stage_backward(grads[0], holder->stages[n_main - 1], true, need_w(n_main - 1), Tensor(), link_state(holder->out_link, grads[0]),
+                                       &holder->stages[n_main - 2], c10::intrusive_ptr<BnLink>(), &fed);
+        link_retire(holder->out_link);
         Tensor shortcut_grad = g[n_main - 1].dres;                     // gradient of the shortcut input
         if (holder->has_downsample) {
             g[n_total - 1] = stage_backward(shortcut_grad, holder->stages[n_total - 1], need_x, need_w(n_total - 1), Tensor());
@@ -1065,10 +1222,14 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         }
         Tensor flow = g[n_main - 1].dx;
         for (int i = n_main - 2; i >= 1; --i) {
-            g[i] = stage_backward(flow, holder->stages[i], true, need_w(i), Tensor());
+            const bool was_fed = fed;
+            g[i] = stage_backward(flow, holder->stages[i], true, need_w(i), Tensor(), was_fed ? 1 : 0, &holder->stages[i - 1], c10::intrusive_ptr<BnLink>(), &fed);
             flow = g[i].dx;
         }
-        g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor());
+        {
+            const bool was_fed = fed;
+            g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor(), was_fed ? 1 : 0, nullptr, holder->in_link, &fed);
+        }
         side_run_jobs();                                              // the unit's weight gradients: second stream, one fork event
         // grouped weight gradients leave when the stage is complete (its first unit carries the downsample projection), when one more
         // unit would not fit into a launch, or per unit (EPI_WGRAD_GROUP=1)
@@ -1085,6 +1246,8 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         }
         for (int k = 0; k < 5; ++k) out.push_back(Tensor());          // geometry, has_downsample, training, momentum, eps
         holder->stages.clear();                                       // release the saved activations now
+        holder->in_link.reset();
+        holder->out_link.reset();
         return out;
     }
 };
@@ -1149,6 +1312,8 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
             StageSaved& sv = holder->stages[0];
             sv.x = x; sv.raw = raw; sv.stats = stats; sv.gamma = gamma; sv.wb = w16; sv.sums_ws = sums_ws; sv.bwd_sums = bwd_sums; sv.flags = flags;
             sv.relu = relu; sv.has_res = false; sv.w_f32 = w.scalar_type() != at::kBFloat16; sv.w = w; sv.need_dx = x.requires_grad();
+            if (x.requires_grad()) holder->in_link = link_claim(x);
+            publish_output(holder, y, sv);
             ctx->saved_data["holder"] = c10::IValue::make_capsule(holder);
         }
         return y;
@@ -1160,7 +1325,9 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
         TORCH_CHECK(!holder->stages.empty(), "deconv_bn_act: backward called twice (the fused nodes free their activations in backward)");
         g_side.jobs.clear();
         const StageSaved& sv = holder->stages[0];
-        BnGrads g = bn_backward(grads[0], sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false);
+        BnGrads g = bn_backward(grads[0], sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false,
+                                link_state(holder->out_link, grads[0]));
+        link_retire(holder->out_link);
         const Tensor& x = sv.x;
         const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)sv.raw.size(1);
         const double flops = 2.0 * B * H * W * 16.0 * Cin * Cout;
@@ -1169,8 +1336,15 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
             dx = at::empty_like(x);
             Tensor& ws = workspace(epi_gemm_workspace_bytes(B * H * W, Cin, 16 * Cout, 1), x);
             ScopedTimer timer("head_deconv4x4s2_bwd_data", flops, 0.0, current_stream(x));
-            check(epi_deconv4x4s2_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(), (size_t)ws.numel(),
-                                           current_stream(x)), "epi_deconv4x4s2_bwd_data");
+            EpiBnReduce red = {};
+            int red_done = 0;
+            if (link_reduce_args(holder->in_link, &red))       // the BatchNorm-backward reduction of the layer that produced x, in this epilogue
+                check(epi_deconv4x4s2_bwd_data_bnred(g.dx.data_ptr(), sv.wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, &red, &red_done, ws.data_ptr(),
+                                                     (size_t)ws.numel(), current_stream(x)), "epi_deconv4x4s2_bwd_data_bnred");
+            else
+                check(epi_deconv4x4s2_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), dx.data_ptr(), B, H, W, Cin, Cout, ws.data_ptr(), (size_t)ws.numel(),
+                                               current_stream(x)), "epi_deconv4x4s2_bwd_data");
+            if (red_done) link_mark_reduced(holder->in_link, dx);
         }
         if (ctx->needs_input_grad(1)) {
             // [Cin, Cout, 4, 4] in channels_last strides = memory [Cin][16 taps][Cout]: the kernel's own output order
@@ -1196,6 +1370,8 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
         }
         side_run_jobs();
         holder->stages.clear();
+        holder->in_link.reset();
+        holder->out_link.reset();
         return {dx, dw, Tensor(), g.dgamma, g.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
@@ -1229,6 +1405,10 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
         }
         ctx->saved_data["has_bias"] = has_bias;
         ctx->saved_data["w_f32"] = w.scalar_type() != at::kBFloat16;
+        if (x.requires_grad()) {
+            auto link = link_claim(x);
+            if (link) ctx->saved_data["in_link"] = c10::IValue::make_capsule(link);
+        }
         ctx->save_for_backward({x, w16, w, has_bias ? *bias_opt : Tensor()});
         return y;
     }
@@ -1249,8 +1429,17 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
             dx = at::empty_like(x);
             Tensor& ws = workspace(epi_gemm_workspace_bytes(M, Cin, Cout, 1), x);
             ScopedTimer timer("head_gemm_bf16", flops, 0.0, current_stream(x));
-            check(epi_gemm_bf16(dy.data_ptr(), Cout, wt.data_ptr(), Cout, dx.data_ptr(), Cin, EPI_BF16, M, Cin, Cout, nullptr, ws.data_ptr(),
-                                (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16");
+            c10::intrusive_ptr<BnLink> link;
+            if (ctx->saved_data.count("in_link")) link = c10::static_intrusive_pointer_cast<BnLink>(ctx->saved_data["in_link"].toCapsule());
+            EpiBnReduce red = {};
+            int red_done = 0;
+            if (link_reduce_args(link, &red))                  // the last deconvolution's BatchNorm-backward reduction, in this epilogue
+                check(epi_gemm_bf16_bnred(dy.data_ptr(), Cout, wt.data_ptr(), Cout, dx.data_ptr(), Cin, M, Cin, Cout, &red, &red_done, ws.data_ptr(),
+                                          (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16_bnred");
+            else
+                check(epi_gemm_bf16(dy.data_ptr(), Cout, wt.data_ptr(), Cout, dx.data_ptr(), Cin, EPI_BF16, M, Cin, Cout, nullptr, ws.data_ptr(),
+                                    (size_t)ws.numel(), current_stream(x)), "epi_gemm_bf16");
+            if (red_done) link_mark_reduced(link, dx);
         }
         if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) {
             // bias gradient = column sums of dy (one more read of the 285 MB logits gradient): second stream as well when nobody reads it early
@@ -1438,6 +1627,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("declare_hook_free", &declare_hook_free,
           "parameters whose post-accumulate hooks were all removed again (torch keeps the empty hook object): their gradients may stay on the "
           "second stream / in a grouped launch / unreduced until the end of the pass; replaces the previous declaration");
+    m.def("bn_bwd_fuse_counts", &bn_bwd_fuse_counts, "(fused, refused) BatchNorm backward passes since the last reset", py::arg("reset") = false);
+    m.def("bn_bwd_fuse_mode", &bn_bwd_fuse_mode,
+          "BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's gradient (EpiBnReduce): 1 on (default; "
+          "EPI_BN_BWD_FUSE=0 turns it off), 0 off; returns the previous setting, a negative argument only queries");
     m.def("wgrad_group_mode", &wgrad_group_mode,
           "grouped weight-gradient launches: 0 one launch per layer, 1 one per autograd node, 2 one per ResNet stage; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");

@@ -55,6 +55,10 @@ _SIGNATURES = {
     "epi_conv2d_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_conv2d_pack_weight_bwd_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
     "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "epi_deconv4x4s2_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_gemm_bf16_bnred": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_bn_act_bwd_reduced": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),
     "epi_conv2d_bwd_weight_deferred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp, _vp]),
     "epi_slab_reduce_chunks": (ctypes.c_longlong, [ctypes.c_longlong]),
@@ -666,6 +670,11 @@ class EpiWgradItem(ctypes.Structure):
     _fields_ = [("x", _vp), ("dy", _vp), ("dw", _vp)] + [(k, _i) for k in ("dw_dtype", "kind", "B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
 
 
+class EpiBnReduce(ctypes.Structure):
+    """include/epipolar_hip.h EpiBnReduce: the BatchNorm-backward reduction fused into a backward-data launch."""
+    _fields_ = [("z", _vp), ("y", _vp), ("bn", _vp), ("sums", _vp), ("relu", _i)]
+
+
 class EpiSlabReduce(ctypes.Structure):
     _fields_ = [("slabs", _vp), ("out", _vp), ("n", ctypes.c_longlong), ("chunk_begin", ctypes.c_longlong), ("nsplit", _i), ("out_bf16", _i)]
 
@@ -827,6 +836,34 @@ def conv2d_pack_weight_bwd(weight, stride=1, padding=0, out=None):
         out = torch.empty(w.numel(), dtype=torch.bfloat16, device=w.device)
     _check(lib.epi_conv2d_pack_weight_bwd(_ptr(w), cout, cin, kh, kw, stride, padding, _ptr(out), _stream()), "epi_conv2d_pack_weight_bwd")
     return out
+
+
+def conv2d_bwd_data_bnred(dy, w_bwd, in_shape, kernel, stride, padding, z, bn, relu=True, y=None, addend=None):
+    """``conv2d_bwd_data`` with the BatchNorm-backward reduction of the layer that produced this convolution's input in the epilogue
+    (epi_conv2d_bwd_data_bnred).  z: that layer's raw output (shape ``in_shape``, channels_last bf16); bn: f32 [4, C] = mean | rstd |
+    scale | shift; y: its saved output when the mask comes from there.  Returns (dx or dz, sums [2, C] f32, fused: bool) -- fused False:
+    dx is the plain gradient and sums is zero."""
+    lib = load()
+    dy = _nhwc_bf16(dy, "dy")
+    z = _nhwc_bf16(z, "z")
+    b, cin, h, wd = in_shape
+    cout = dy.shape[1]
+    kh, kw = (kernel, kernel) if isinstance(kernel, int) else kernel
+    if tuple(z.shape) != (b, cin, h, wd) or tuple(bn.shape) != (4, cin) or bn.dtype != torch.float32 or not bn.is_contiguous():
+        raise ValueError("z must have the shape of dx and bn must be f32 [4, Cin]")
+    dx = torch.empty((b, cin, h, wd), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    sums = torch.zeros(2, cin, dtype=torch.float32, device=dy.device)
+    ws = _workspace(lib.epi_conv2d_workspace_bytes(b, h, wd, cin, cout, kh, kw, stride, padding), dy.device)
+    if addend is not None:
+        addend = _nhwc_bf16(addend, "addend")
+    if y is not None:
+        y = _nhwc_bf16(y, "y")
+    red = EpiBnReduce(_ptr(z), _ptr(y), _ptr(bn), _ptr(sums), 1 if relu else 0)
+    done = ctypes.c_int(0)
+    with _on(dy.device):
+        _check(lib.epi_conv2d_bwd_data_bnred(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(addend),
+                                             ctypes.byref(red), ctypes.byref(done), _ptr(ws), ws.numel(), _stream()), "epi_conv2d_bwd_data_bnred")
+    return dx, sums, bool(done.value)
 
 
 def conv2d_bwd_data(dy, w_bwd, in_shape, kernel, stride=1, padding=0, addend=None):

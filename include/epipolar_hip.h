@@ -231,6 +231,36 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, float* param_grads, epi_stream_t stream);
 
+/* ---- The BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's dy ---------------------------
+ * (autograd of `out = relu(bn(conv(x)) [+ residual])`, pose3d_resnet.py:33-46,68-88,186-199: the gradient of a BatchNorm output is
+ * produced by the backward-data pass of the convolution that consumed it.)  epi_bn_act_bwd starts with a pass over (dy, x, y) for
+ * sum(dz) and sum(dz * xhat), dz = dy * [output > 0].  The *_bnred variants of the backward-data entries do that in their epilogue:
+ *   red->z    raw forward output the BatchNorm normalised, bf16, same rows / stride as the dx being produced
+ *   red->y    saved forward output (mask = y > 0) for residual + ReLU layers, or NULL: mask = scale*z + shift > 0 (ignored without relu)
+ *   red->bn   [mean | rstd | scale | shift], C floats each (the `mean` pointer epi_bn_act_fwd filled, when the four are contiguous)
+ *   red->sums [2C] f32 accumulator, ZERO before the first contribution: += (sum dz | sum dz * xhat)
+ * *red_done = 1: dx holds dz (the masked gradient) and the sums are in -- finish with epi_bn_act_bwd_reduced; dz is also the gradient
+ *   of the residual input, so no second output is written.  *red_done = 0 (split-K launches, rows not 16-byte aligned, EPI_BN_BWD_FUSE=0):
+ *   dx holds the plain gradient, red->sums is untouched -- call epi_bn_act_bwd as before.
+ * epi_bn_act_bwd_reduced: dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R) from dz and the finished sums (no mask, no reduction). */
+typedef struct EpiBnReduce {
+    const void* z;
+    const void* y;
+    const float* bn;
+    float* sums;
+    int relu;
+} EpiBnReduce;
+int epi_bn_act_bwd_reduced(const void* dz, const void* x, long long R, int C, const float* gamma, const float* mean, const float* rstd,
+                           const float* scale_shift, const float* dbeta_dgamma, void* dx, float* fwd_sums_clear, float* param_grads,
+                           epi_stream_t stream);
+int epi_conv2d_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                              int stride, int pad, const void* addend, const EpiBnReduce* red, int* red_done, void* workspace,
+                              size_t workspace_bytes, epi_stream_t stream);
+int epi_deconv4x4s2_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
+                                   const EpiBnReduce* red, int* red_done, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+int epi_gemm_bf16_bnred(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int M, int N, int K, const EpiBnReduce* red,
+                        int* red_done, void* workspace, size_t workspace_bytes, epi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions on the matrix cores -- replace the cuDNN/MIOpen calls behind every bias-free nn.Conv2d of
  * lib/models/pose3d_resnet.py:21-88,130-136 (BasicBlock / Bottleneck conv1..conv3, downsample.0; groups 1, dilation 1).

@@ -517,3 +517,127 @@ def hip_bn_module(c, gamma, beta, dev):
         bn.bias.copy_(beta)
     bn.train()
     return bn
+
+
+# (Cin = channels of dx, Cout, k, stride, H of dx, batch, mask from y, addend): the launch each takes is noted
+BNRED_CASES = [
+    (64, 256, 1, 1, 16, 4, False, False),      # plain 1x1, 64 columns (tall tile)
+    (256, 64, 1, 1, 64, 4, True, True),        # K = 64, N = 256, 16 384 rows (a unit's first stage, shortcut added): A-stationary shape, kept on the generic kernel
+    (512, 128, 1, 1, 32, 16, True, True),      # the same with K = 128
+    (64, 64, 3, 1, 32, 4, False, False),       # patch-stationary 3x3
+    (128, 128, 3, 1, 16, 8, False, False),     # patch-stationary 3x3, 128 columns, too few rows: split launch, no fusion
+    (128, 128, 3, 1, 32, 32, False, False),    # patch-stationary 3x3, 128 columns (ResNet-50 layer2 at the bench shape)
+    (128, 128, 3, 2, 32, 4, False, False),     # stride 2: four parity phases, scattered rows
+    (256, 512, 1, 2, 32, 4, True, True),       # the downsample projection's geometry (three phases without taps)
+    (256, 1088, 1, 1, 32, 16, False, False),   # the final layer's backward-data (K = 1088): 128-column tiles
+]
+
+
+BNRED_MAY_SPLIT = {c for c in BNRED_CASES if c[:6] == (128, 128, 3, 1, 16, 8)}       # 2 048 rows x 1 152 of K: channel-split patch launch
+
+
+@pytest.mark.parametrize("case", BNRED_CASES, ids=["%dfrom%d_k%ds%d_h%d_b%d_y%d_add%d" % c for c in BNRED_CASES])
+def test_conv2d_bwd_data_with_fused_batchnorm_backward_reduction(case):
+    """epi_conv2d_bwd_data_bnred: the epilogue masks the gradient (dz = dx * [bn output > 0]) and accumulates sum(dz), sum(dz * xhat)
+    per channel.  Against the SAME launch without the fusion (the bf16 dx it would have written) masked in PyTorch, and float64 sums."""
+    from epipolarpose_amd import hip
+    cin, cout, k, stride, h, b, from_y, with_addend = case
+    pad = k // 2
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(cin + 3 * cout + k + stride)
+    ho = (h + 2 * pad - k) // stride + 1
+    dy = _rand((b, cout, ho, ho), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    w = _rand((cout, cin, k, k), gen, scale=(2.0 / (cin * k * k)) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    z = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    addend = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last) if with_addend else None
+    mean = torch.randn(cin, generator=gen) * 0.2
+    rstd = torch.rand(cin, generator=gen) + 0.5
+    gamma, beta = torch.randn(cin, generator=gen), torch.randn(cin, generator=gen) * 0.3
+    scale = gamma * rstd
+    shift = beta - mean * scale
+    bn = torch.stack([mean, rstd, scale, shift]).to(dev).contiguous()
+    y = None
+    if from_y:          # residual + ReLU layer: the mask is the saved output, NOT a function of z alone
+        y = torch.relu(z.float() * scale.to(dev).view(1, -1, 1, 1) + shift.to(dev).view(1, -1, 1, 1) + _rand((b, cin, h, h), gen).to(dev).float())
+        y = y.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wb = hip.conv2d_pack_weight_bwd(w, stride, pad)
+    plain = hip.conv2d_bwd_data(dy, wb, (b, cin, h, h), k, stride, pad, addend=addend)
+    dz, sums, fused = hip.conv2d_bwd_data_bnred(dy, wb, (b, cin, h, h), k, stride, pad, z, bn, relu=True, y=y, addend=addend)
+    if not fused:       # a split-K launch (few rows): the contract is "plain gradient, accumulator untouched" -- and only where that is expected
+        assert case in BNRED_MAY_SPLIT, "this geometry is expected on a launch that carries the fused reduction"
+        assert torch.equal(dz, plain) and float(sums.abs().max()) == 0.0
+        return
+    zf = z.float()
+    if from_y:
+        mask = y.float() > 0
+    else:
+        t = zf * bn[2].view(1, -1, 1, 1) + bn[3].view(1, -1, 1, 1)
+        mask = t > 0
+        near = t.abs() <= 1e-6 * (zf.abs() * bn[2].abs().view(1, -1, 1, 1) + bn[3].abs().view(1, -1, 1, 1))   # a fused multiply-add may decide these differently
+    ref = torch.where(mask, plain, torch.zeros_like(plain))
+    same = dz == ref
+    if not from_y:
+        same = same | near
+    assert bool(same.all()), int((~same).sum())
+    d64 = dz.double()
+    xhat = (zf.double() - bn[0].double().view(1, -1, 1, 1)) * bn[1].double().view(1, -1, 1, 1)
+    ref_s = torch.stack([d64.sum(dim=(0, 2, 3)), (d64 * xhat).sum(dim=(0, 2, 3))])
+    scale_s = torch.stack([d64.abs().sum(dim=(0, 2, 3)), (d64 * xhat).abs().sum(dim=(0, 2, 3))]) + 1e-12
+    assert float(((sums.double() - ref_s).abs() / scale_s).max()) <= 2e-6          # fp32 accumulation of a few thousand terms per tile, then atomics
+    # no ReLU: nothing is masked, the sums still come out
+    dz2, sums2, fused2 = hip.conv2d_bwd_data_bnred(dy, wb, (b, cin, h, h), k, stride, pad, z, bn, relu=False, y=None, addend=addend)
+    assert fused2 and torch.equal(dz2, plain)
+    p64 = plain.double()
+    ref2 = torch.stack([p64.sum(dim=(0, 2, 3)), (p64 * xhat).sum(dim=(0, 2, 3))])
+    scale2 = torch.stack([p64.abs().sum(dim=(0, 2, 3)), (p64 * xhat).abs().sum(dim=(0, 2, 3))]) + 1e-12
+    assert float(((sums2.double() - ref2).abs() / scale2).max()) <= 2e-6
+
+
+def test_fused_batchnorm_backward_reduction_in_the_network():
+    """The whole pose network, one backward pass with the reductions fused into the backward-data launches (across autograd nodes:
+    unit -> unit, head -> backbone, final layer -> head) and one without: the fused pass must actually happen (counted by the glue),
+    and every parameter gradient must agree with the unfused pass to the noise of two unfused passes (atomics)."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    import copy
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.EXTRA.NUM_LAYERS = 50
+    j = 4
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, 16, [128, 128]
+    torch.manual_seed(5)
+    base = get_pose_net(cfg, is_train=False).to(dev).train()
+    x = torch.randn(16, 3, 128, 128, device=dev)
+    gt = (torch.rand(16, 3 * j, device=dev) - 0.5) * 0.4
+    vis = torch.ones(16, 3 * j, device=dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+
+    def grads(fuse):
+        prev = hip.glue().bn_bwd_fuse_mode(1 if fuse else 0)
+        try:
+            m = copy.deepcopy(base)
+            hip.glue().bn_bwd_fuse_counts(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x)
+            crit(out, gt, vis).backward()
+            torch.cuda.synchronize()
+            counts = hip.glue().bn_bwd_fuse_counts(True)
+            return {k: p.grad.detach().float().clone() for k, p in m.named_parameters()}, counts, out.detach().float()
+        finally:
+            hip.glue().bn_bwd_fuse_mode(prev)
+    a, ca, oa = grads(False)
+    b, cb, ob = grads(True)
+    assert ca == [0, 0]
+    # ResNet-50: 16 units x 3 BatchNorms + 3 head layers + stem + 4 projections = 56; the stem (max-pool in between), the projections
+    # (fed by the shortcut gradient) and the split-K launches of the small late layers keep their own reduction
+    assert cb[0] >= 20 and cb[1] == 0, cb              # (27 at this size; 128 x 128 images leave layer3 / layer4 to split launches)
+    # the forward passes are two runs of the same code: where they already differ by an atomics-order rounding flip the gradients are
+    # not comparable at random initialisation (tests/test_hip_step_in_backward.py); compare only like with like
+    if float((oa - ob).abs().max()) <= 1e-3 * float(oa.abs().max()):
+        for k in a:
+            ca_, cb_ = a[k].reshape(-1).double(), b[k].reshape(-1).double()
+            cos = float(ca_ @ cb_ / (ca_.norm() * cb_.norm() + 1e-300))
+            assert cos >= 0.98, (k, cos)
