@@ -248,7 +248,9 @@ def build_roofline(args, ksum, glue_times, model, images):
         nbytes = sum(v["algorithmic_bytes_per_step"] for v in bn.values())
         out["batchnorm"] = {"what": "bn_stats / bn_apply / bn_bwd_reduce / bn_bwd_apply: the dominant HBM-bound family (fused BatchNorm + "
                                     "residual + ReLU, forward and backward)", "bound": "hbm", "ms_per_step": round(ms, 4),
-                            "launches_per_step": round(sum(v["launches_per_step"] for v in bn.values()) * 2, 1),
+                            # (a "+" entry is two kernels -- its own statistics / reduction pass and the apply pass --, the others one: the
+                            #  statistics came from the producing GEMM's epilogue, the backward reduction from the backward-data GEMM's)
+                            "launches_per_step": round(sum(v["launches_per_step"] * (2 if "+" in k else 1) for k, v in bn.items()), 1),
                             "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if not out:          # hipGraph replay: only the criterion probe was timed
@@ -261,7 +263,38 @@ def build_roofline(args, ksum, glue_times, model, images):
                        "the timed region (recording them inside it makes the step host-bound and would falsify `value`); in these steps the "
                        "weight gradients run on the main stream too, so that every figure is the kernel's own duration")
     out["note"] = "traffic: not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*pmc*)"
+    default_workload = (args.workload == "fs" and args.layers == 50 and args.image == 256 and args.batch == 32 and args.views == 4 and
+                        args.joints == 17 and args.depth == 64 and not args.fp32 and not args.graph)
+    pmc = pmc_traffic(default_workload)
+    if pmc and "traffic" in out and out.get("launches_per_step"):
+        g = pmc["families"].get("implicit_gemm")
+        if g:
+            out["traffic"] = round(g["hbm_bytes_per_step"] / out["launches_per_step"])
+            out["traffic_per_step"] = round(g["hbm_bytes_per_step"])
+        bnp = pmc["families"].get("batchnorm")
+        if bnp and "batchnorm" in out:
+            out["batchnorm"]["traffic_per_step"] = round(bnp["hbm_bytes_per_step"])
+            out["batchnorm"]["algorithmic_bytes_per_step"] = round(sum(v["algorithmic_bytes_per_step"] for v in bn.values()))
+        out["note"] = ("traffic: HBM bytes per launch of the family (per step / launches_per_step) from the committed PMC passes of this same "
+                       "command and workload -- %s; %s; %s" % (PMC_FILE, pmc["source"], pmc["correction"]))
     return out
+
+
+PMC_FILE = "profiles/r03_pmc_step_families.json"
+
+
+def pmc_traffic(default_workload):
+    """The committed summary of the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py at the default workload
+    (tools/gpu_pmc_step.sh): counters cannot be read from inside the process, so `roofline.traffic` quotes that file -- and only for the
+    workload it was taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
+    if not default_workload or not os.path.isfile(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
