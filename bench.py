@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (functional testing only)")
     ap.add_argument("--force-grad-sync", action="store_true", help="diagnostic: run the N>1 gradient-bucket path at N=1 (copies "
                     "into the flat buckets, no collective) to price its overhead on one GPU")
+    ap.add_argument("--refiner-leg", action="store_true", help="also time the refiner MLP beside the step (configs[4] names it: post-lift refinement of "
+                    "the batch's poses in inference mode, and one refiner training step at the reference's batch size 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ss-leg", action="store_true", help="skip the extra configs[2] (self-supervised) measurement that rides along")
     ap.add_argument("--no-loader-leg", action="store_true", help="skip the extra measurement with the GPU input pipeline in the step "
@@ -280,6 +282,48 @@ def build_roofline(args, ksum, glue_times, model, images):
     return out
 
 
+def refiner_leg(args, device):
+    """configs[4]'s "refiner MLP post-lift" (refiner/model.py:74-143, refiner/main.py:31-60), timed beside the pose step: (a) the refinement of one
+    batch of lifted poses (15 joints x 3, inference mode, both heads), (b) one training step of the refiner at the reference's DataLoader batch size."""
+    from epipolarpose_amd.refiner.main import TwoHeadMSE, make_optimizer
+    from epipolarpose_amd.refiner.model import get_model, weight_init
+    torch.manual_seed(7)
+    model = get_model(weights=None).to(device)
+    model.apply(weight_init)
+    poses = torch.randn(args.batch, 45, device=device)
+    model.eval()
+    with torch.no_grad():
+        for _ in range(5):
+            model(poses)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            model(poses)
+        torch.cuda.synchronize()
+        infer_ms = (time.perf_counter() - t0) / 50 * 1e3
+    model.train()
+    criterion, optimizer = TwoHeadMSE(), make_optimizer(model, lr=1e-3)
+    inp, tar = torch.randn(64, 45, device=device), torch.randn(64, 45, device=device)
+
+    def rstep():
+        optimizer.zero_grad()
+        loss = criterion(model(inp), tar)
+        loss.backward()
+        optimizer.step()
+        return loss
+    for _ in range(5):
+        rstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        loss = rstep()
+    torch.cuda.synchronize()
+    train_ms = (time.perf_counter() - t0) / 50 * 1e3
+    return {"workload": "refiner MLP (LinearModelPG, 1024 wide, 2 stages): post-lift refinement of %d poses in inference mode; one training step at batch 64" % args.batch,
+            "post_lift_ms_per_batch": round(infer_ms, 4), "post_lift_poses_per_s": round(args.batch / (infer_ms * 1e-3), 1),
+            "train_ms_per_step": round(train_ms, 4), "train_samples_per_s": round(64 / (train_ms * 1e-3), 1), "final_loss": round(float(loss.item()), 6)}
+
+
 PMC_FILE = "profiles/r03_pmc_step_families.json"
 
 
@@ -471,6 +515,10 @@ def main():
                        "ms_per_step": round(l_elapsed / args.steps * 1e3, 3), "host_ms_per_batch_pipeline_only": round(host_batch * 1e3, 3),
                        "final_loss": round(float(l_loss.item()), 6)}
 
+    refiner_line = None
+    if args.refiner_leg and not use_graph:
+        refiner_line = refiner_leg(args, device)
+
     if rank == 0:
         global_batch = args.batch * world
         elem = 4 if args.fp32 else 2
@@ -483,10 +531,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": ("configs[1]: ResNet-%d Integral-pose, 4-view %dx%d synthetic, batch=%d/GPU, fully-supervised "
-                                    "SmoothL1 loss" if args.workload == "fs" else
-                                    "configs[2]: ResNet-%d self-supervised, 4-view %dx%d epipolar-triangulation pseudo-labels, "
-                                    "batch=%d/GPU") % (args.layers, args.image, args.image, args.batch),
+            # (the per-GPU share of configs[4] -- ResNet-152 at 384 x 384 -- is `--layers 152 --image 384`: any other shape than the default names itself)
+            "config": {"workload": (("configs[4] per-GPU share: " if (args.layers, args.image) == (152, 384) else
+                                     ("configs[1]: " if args.workload == "fs" else "configs[2]: ") if (args.layers, args.image) == (50, 256) else "") +
+                                    ("ResNet-%d Integral-pose, 4-view %dx%d synthetic, batch=%d/GPU, fully-supervised SmoothL1 loss" if args.workload == "fs" else
+                                     "ResNet-%d self-supervised, 4-view %dx%d epipolar-triangulation pseudo-labels, batch=%d/GPU")
+                                    % (args.layers, args.image, args.image, args.batch)),
                        "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
                        "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6),
                        "launch": "hipGraph replay" if use_graph else "eager",
@@ -498,6 +548,7 @@ def main():
             "roofline": roofline,
             "workload_ss": ss_line,
             "workload_loader": loader_line,
+            "workload_refiner": refiner_line,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, scenes)
