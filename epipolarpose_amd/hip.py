@@ -39,6 +39,8 @@ _SIGNATURES = {
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_poly": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_fundamental_8point": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "epi_fundamental_lmeds_medians": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "epi_fundamental_errors": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "epi_correct_matches": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "epi_reproject_labels": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _vp, _vp, _vp]),
     "epi_self_supervision": (_i, [_vp, _i, _i, _i, ctypes.POINTER(EpiViewMeta), _d, _d, _d, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
@@ -417,6 +419,33 @@ def fundamental_8point(u1, u2):
     with _on(u1.device):
         _check(lib.epi_fundamental_8point(_ptr(u1), _ptr(u2), g, j, _ptr(f), _ptr(status), _stream()), "epi_fundamental_8point")
     return f, status
+
+
+def fundamental_lmeds_medians(f, u1, u2):
+    """Median symmetric epipolar error of every candidate: f [H, 3, 3] float64, u1 / u2 [N, 2] float64 -> medians [H] float64."""
+    lib = load()
+    f = _dev(f, torch.float64, "f").contiguous()
+    u1, u2 = _dev(u1, torch.float64, "u1").contiguous(), _dev(u2, torch.float64, "u2").contiguous()
+    if f.dim() != 3 or f.shape[1:] != (3, 3) or u1.dim() != 2 or u1.shape[1] != 2 or u2.shape != u1.shape:
+        raise ValueError("f must be [H, 3, 3] and u1, u2 [N, 2]")
+    med = torch.empty((f.shape[0],), dtype=torch.float64, device=f.device)
+    with _on(f.device):
+        _check(lib.epi_fundamental_lmeds_medians(_ptr(f), f.shape[0], _ptr(u1), _ptr(u2), u1.shape[0], _ptr(med), _stream()),
+               "epi_fundamental_lmeds_medians")
+    return med
+
+
+def fundamental_errors(f, u1, u2):
+    """float32 symmetric epipolar errors [N] of ONE matrix f [3, 3] float64 over the pairs u1 / u2 [N, 2] float64."""
+    lib = load()
+    f = _dev(f, torch.float64, "f").contiguous()
+    u1, u2 = _dev(u1, torch.float64, "u1").contiguous(), _dev(u2, torch.float64, "u2").contiguous()
+    if f.shape != (3, 3) or u1.dim() != 2 or u1.shape[1] != 2 or u2.shape != u1.shape:
+        raise ValueError("f must be [3, 3] and u1, u2 [N, 2]")
+    err = torch.empty((u1.shape[0],), dtype=torch.float32, device=f.device)
+    with _on(f.device):
+        _check(lib.epi_fundamental_errors(_ptr(f), _ptr(u1), _ptr(u2), u1.shape[0], _ptr(err), _stream()), "epi_fundamental_errors")
+    return err
 
 
 def correct_matches(f, u1, u2):

@@ -48,11 +48,13 @@ class Camera:
         return np.dot(np.dot(self.camera_matrix.T, fundamental_mat), self.camera_matrix)
 
     def get_fundamental_matrix(self, u1, u2):
-        """cameras.py:136-143 (integer pixel coordinates as the reference casts them); 8-point on the GPU, all inliers."""
-        from .triangulation import find_fundamental_mat_8point
+        """cameras.py:136-143: integer pixel coordinates as the reference casts them, the least-median-of-squares estimate
+        (``cv2.FM_LMEDS``: utils/triangulation.py find_fundamental_mat_lmeds) and the inlier pairs it selects."""
+        from .triangulation import find_fundamental_mat_lmeds
         u1, u2 = np.int32(u1), np.int32(u2)
-        f, _ = find_fundamental_mat_8point(u1.astype(np.float64), u2.astype(np.float64))
-        return f, (u1, u2)
+        f, mask = find_fundamental_mat_lmeds(u1, u2)
+        keep = mask.ravel() == 1
+        return f, (u1[keep], u2[keep])
 
     def world_to_camera_frame(self, P):
         assert len(P.shape) == 2 and P.shape[1] == 3

@@ -137,6 +137,14 @@ int epi_triangulate_poly(const void* kps, int kps_stride, const void* P, int dty
  * status [G] int32 or NULL: 1, or 0 for degenerate input (J < 8, coincident points: F = 0). */
 int epi_fundamental_8point(const double* u1, const double* u2, int G, int J, double* F, int32_t* status, epi_stream_t stream);
 
+/* The part of cv2.findFundamentalMat(points1, points2, FM_LMEDS) (cameras.py:136-143) that scales with the number of correspondences:
+ * F [H][3][3] f64 candidate matrices (the 7-point solutions of the random samples: host side, utils/triangulation.py
+ * find_fundamental_mat_lmeds), u1/u2 [N][2] f64 -> medians [H] f64 = median over the N pairs of the float32 symmetric epipolar error
+ * max(d(x1, F^T x2)^2, d(x2, F x1)^2) (mean of the two middle elements for even N); epi_fundamental_errors: the errors [N] f32 of one
+ * matrix (the inlier test err <= sigma^2).  OpenCV 4.1.0 ptsetreg.cpp / fundam.cpp restated: parity with OpenCV itself is unpinned. */
+int epi_fundamental_lmeds_medians(const double* F, int H, const double* u1, const double* u2, int N, double* medians, epi_stream_t stream);
+int epi_fundamental_errors(const double* F, const double* u1, const double* u2, int N, float* err, epi_stream_t stream);
+
 /* cv2.correctMatches(F, points1, points2) (called at triangulation.py:210,216), batched: F [G][3][3],
  * u1/u2/out1/out2 [G][J][2], all f64 device pointers.  out may alias in. */
 int epi_correct_matches(const double* F, const double* u1, const double* u2, int G, int J,

@@ -246,3 +246,158 @@ def essential_from_fundamental(f, k1, k2=None):
     k1 = np.asarray(k1, np.float64)
     k2 = k1 if k2 is None else np.asarray(k2, np.float64)
     return k2.T @ np.asarray(f, np.float64) @ k1
+
+
+# ---- cv2.findFundamentalMat(u1, u2, cv2.FM_LMEDS) (cameras.py:136-143) ---------------------------------------------------------------
+# The algorithm lives in OpenCV (conda pin 4.1.0; absent here): modules/calib3d/src/fundam.cpp (findFundamentalMat, run7Point,
+# FMEstimatorCallback), modules/calib3d/src/ptsetreg.cpp (LMeDSPointSetRegistrator::run, getSubset, RANSACUpdateNumIters),
+# modules/core (cv::RNG, solveCubic).  Restated from its published source; parity with OpenCV itself is UNPINNED (no cv2 in the image).
+# What makes it deterministic is OpenCV's own design: the sampler is a fixed-seed generator, `RNG rng((uint64)-1)`.
+CV_RNG_COEFF = 4164903690
+
+
+class CvRNG:
+    """cv::RNG: multiply-with-carry, state 64 bit; next() returns the low 32 bits of the new state."""
+
+    def __init__(self, state=0xFFFFFFFFFFFFFFFF):
+        self.state = state if state else 0xFFFFFFFF
+
+    def next(self):
+        self.state = ((self.state & 0xFFFFFFFF) * CV_RNG_COEFF + (self.state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        return self.state & 0xFFFFFFFF
+
+    def uniform_int(self, a, b):
+        return a if a == b else int(self.next() % (b - a) + a)
+
+
+def ransac_update_num_iters(p, ep, model_points, max_iters):
+    """ptsetreg.cpp RANSACUpdateNumIters."""
+    p, ep = min(max(p, 0.0), 1.0), min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, np.finfo(np.float64).tiny)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < np.finfo(np.float64).tiny:
+        return 0
+    num, denom = np.log(num), np.log(denom)
+    return max_iters if denom >= 0 or -num >= max_iters * (-denom) else int(np.rint(num / denom))
+
+
+def _have_collinear_points(pts, count):
+    """fundam.cpp haveCollinearPoints: is the LAST selected point on a line through two earlier ones (or on top of one)?"""
+    i = count - 1
+    eps = float(np.finfo(np.float32).eps)
+    for j in range(i):
+        dx1, dy1 = float(pts[j][0]) - float(pts[i][0]), float(pts[j][1]) - float(pts[i][1])
+        for k in range(j):
+            dx2, dy2 = float(pts[k][0]) - float(pts[i][0]), float(pts[k][1]) - float(pts[i][1])
+            if abs(dx2 * dy1 - dy2 * dx1) <= eps * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                return True
+    return False
+
+
+def fm_get_subset(rng, m1, m2, model_points=7, max_attempts=1000):
+    """ptsetreg.cpp getSubset: model_points DISTINCT indices (a duplicate is redrawn), accepted when neither sample is degenerate."""
+    count = len(m1)
+    for _ in range(max_attempts):
+        idx = []
+        for _i in range(model_points):
+            v = rng.uniform_int(0, count)
+            while v in idx:
+                v = rng.uniform_int(0, count)
+            idx.append(v)
+        if not _have_collinear_points(m1[idx], model_points) and not _have_collinear_points(m2[idx], model_points):
+            return idx
+    return None
+
+
+def fm_run_7point(s1, s2):
+    """fundam.cpp run7Point: the matrices of the two-dimensional null space of the 7 epipolar equations with det = 0, F[2][2] = 1.
+    (Any basis of the null space gives the same set of matrices; OpenCV takes the last two right-singular vectors.)"""
+    x0, y0, x1, y1 = s1[:, 0].astype(np.float64), s1[:, 1].astype(np.float64), s2[:, 0].astype(np.float64), s2[:, 1].astype(np.float64)
+    a = np.stack([x1 * x0, x1 * y0, x1, y1 * x0, y1 * y0, y1, x0, y0, np.ones(7)], axis=1)
+    vt = np.linalg.svd(a, full_matrices=True)[2]
+    f1, f2 = vt[7].copy(), vt[8].copy()
+    f1 -= f2                                          # f = lambda * f1 + f2 after this line, lambda = the original mixing weight
+    det = lambda m: float(np.linalg.det(m.reshape(3, 3)))
+    # the cubic det(lambda * f1 + f2) through four samples of lambda (exact for a cubic)
+    lam = np.array([-1.0, 0.0, 1.0, 2.0])
+    vals = np.array([det(l * f1 + f2) for l in lam])
+    coeffs = np.linalg.solve(np.vander(lam, 4), vals)       # c3 l^3 + c2 l^2 + c1 l + c0
+    roots = np.roots(coeffs) if abs(coeffs[0]) > 0 else np.roots(coeffs[1:])
+    out = []
+    for r in roots:
+        if abs(r.imag) > 1e-9 * max(1.0, abs(r.real)):
+            continue
+        lam_k, mu = float(r.real), 1.0
+        s = f1[8] * lam_k + f2[8]
+        f = np.empty(9)
+        if abs(s) > np.finfo(np.float64).eps:
+            mu = 1.0 / s
+            lam_k *= mu
+            f[8] = 1.0
+        else:
+            f[8] = 0.0
+        f[:8] = f1[:8] * lam_k + f2[:8] * mu
+        out.append(f.reshape(3, 3))
+    return out
+
+
+def fm_compute_error(f, m1, m2):
+    """fundam.cpp FMEstimatorCallback::computeError: max of the two squared point-to-epipolar-line distances, stored as float32."""
+    f = np.asarray(f, np.float64)
+    x1, y1, x2, y2 = (m1[:, 0].astype(np.float64), m1[:, 1].astype(np.float64), m2[:, 0].astype(np.float64), m2[:, 1].astype(np.float64))
+    a = f[0, 0] * x1 + f[0, 1] * y1 + f[0, 2]
+    b = f[1, 0] * x1 + f[1, 1] * y1 + f[1, 2]
+    c = f[2, 0] * x1 + f[2, 1] * y1 + f[2, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s2 = 1.0 / (a * a + b * b)
+        d2 = x2 * a + y2 * b + c
+        a = f[0, 0] * x2 + f[1, 0] * y2 + f[2, 0]
+        b = f[0, 1] * x2 + f[1, 1] * y2 + f[2, 1]
+        c = f[0, 2] * x2 + f[1, 2] * y2 + f[2, 2]
+        s1 = 1.0 / (a * a + b * b)
+        d1 = x1 * a + y1 * b + c
+        e1, e2 = d1 * d1 * s1, d2 * d2 * s2
+    return np.where(e1 < e2, e2, e1).astype(np.float32)       # std::max(e1, e2)
+
+
+def fm_median(err):
+    """LMeDSPointSetRegistrator: the sorted errors' middle element, or the mean of the two middle ones (float sum, then * 0.5)."""
+    e = np.sort(np.asarray(err, np.float32))
+    n = len(e)
+    return float(e[n // 2]) if n % 2 else float(np.float32(e[n // 2 - 1] + e[n // 2])) * 0.5
+
+
+def fundamental_lmeds(u1, u2, confidence=0.99, max_iters=1000):
+    """cv2.findFundamentalMat(u1, u2, cv2.FM_LMEDS) -> (F [3, 3] float64 or None, mask uint8 [N]).  u1, u2 [N, 2]; OpenCV converts the
+    points to float32 first (the reference hands it int32 pixel coordinates, cameras.py:137-138)."""
+    m1, m2 = np.asarray(u1, np.float32).reshape(-1, 2), np.asarray(u2, np.float32).reshape(-1, 2)
+    count, model_points = len(m1), 7
+    if count < model_points:
+        return None, np.zeros(count, np.uint8)
+    niters = max(ransac_update_num_iters(confidence, 0.45, model_points, max_iters), 3)
+    rng = CvRNG(0xFFFFFFFFFFFFFFFF)
+    best, min_median = None, np.inf
+    for it in range(niters if count > model_points else 1):
+        if count > model_points:
+            idx = fm_get_subset(rng, m1, m2, model_points)
+            if idx is None:
+                if it == 0:
+                    return None, np.zeros(count, np.uint8)
+                break
+            s1, s2 = m1[idx], m2[idx]
+        else:
+            s1, s2 = m1, m2
+        for f in fm_run_7point(s1, s2):
+            median = fm_median(fm_compute_error(f, m1, m2))
+            if median < min_median:
+                min_median, best = median, f
+    if best is None:
+        return None, np.zeros(count, np.uint8)
+    with np.errstate(divide="ignore", invalid="ignore"):     # count == 7: 5 / 0 = inf as in C++ (every point an inlier; inf * 0 = NaN -> 0.001)
+        sigma = 2.5 * 1.4826 * (1.0 + np.float64(5.0) / np.float64(count - model_points)) * np.sqrt(min_median)
+    sigma = sigma if sigma > 0.001 else 0.001                # MAX(sigma, 0.001)
+    thresh = np.float32(sigma * sigma)
+    mask = (fm_compute_error(best, m1, m2) <= thresh).astype(np.uint8)
+    if int(mask.sum()) < model_points:
+        return None, np.zeros(count, np.uint8)
+    return best, mask

@@ -310,3 +310,47 @@ def test_fundamental_8point_vs_oracle(dev):
     np.testing.assert_allclose(fm, ft / ft[2, 2], atol=1e-8 * np.abs(ft / ft[2, 2]).max())
     k = np.array([[1100.0, 0, 500.0], [0, 1100.0, 510.0], [0, 0, 1.0]])
     np.testing.assert_allclose(tri.essential_matrix(fm, k), k.T @ fm @ k)
+
+
+@pytest.mark.parametrize("n,outliers", [(60, 20), (17, 0), (1001, 400), (7, 0)])
+def test_fundamental_lmeds_vs_oracle(dev, n, outliers):
+    """cv2.findFundamentalMat(FM_LMEDS) mirror (cameras.py:136-143): host sampling + 7-point, GPU medians / errors == the oracle's plain restatement
+    (same samples from OpenCV's fixed-seed generator, so the same matrix and the same mask), through `Camera.get_fundamental_matrix` as well."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.synthetic import make_cameras, project
+    from epipolarpose_amd.utils import triangulation as tri
+    from epipolarpose_amd.utils.cameras import Camera
+    cams = make_cameras(4)
+    rng = np.random.default_rng(n + outliers)
+    x = rng.normal(0, 300, size=(n, 3)) + [0, 0, 900]
+    u1 = project(x, cams[0])[0] + rng.normal(0, 0.5, (n, 2))
+    u2 = project(x, cams[2])[0] + rng.normal(0, 0.5, (n, 2))
+    bad = rng.choice(n, outliers, replace=False)
+    u2[bad] += rng.uniform(40, 120, (outliers, 2)) * rng.choice([-1, 1], (outliers, 2))
+    i1, i2 = np.int32(u1), np.int32(u2)
+    ref_f, ref_mask = o_tri.fundamental_lmeds(i1, i2)
+    f, mask = tri.find_fundamental_mat_lmeds(i1, i2)
+    assert ref_f is not None and f is not None and mask.shape == (n, 1)
+    np.testing.assert_allclose(f, ref_f, rtol=1e-9, atol=1e-12 * np.abs(ref_f).max())
+    assert np.array_equal(mask.ravel(), ref_mask)
+    if outliers:
+        good = np.setdiff1d(np.arange(n), bad)
+        assert mask.ravel()[good].mean() >= 0.8 and mask.ravel()[bad].mean() <= 0.15
+    # the scoring kernels against the oracle on arbitrary candidates (odd and even N take different median paths)
+    cand = np.stack([ref_f, ref_f + 1e-7 * rng.normal(size=(3, 3)), rng.normal(size=(3, 3))])
+    d1, d2 = torch.from_numpy(i1.astype(np.float64)).to(dev), torch.from_numpy(i2.astype(np.float64)).to(dev)
+    med = hip.fundamental_lmeds_medians(torch.from_numpy(cand).to(dev), d1, d2).cpu().numpy()
+    for h in range(3):
+        e_ref = o_tri.fm_compute_error(cand[h], i1.astype(np.float32), i2.astype(np.float32))
+        e = hip.fundamental_errors(torch.from_numpy(cand[h]).to(dev), d1, d2).cpu().numpy()
+        np.testing.assert_allclose(e, e_ref, rtol=2e-6, atol=1e-10)        # (a sample point fits its own candidate: d = a cancellation at 1e-12)
+        assert abs(med[h] - o_tri.fm_median(e)) <= 1e-12 * max(1.0, abs(med[h]))          # the median of the kernel's own errors, exactly
+    for k in (n - 1, n - 2) if n > 8 else ():              # the other parity of N
+        m2 = hip.fundamental_lmeds_medians(torch.from_numpy(cand[:1]).to(dev), d1[:k], d2[:k]).cpu().numpy()
+        e = hip.fundamental_errors(torch.from_numpy(cand[0]).to(dev), d1[:k], d2[:k]).cpu().numpy()
+        assert abs(m2[0] - o_tri.fm_median(e)) <= 1e-12 * max(1.0, abs(m2[0]))
+    # the reference's method
+    cam = Camera((np.eye(3), np.zeros((3, 1)), (1100.0, 1100.0), (500.0, 510.0), None, None, "cam"))       # cameras.py:8
+    fm, (k1, k2) = cam.get_fundamental_matrix(u1, u2)
+    np.testing.assert_allclose(fm, ref_f, rtol=1e-9, atol=1e-12 * np.abs(ref_f).max())
+    assert k1.dtype == np.int32 and len(k1) == len(k2) == int(ref_mask.sum()) and np.array_equal(k1, i1[ref_mask == 1])

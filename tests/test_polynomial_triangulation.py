@@ -190,3 +190,78 @@ def test_hostcheck_8point_matches_oracle(hostlib, n, noise):
     assert ok and okd == 1
     np.testing.assert_allclose(fd.reshape(3, 3), f, rtol=0, atol=1e-11 * np.abs(f).max())
     assert hostlib.hostcheck_fundamental_8point(_dp(u1), _dp(u2), 7, _dp(fd)) == 0 and not fd.any()
+
+
+# ------------------------------------------------------------------ fundamental matrix from matches (least median of squares)
+def _sym_epi_dist(f, u1, u2):
+    """the larger of the two point-to-epipolar-line distances, in pixels"""
+    l2, l1 = _h(u1) @ f.T, _h(u2) @ f
+    d2 = np.abs((l2 * _h(u2)).sum(1)) / np.hypot(l2[:, 0], l2[:, 1])
+    d1 = np.abs((l1 * _h(u1)).sum(1)) / np.hypot(l1[:, 0], l1[:, 1])
+    return np.maximum(d1, d2)
+
+
+def test_oracle_cv_rng_and_iteration_count():
+    """cv::RNG is a multiply-with-carry generator (x = x_lo * 4164903690 + x_hi) and OpenCV seeds the LMedS sampler with (uint64)-1;
+    the iteration count for confidence 0.99, 45 % outliers, 7 points is round(log(0.01) / log(1 - 0.55^7)) = 300."""
+    r = o_tri.CvRNG()
+    s = 0xFFFFFFFFFFFFFFFF
+    for _ in range(5):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+        assert r.next() == s & 0xFFFFFFFF
+    assert o_tri.CvRNG(0).state == 0xFFFFFFFF                            # a zero seed is replaced
+    assert o_tri.ransac_update_num_iters(0.99, 0.45, 7, 1000) == 300
+    assert o_tri.ransac_update_num_iters(0.99, 0.45, 7, 100) == 100      # capped
+    assert o_tri.ransac_update_num_iters(0.99, 0.0, 7, 1000) == 0        # no outliers: 1 - 1^7 = 0, "no iterations needed"
+    assert o_tri.ransac_update_num_iters(0.99, 1.0, 7, 1000) == 1000     # only outliers: log(1) = 0 -> the cap
+    draws = [o_tri.CvRNG().uniform_int(0, 60) for _ in range(2)]
+    assert draws[0] == draws[1] and 0 <= draws[0] < 60                   # fixed seed: the same stream every time
+
+
+@pytest.mark.parametrize("pair,outliers", [((0, 1), 0), ((0, 2), 20), ((1, 3), 26)])
+def test_oracle_lmeds_properties(pair, outliers):
+    """findFundamentalMat(FM_LMEDS) restated: up to 43 % gross outliers are rejected, the estimate explains the inliers to the noise level,
+    has rank 2 and F[2][2] = 1, is a deterministic function of its input, and its 7-point candidates interpolate their samples."""
+    n = 60
+    _, u1, u2, p1, p2 = _scene(21 + outliers, n=n, noise=0.5, pair=pair)
+    rng = np.random.default_rng(3)
+    bad = rng.choice(n, outliers, replace=False)
+    u2 = u2.copy()
+    u2[bad] += rng.uniform(40, 120, (outliers, 2)) * rng.choice([-1, 1], (outliers, 2))
+    i1, i2 = np.int32(u1), np.int32(u2)                    # the reference casts to integer pixels (cameras.py:137-138)
+    f, mask = o_tri.fundamental_lmeds(i1, i2)
+    assert f is not None and mask.shape == (n,) and abs(f[2, 2] - 1.0) < 1e-12
+    sv = np.linalg.svd(f, compute_uv=False)
+    assert sv[2] < 1e-9 * sv[0]                            # a member of the pencil with det = 0
+    good = np.setdiff1d(np.arange(n), bad)
+    assert mask[good].mean() >= 0.8                        # (the 2.5-sigma rule on a median-based sigma trims the tail of the genuine pairs too: 52 of 60 kept)
+    assert mask[bad].sum() <= max(1, outliers // 8)        # a gross outlier survives only by landing near its epipolar line
+    assert np.median(_sym_epi_dist(f, i1[good].astype(float), i2[good].astype(float))) < 1.5
+    ft = o_tri.fundamental_from_projections(p1, p2)
+    assert np.median(_sym_epi_dist(ft, i1[good].astype(float), i2[good].astype(float))) < 1.5     # (the yardstick: the true matrix on the same integer pixels)
+    f2, mask2 = o_tri.fundamental_lmeds(i1, i2)
+    assert np.array_equal(f, f2) and np.array_equal(mask, mask2)
+    # the 7-point candidates of a sample pass through its seven pairs
+    idx = o_tri.fm_get_subset(o_tri.CvRNG(), i1.astype(np.float32), i2.astype(np.float32))
+    assert len(set(idx)) == 7
+    cands = o_tri.fm_run_7point(i1[idx].astype(np.float32), i2[idx].astype(np.float32))
+    assert 1 <= len(cands) <= 3
+    for c in cands:
+        assert _epi_residual(c, i1[idx].astype(float), i2[idx].astype(float)).max() < 1e-6
+        assert abs(np.linalg.det(c)) < 1e-9 * np.abs(c).max() ** 3 + 1e-18
+    # too few points / the minimal case
+    assert o_tri.fundamental_lmeds(i1[:6], i2[:6])[0] is None
+    f7, m7 = o_tri.fundamental_lmeds(i1[good[:7]], i2[good[:7]])
+    assert f7 is not None and m7.sum() == 7
+
+
+def test_oracle_lmeds_median_and_error():
+    """the error is the larger squared epipolar distance as float32; the median of an even count is the mean of the two middle elements"""
+    assert o_tri.fm_median(np.float32([4, 1, 3])) == 3.0 and o_tri.fm_median(np.float32([4, 1, 3, 2])) == 2.5
+    _, u1, u2, p1, p2 = _scene(5, n=9, noise=0.0)
+    f = o_tri.fundamental_from_projections(p1, p2)
+    e = o_tri.fm_compute_error(f / f[2, 2], u1.astype(np.float32), u2.astype(np.float32))
+    assert e.dtype == np.float32 and e.max() < 1e-3
+    off = u2 + [0.0, 7.0]
+    e2 = o_tri.fm_compute_error(f / f[2, 2], u1.astype(np.float32), off.astype(np.float32))
+    np.testing.assert_allclose(np.sqrt(e2), _sym_epi_dist(f, u1.astype(np.float32).astype(float), off.astype(np.float32).astype(float)), rtol=1e-5)
