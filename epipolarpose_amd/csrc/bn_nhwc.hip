@@ -479,6 +479,95 @@ using namespace epi;
 // layers (few rows, so few producers -- and every apply workgroup reads all of them).
 extern "C" int epi_bn_sum_copies(int C) { return C <= 512 ? 4 : 1; }
 
+// One channel's affine of one BatchNorm call (BnAffine) with the lead workgroup's side effects -- the derivation of bn_apply2d_kernel
+__device__ __forceinline__ void bn_derive(const BnAffine& a, int C, int c, bool lead, float& sc, float& sh) {
+    double m, var;
+    if (a.sums) {
+        float s1 = a.sums[c], s2 = a.sums[C + c];
+        for (int k = 1; k < a.ncopies; ++k) { s1 += a.sums[2 * k * C + c]; s2 += a.sums[(2 * k + 1) * C + c]; }
+        m = (double)s1 * a.inv_r;
+        var = fma(-m, m, (double)s2 * a.inv_r);
+        if (var < 0) var = 0;
+    } else {
+        m = a.running_mean[c];
+        var = a.running_var[c];
+    }
+    const float rs = 1.0f / sqrtf((float)var + a.eps);
+    sc = a.gamma[c] * rs;
+    sh = a.beta[c] - (float)m * sc;
+    if (lead) {
+        if (a.mean) { a.mean[c] = (float)m; a.rstd[c] = rs; }
+        a.scale[c] = sc;
+        a.shift[c] = sh;
+        if (a.sums && a.running_mean) {
+            const double unbiased = (a.R > 1) ? var * (double)a.R / (double)(a.R - 1) : var;
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+        }
+        if (a.bwd_sums) { a.bwd_sums[c] = 0.f; a.bwd_sums[C + c] = 0.f; }
+    }
+}
+
+// y = relu(x * scale[c] + shift[c] + xd * scale_d[c] + shift_d[c]): the LAST BatchNorm of a residual unit whose shortcut is a projection
+// (`residual = self.downsample(x)` = conv -> BatchNorm without activation, pose3d_resnet.py:79-86) and that projection's BatchNorm in ONE pass over
+// the two raw convolution outputs: the projection's normalised output -- a C-wide tensor written once and read once -- is never materialised.
+// Partition and register-resident coefficients as bn_apply2d_kernel; both layers' saved statistics, running estimates and accumulator
+// hand-overs are done here.
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_dual_kernel(const T* __restrict__ x, const T* __restrict__ xd, long long R, int C, int rows_per_wg,
+                                                                   BnAffine a, BnAffine d, T* __restrict__ y) {
+    constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
+    __shared__ float ss[3 * SLAB];                // scale | scale of the projection | both shifts added
+    const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    const bool lead = blockIdx.y == 0;
+    if (threadIdx.x < SLAB) {
+        const int c = slab * SLAB + threadIdx.x;
+        float sc = 0.f, sh = 0.f, scd = 0.f, shd = 0.f;
+        if (c < C) {
+            bn_derive(a, C, c, lead, sc, sh);
+            bn_derive(d, C, c, lead, scd, shd);
+        }
+        ss[threadIdx.x] = sc;
+        ss[SLAB + threadIdx.x] = scd;
+        ss[2 * SLAB + threadIdx.x] = sh + shd;
+    }
+    if (lead && slab == 0 && threadIdx.x == 0) {
+        if (a.num_batches && a.sums) a.num_batches[0] += 1;
+        if (d.num_batches && d.sums) d.num_batches[0] += 1;
+    }
+    __syncthreads();
+    const int ch0 = slab * SLAB + g * V;
+    if (ch0 >= C) return;
+    float sc[V], scd[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = ss[g * V + k]; scd[k] = ss[SLAB + g * V + k]; sh[k] = ss[2 * SLAB + g * V + k]; }
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    long long r = r0 + rl;
+    for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {            // two rows (four independent 16-byte loads) in flight per lane
+        float va[V], da[V], vb[V], db[V];
+        Elem<T>::load(x + r * C + ch0, va);
+        Elem<T>::load(xd + r * C + ch0, da);
+        Elem<T>::load(x + (r + BN_RLANES) * C + ch0, vb);
+        Elem<T>::load(xd + (r + BN_RLANES) * C + ch0, db);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            va[k] = fmaxf(va[k] * sc[k] + da[k] * scd[k] + sh[k], 0.f);
+            vb[k] = fmaxf(vb[k] * sc[k] + db[k] * scd[k] + sh[k], 0.f);
+        }
+        Elem<T>::store(y + r * C + ch0, va);
+        Elem<T>::store(y + (r + BN_RLANES) * C + ch0, vb);
+    }
+    for (; r < r1; r += BN_RLANES) {
+        float v[V], dv[V];
+        Elem<T>::load(x + r * C + ch0, v);
+        Elem<T>::load(xd + r * C + ch0, dv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k] * sc[k] + dv[k] * scd[k] + sh[k], 0.f);
+        Elem<T>::store(y + r * C + ch0, v);
+    }
+}
+
 template <typename T>
 static int bn_act_fwd_impl(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                            float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
@@ -534,6 +623,43 @@ extern "C" int epi_bn_act_fwd(const void* x, const void* residual, long long R, 
                               float* bwd_sums, void* y, epi_stream_t stream) {
     return bn_act_fwd_impl<unsigned short>(x, residual, R, C, gamma, beta, eps, momentum, training, relu, running_mean, running_var,
                                            num_batches_tracked, mean, rstd, scale_shift, sums_ws, bwd_sums, y, stream);
+}
+static void bn_affine_from(const EpiBnLayer& l, long long R, int C, int training, float eps, float momentum, BnAffine* a) {
+    a->sums = training ? l.sums_ws : nullptr; a->ncopies = epi_bn_sum_copies(C); a->R = R; a->inv_r = 1.0 / (double)R; a->gamma = l.gamma; a->beta = l.beta;
+    a->eps = eps; a->momentum = momentum; a->running_mean = l.running_mean; a->running_var = l.running_var; a->num_batches = l.num_batches_tracked;
+    a->mean = l.mean; a->rstd = l.rstd; a->scale = l.scale_shift; a->shift = l.scale_shift + C; a->bwd_sums = training ? l.bwd_sums : nullptr;
+}
+extern "C" int epi_bn_act_fwd_dual(const void* x, const void* x_proj, long long R, int C, const EpiBnLayer* main_bn, const EpiBnLayer* proj_bn,
+                                   float eps, float momentum, int training, void* y, epi_stream_t stream) {
+    typedef unsigned short T;
+    constexpr int V = Elem<T>::VEC;
+    if (!x || !x_proj || !main_bn || !proj_bn || !y) return EPI_ERR_INVALID_ARGUMENT;
+    for (const EpiBnLayer* l : {main_bn, proj_bn}) {
+        if (!l->gamma || !l->beta || !l->scale_shift) return EPI_ERR_INVALID_ARGUMENT;
+        if (training && (!l->mean || !l->rstd || !l->sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
+        if (!training && (!l->running_mean || !l->running_var)) return EPI_ERR_INVALID_ARGUMENT;
+        if ((l->running_mean == nullptr) != (l->running_var == nullptr)) return EPI_ERR_INVALID_ARGUMENT;
+    }
+    if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int rpw = 0;
+    dim3 rgrid;
+    reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
+    if (training == 1)            // (2: both producers already accumulated their batch sums)
+        for (int k = 0; k < 2; ++k) {
+            hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)(k ? x_proj : x), R, C, rpw, (k ? proj_bn : main_bn)->sums_ws,
+                               epi_bn_sum_copies(C));
+            EPI_CHECK_LAUNCH();
+        }
+    BnAffine a, d;
+    bn_affine_from(*main_bn, R, C, training, eps, momentum, &a);
+    bn_affine_from(*proj_bn, R, C, training, eps, momentum, &d);
+    int rpw2 = 0;
+    dim3 g2;
+    apply_blocking(R, C, &rpw2, &g2, 8 * V);
+    hipLaunchKernelGGL(bn_apply_dual_kernel<T>, g2, dim3(BN_THREADS), 0, st, (const T*)x, (const T*)x_proj, R, C, rpw2, a, d, (T*)y);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
 }
 // the same on fp32 activations (x, residual, y are float [R][C]): the fp32-grade verification mode (models/precise.py)
 extern "C" int epi_bn_act_fwd_f32(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,

@@ -1395,7 +1395,11 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     // (a launch that carries the fused BatchNorm-backward reduction stays on the generic kernel: the A-stationary kernel has no registers left
     //  to request a slice's z / y ahead of its MFMAs, and with them requested at their use it ran 84 .. 92 us instead of 19 .. 20 us --
     //  profiles/r03_bn_bwd_fused_reduction.txt)
-    if (!want_red.z &&
+    // A launch that wants BatchNorm statistics leaves the A-stationary kernel for the generic one, whose epilogue delivers them: 6.530 vs 6.562
+    // ms/step against the A-stationary kernel + a separate statistics pass over its output (forward convolutions +46 us, BatchNorm -64 us and 8
+    // launches; EPI_STATS_OFF_ASTAT=0 restores the round-2 arrangement; statistics from the A-stationary epilogue itself cost more than either)
+    static const bool stats_off_astat = [] { const char* e = getenv("EPI_STATS_OFF_ASTAT"); return !(e && e[0] == '0'); }();
+    if (!want_red.z && !(want_stats && stats_off_astat && !a.bias) &&
         !out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
         const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);

@@ -828,8 +828,10 @@ struct StageSaved {       // what a stage's backward needs
     Tensor w;                           // the weight itself (a parameter or its training copy): consulted by the deferred-reduce rule
 };
 
+// defer_bn: run the convolution (and its epilogue statistics) only and return the RAW output -- the caller normalises it together with another
+// stage's (dual_bn_forward); *sums_done_out then says whether the batch sums are already in sums_ws
 Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& residual, bool training, double momentum, double eps, bool need_dx,
-                     StageSaved* save) {
+                     StageSaved* save, bool defer_bn = false, int* sums_done_out = nullptr) {
     Tensor x = x_in;
     TORCH_CHECK(x.is_cuda() && sp.w.is_cuda(), "conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
     if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
@@ -863,7 +865,10 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
     BnBuffers b{sp.gamma, sp.beta, sp.running_mean, sp.running_var, sp.num_batches, sp.sums_ws, sp.bwd_sums, sp.flags};
     Tensor stats;
     Tensor y;
-    if (training && !sums_done) {       // the statistics pass runs separately; re-arm the flag protocol for bn_forward
+    if (sums_done_out) *sums_done_out = sums_done;
+    if (defer_bn) {
+        y = raw;                        // (statistics, y and the saved mask source are filled in by dual_bn_forward)
+    } else if (training && !sums_done) {       // the statistics pass runs separately; re-arm the flag protocol for bn_forward
         sp.flags.data_ptr<int>()[0] = 0;
         y = bn_forward(raw, residual, b, training, momentum, eps, sp.relu, &stats, false);
     } else {
@@ -883,13 +888,54 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
         }
         save->x = x; save->raw = raw;
         // a detached alias: the returned tensor itself will carry this node as grad_fn -- holding it would close a reference cycle
-        save->y = (sp.relu && has_res) ? y.detach() : Tensor(); save->stats = stats; save->gamma = sp.gamma; save->wb = wb;
+        save->y = (sp.relu && has_res && !defer_bn) ? y.detach() : Tensor(); save->stats = stats; save->gamma = sp.gamma; save->wb = wb;
         save->sums_ws = sp.sums_ws; save->bwd_sums = sp.bwd_sums; save->flags = sp.flags;
         save->w_sizes = w.sizes().vec();
         save->w_strides = (w.is_contiguous(at::MemoryFormat::ChannelsLast) || (K == 1 && w.is_contiguous())) ? w.strides().vec() : w16.strides().vec();
         save->K = K; save->S = S; save->P = P; save->relu = sp.relu; save->has_res = has_res; save->w_f32 = w.scalar_type() != at::kBFloat16;
         save->w = w;
         save->need_dx = need_dx;
+    }
+    return y;
+}
+
+// y = relu(bn_main(raw_main) + bn_proj(raw_proj)) in one pass (epi_bn_act_fwd_dual): the last stage of a residual unit with a projection shortcut.
+// Both stages ran with defer_bn; their saved state gets the statistics (and the main stage the mask source) here.
+int g_bn_dual = -1;
+bool bn_dual_enabled() {
+    if (g_bn_dual < 0) { const char* e = getenv("EPI_BN_DUAL"); g_bn_dual = (e && e[0] == '0') ? 0 : 1; }
+    return g_bn_dual != 0;
+}
+int bn_dual_mode(int mode) {                    // test / measurement hook: returns the previous setting; a negative mode only queries
+    const int prev = bn_dual_enabled() ? 1 : 0;
+    if (mode >= 0) g_bn_dual = mode ? 1 : 0;
+    return prev;
+}
+Tensor dual_bn_forward(const Tensor& raw_main, const StageParams& pm, const Tensor& raw_proj, const StageParams& pp, bool training, bool sums_ready,
+                       double momentum, double eps, StageSaved* save_main, StageSaved* save_proj) {
+    const int64_t B = raw_main.size(0), C = raw_main.size(1), H = raw_main.size(2), W = raw_main.size(3);
+    TORCH_CHECK(raw_proj.sizes() == raw_main.sizes() && pm.gamma.numel() == C && pp.gamma.numel() == C, "residual_unit: projection shape");
+    Tensor y = at::empty_like(raw_main);
+    Tensor stats_m = at::empty({4 * C}, pm.gamma.options().dtype(at::kFloat)), stats_p = at::empty({4 * C}, pm.gamma.options().dtype(at::kFloat));
+    auto layer = [&](const StageParams& p, Tensor& st) {
+        EpiBnLayer l;
+        float* sp = st.data_ptr<float>();
+        l.gamma = p.gamma.data_ptr<float>(); l.beta = p.beta.data_ptr<float>();
+        l.running_mean = p.running_mean.data_ptr<float>(); l.running_var = p.running_var.data_ptr<float>();
+        l.num_batches_tracked = reinterpret_cast<long long*>(p.num_batches.data_ptr<int64_t>());
+        l.mean = sp; l.rstd = sp + C; l.scale_shift = sp + 2 * C;
+        l.sums_ws = p.sums_ws.data_ptr<float>(); l.bwd_sums = p.bwd_sums.data_ptr<float>();
+        return l;
+    };
+    const EpiBnLayer lm = layer(pm, stats_m), lp = layer(pp, stats_p);
+    const double tbytes = 2.0 * (double)raw_main.numel();
+    ScopedTimer timer(training ? (sums_ready ? "bn_fwd_apply" : "bn_fwd_stats+apply") : "bn_fwd_eval", 0.0, tbytes * ((training && !sums_ready ? 2 : 0) + 3),
+                      current_stream(raw_main));
+    check(epi_bn_act_fwd_dual(raw_main.data_ptr(), raw_proj.data_ptr(), B * H * W, (int)C, &lm, &lp, (float)eps, (float)momentum,
+                              training ? (sums_ready ? 2 : 1) : 0, y.data_ptr(), current_stream(raw_main)), "epi_bn_act_fwd_dual");
+    if (training) {
+        if (save_main) { save_main->stats = stats_m; save_main->y = y.detach(); save_main->has_res = true; }
+        if (save_proj) { save_proj->stats = stats_p; save_proj->has_res = false; }
     }
     return y;
 }
@@ -1188,9 +1234,35 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         Tensor out = x;
         for (int i = 0; i + 1 < n_main; ++i)
             out = stage_forward(out, stage(i, true), Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i]);
-        Tensor shortcut = x;
-        if (has_downsample) shortcut = stage_forward(x, stage(n_total - 1, false), Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1]);
-        Tensor y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1]);
+        Tensor shortcut = x, y;
+        if (has_downsample && bn_dual_enabled()) {
+            // projection shortcut: both convolutions first, then ONE pass normalises both raw outputs, adds them and applies the ReLU -- the
+            // projection's BatchNorm output is never written (EPI_BN_DUAL=0: the two separate passes of round 2)
+            int done_p = 0, done_m = 0;
+            const StageParams pp = stage(n_total - 1, false), pm = stage(n_main - 1, true);
+            Tensor raw_p = stage_forward(x, pp, Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1], true, &done_p);
+            Tensor raw_m = stage_forward(out, pm, Tensor(), training, momentum, eps, true, &holder->stages[n_main - 1], true, &done_m);
+            if (!training || done_p == done_m) {
+                y = dual_bn_forward(raw_m, pm, raw_p, pp, training, training && done_m, momentum, eps, training ? &holder->stages[n_main - 1] : nullptr,
+                                    training ? &holder->stages[n_total - 1] : nullptr);
+            } else {                    // one producer delivered its batch sums, the other did not: the two separate passes
+                auto finish = [&](const Tensor& raw, const StageParams& p, const Tensor& res, int done, StageSaved* sv) {
+                    BnBuffers b{p.gamma, p.beta, p.running_mean, p.running_var, p.num_batches, p.sums_ws, p.bwd_sums, p.flags};
+                    Tensor stats;
+                    if (!done) p.flags.data_ptr<int>()[0] = 0;
+                    Tensor out_y = bn_forward(raw, res, b, training, momentum, eps, p.relu, &stats, done != 0);
+                    sv->stats = stats;
+                    sv->has_res = res.defined();
+                    sv->y = (p.relu && res.defined()) ? out_y.detach() : Tensor();
+                    return out_y;
+                };
+                shortcut = finish(raw_p, pp, Tensor(), done_p, &holder->stages[n_total - 1]);
+                y = finish(raw_m, pm, shortcut, done_m, &holder->stages[n_main - 1]);
+            }
+        } else {
+            if (has_downsample) shortcut = stage_forward(x, stage(n_total - 1, false), Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1]);
+            y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1]);
+        }
         ctx->saved_data["training"] = training;
         if (training) {
             publish_output(holder, y, holder->stages[n_main - 1]);
@@ -1233,7 +1305,15 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         side_run_jobs();                                              // the unit's weight gradients: second stream, one fork event
         // grouped weight gradients leave when the stage is complete (its first unit carries the downsample projection), when one more
         // unit would not fit into a launch, or per unit (EPI_WGRAD_GROUP=1)
-        if (group_mode() == 1 || holder->has_downsample || g_side.group.size() + 4 > (size_t)epi_wgrad_group_max()) side_group_flush();
+        // (EPI_WGRAD_GROUP_ROWS = N: also flush a unit by itself when it reduces over >= N rows.  Measured with N = 65 536 -- layer 1 at the bench
+        //  shape, whose stage group otherwise leaves at the very end of the backward chain: 6.606 vs 6.600 ms/step, 7 launches instead of 5; the
+        //  earlier launches take from the main stream what the shorter tail gives back.  Off.)
+        static const long long unit_rows = [] { const char* e = getenv("EPI_WGRAD_GROUP_ROWS"); return e ? atoll(e) : 0LL; }();
+        const StageSaved& s0 = holder->stages.empty() ? StageSaved() : holder->stages[0];
+        const long long rows = s0.x.defined() ? (long long)s0.x.size(0) * s0.x.size(2) * s0.x.size(3) : 0;
+        if (group_mode() == 1 || holder->has_downsample || g_side.group.size() + 4 > (size_t)epi_wgrad_group_max() ||
+            (unit_rows > 0 && rows >= unit_rows))
+            side_group_flush();
         variable_list out;
         out.reserve(1 + n_total * STAGE_TENSORS + 5);
         out.push_back(g[0].dx);
@@ -1627,6 +1707,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("declare_hook_free", &declare_hook_free,
           "parameters whose post-accumulate hooks were all removed again (torch keeps the empty hook object): their gradients may stay on the "
           "second stream / in a grouped launch / unreduced until the end of the pass; replaces the previous declaration");
+    m.def("bn_dual_mode", &bn_dual_mode,
+          "projection shortcut: the unit's last BatchNorm and the projection's BatchNorm in one pass (1, default; EPI_BN_DUAL=0 turns it off) or "
+          "two passes (0); returns the previous setting, a negative argument only queries");
     m.def("bn_bwd_fuse_counts", &bn_bwd_fuse_counts, "(fused, refused) BatchNorm backward passes since the last reset", py::arg("reset") = false);
     m.def("bn_bwd_fuse_mode", &bn_bwd_fuse_mode,
           "BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's gradient (EpiBnReduce): 1 on (default; "

@@ -239,6 +239,27 @@ int epi_bn_act_bwd(const void* dy, const void* x, const void* y, long long R, in
                    const float* mean, const float* rstd, const float* scale_shift, int relu,
                    float* dbeta_dgamma, void* dx, void* dres, float* fwd_sums_clear, float* param_grads, epi_stream_t stream);
 
+/* The last BatchNorm of a residual unit whose shortcut is a projection, and that projection's own BatchNorm, in ONE pass
+ * (`residual = self.downsample(x)`; `out = self.bn3(out); out += residual; out = self.relu(out)`, pose3d_resnet.py:68-88 with :130-136):
+ *   y = relu(bn_main(x) + bn_proj(x_proj)),  x / x_proj / y [R][C] bf16 -- the projection's normalised output is never written.
+ * Each EpiBnLayer carries the arguments epi_bn_act_fwd takes per layer (same accumulator protocol, same saved statistics, running
+ * estimates updated); training: 1 = compute both layers' batch sums here, 2 = both producers delivered them, 0 = running statistics.
+ * The backward pass is unchanged: epi_bn_act_bwd of the main layer yields dres, which is the projection BatchNorm's dy. */
+typedef struct EpiBnLayer {
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* num_batches_tracked;
+    float* mean;          /* out [C] */
+    float* rstd;          /* out [C] */
+    float* scale_shift;   /* out [2C] */
+    float* sums_ws;       /* [epi_bn_sum_copies(C)][2C] */
+    float* bwd_sums;      /* [2C] */
+} EpiBnLayer;
+int epi_bn_act_fwd_dual(const void* x, const void* x_proj, long long R, int C, const EpiBnLayer* main_bn, const EpiBnLayer* proj_bn,
+                        float eps, float momentum, int training, void* y, epi_stream_t stream);
+
 /* ---- The BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's dy ---------------------------
  * (autograd of `out = relu(bn(conv(x)) [+ residual])`, pose3d_resnet.py:33-46,68-88,186-199: the gradient of a BatchNorm output is
  * produced by the backward-data pass of the convolution that consumed it.)  epi_bn_act_bwd starts with a pass over (dy, x, y) for

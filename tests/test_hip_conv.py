@@ -301,16 +301,21 @@ def test_conv2d_bwd_data_epilogue_addend(geo):
 
 
 @pytest.mark.parametrize("kind", ["bottleneck_proj", "bottleneck_identity", "bottleneck_stride2", "basic_identity", "basic_stride2"])
-def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
+def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch, request):
     """One autograd node per residual unit (shortcut gradient added in the first stage's dgrad epilogue) against one node per
     conv/bn stage with autograd's own accumulation: same kernels, same roundings -> the same outputs and gradients."""
     import copy
+    from epipolarpose_amd import hip
     from epipolarpose_amd.models import pose3d_resnet as P
     dev = torch.device("cuda:0")
     plan, inpl, planes, stride = {"bottleneck_proj": (P._BOTTLENECK, 64, 64, 1), "bottleneck_identity": (P._BOTTLENECK, 256, 64, 1),
                                   "bottleneck_stride2": (P._BOTTLENECK, 256, 128, 2), "basic_identity": (P._BASIC, 64, 64, 1),
                                   "basic_stride2": (P._BASIC, 64, 128, 2)}[kind]
     torch.manual_seed(3)
+    # (the per-stage chain rounds the projection's BatchNorm output to bf16 before the add; the unit node's one-pass form of the two
+    #  BatchNorms does not: "same roundings" holds for the two-pass form, the one-pass form has its own test below)
+    prev_dual = hip.glue().bn_dual_mode(0)
+    request.addfinalizer(lambda: hip.glue().bn_dual_mode(prev_dual))
     monkeypatch.setenv("EPI_UNIT_NODE", "1")
     unit = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
     assert unit._unit is not None
@@ -350,6 +355,56 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch):
     for (ka, va), (kb, vb) in zip(unit.state_dict().items(), staged.state_dict().items()):      # running statistics advanced alike
         assert ka == kb
         near(va, vb, ka)
+
+
+@pytest.mark.parametrize("kind", ["bottleneck_proj", "bottleneck_stride2", "basic_stride2"])
+@pytest.mark.parametrize("training", [True, False])
+def test_projection_batchnorm_in_one_pass(kind, training):
+    """epi_bn_act_fwd_dual: y = relu(bn3(z3) + bn_proj(z_proj)) in one pass over the two raw convolution outputs against the two passes
+    (projection BatchNorm written in bf16, then bn3 + residual + ReLU): the output differs by at most the bf16 rounding of the shortcut
+    that the one-pass form no longer performs, statistics / running estimates are identical, gradients agree to the noise of that rounding."""
+    import copy
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.models import pose3d_resnet as P
+    dev = torch.device("cuda:0")
+    plan, inpl, planes, stride = {"bottleneck_proj": (P._BOTTLENECK, 64, 64, 1), "bottleneck_stride2": (P._BOTTLENECK, 256, 128, 2),
+                                  "basic_stride2": (P._BASIC, 64, 128, 2)}[kind]
+    torch.manual_seed(13)
+    base = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
+    assert base._unit is not None
+    for mod in base.modules():                               # non-trivial running statistics for the eval case
+        if hasattr(mod, "running_mean"):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+    gen = torch.Generator().manual_seed(14)
+    x = _rand((8, inpl, 16, 16), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for dual in (1, 0):
+        prev = hip.glue().bn_dual_mode(dual)
+        try:
+            m = copy.deepcopy(base)
+            m.train(training)
+            xin = x.clone().requires_grad_(training)
+            y = m(xin)
+            grads = {}
+            if training:
+                dy = _rand(tuple(y.shape), torch.Generator().manual_seed(15)).to(dev).contiguous(memory_format=torch.channels_last)
+                y.backward(dy)
+                grads = {k: p.grad.float().clone() for k, p in m.named_parameters()}
+                grads["x"] = xin.grad.float().clone()
+            outs.append((y.detach().float().clone(), grads, {k: v.detach().float().clone() for k, v in m.state_dict().items()}))
+        finally:
+            hip.glue().bn_dual_mode(prev)
+    (ya, ga, sa), (yb, gb, sb) = outs
+    # the shortcut term is at most a few units large: its bf16 rounding moves y by <= 2^-8 of it, and y's own rounding by one more bf16 unit
+    tol = 2 ** -7 * float(yb.abs().max())
+    assert float((ya - yb).abs().max()) <= tol, (float((ya - yb).abs().max()), tol)
+    assert float(((ya - yb).abs() > 0).float().mean()) > 0.01 or not training        # the two forms ARE different roundings (not the same code path twice)
+    for k in sa:                                              # statistics come from the raw convolution outputs: identical up to atomics order
+        assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * max(1.0, float(sb[k].abs().max())), k
+    for k in ga:
+        a, b = ga[k].reshape(-1).double(), gb[k].reshape(-1).double()
+        assert float((a - b).norm()) <= 0.12 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
 
 
 def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
