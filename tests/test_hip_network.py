@@ -97,7 +97,10 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
     assert c_ours >= min(0.99, c_stock - 0.01), (c_ours, c_stock)
     gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
     loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
-    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=5e-3)        # (bf16 activations; the fp32-grade mode: 1e-7, test_hip_precise.py)
+    # bf16 activations, and two runs of the SAME code differ: the order of the statistics' atomics can flip a bf16 rounding in the stem, which moves
+    # the logits of these random-weight goldens by 1 - 3 % (tools/debug_fwd_bimodal.py) and the loss by up to 0.6 % (measured 1e-4 .. 5.9e-3 over
+    # repeated runs of r50).  The fp32-grade mode of the same kernels holds this loss to 3e-7 (tests/test_hip_precise.py).
+    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=1e-2)
     loss.backward()
     sd = model.state_dict()
     np.testing.assert_allclose(sd["bn1.running_mean"].cpu().numpy(), g[name + "/bn1.running_mean"], atol=2e-3)
