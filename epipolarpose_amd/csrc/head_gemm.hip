@@ -110,6 +110,8 @@ struct GemmArgs {
     int patch_px;          // conv_patch_kernel: pixels of the staged patch (256 + 2W + 2, rounded up to 8)
     int chunks_per_split;  // conv_patch_kernel: 64-channel chunks per blockIdx.y
     GemmBnRed br;          // unsplit bf16 launches on the coalesced epilogue only (launch_gemm decides and reports)
+    int addend_step;       // 2: `addend` is [B][add_h / 2][add_w / 2][ldc] and holds the contribution of the EVEN pixels of the [B][add_h][add_w] output only
+    int add_h, add_w;      //    (the shortcut gradient through a 1x1 stride-2 projection: every other pixel receives none); plain rows, coalesced epilogue only
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -446,6 +448,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             return ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
         };
         // residual-junction addend: requested NOW, consumed after the LDS round trip below (its latency hides behind the park)
+        // the residual-junction addend of output row `orow`, columns n .. n + 7 (addend_step 2: the half-resolution tensor of the even pixels)
+        auto addend_at = [&](long long orow) -> uint4v {
+            if (p.addend_step != 2) return *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n);
+            const int hw = p.add_h * p.add_w;
+            const int b = (int)(orow / hw), rem = (int)(orow - (long long)b * hw);
+            const int yy = rem / p.add_w, xx = rem - yy * p.add_w;
+            if ((yy | xx) & 1) return uint4v{0u, 0u, 0u, 0u};
+            const long long ar = ((long long)b * (p.add_h >> 1) + (yy >> 1)) * (p.add_w >> 1) + (xx >> 1);
+            return *reinterpret_cast<const uint4v*>(p.addend + ar * p.ldc + n);
+        };
         constexpr bool AD_EARLY = !(RED && TM >= 4);       // (the 256-row tile with the fused reduction: no registers for 16 rows of addend)
         constexpr bool RED_EARLY = RED && !OUT_F32 && TM <= 2;   // z / y of all rows requested here too: their latency hides behind the park
         uint4v ad[TM * 4];
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
 #pragma unroll
             for (int it = 0; it < TM * 4; ++it) {
                 const long long orow = out_row(it);
-                ad[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
+                ad[it] = orow >= 0 ? addend_at(orow) : uint4v{0u, 0u, 0u, 0u};
             }
         }
         uint4v zpre[RED_EARLY ? TM * 4 : 1], ypre[RED_EARLY ? TM * 4 : 1];
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                 }
             }
             uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-            if (p.addend) o = add_bf16x8(o, AD_EARLY ? ad[it] : *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n));
+            if (p.addend) o = add_bf16x8(o, AD_EARLY ? ad[it] : addend_at(orow));
             if (red) o = RED_EARLY ? bnred_apply(p.br, o, zpre[it], ypre[it], rcols, ssum, ssq) : bnred_row(p.br, o, orow * p.ldc + n, rcols, ssum, ssq);
             *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
         }
@@ -1379,6 +1391,10 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
         want_red.z = nullptr;
     if (a.addend && (out_f32 || (reinterpret_cast<uintptr_t>(a.addend) & 15u))) return EPI_ERR_UNSUPPORTED;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
+    const bool half_addend = a.addend && a.addend_step == 2;      // only the generic kernel's coalesced epilogue reads it: plain rows, unsplit
+    if (half_addend && (!a.coalesce || a.ga.enabled || a.sc.enabled || a.ph.enabled || nphase != 1 || a.add_h <= 0 || a.add_w <= 0 || ((a.add_h | a.add_w) & 1) ||
+                        (long long)a.M % ((long long)a.add_h * a.add_w)))
+        return EPI_ERR_UNSUPPORTED;
     // BatchNorm statistics from the GEMM epilogue (on; EPI_FUSE_BN_STATS=0 keeps the separate statistics pass: 8.46 vs 8.49 ms/step,
     // 471 vs 507 launches, profiles/r02_fs_steady_state_d_*).  First version, measured and rejected: per-WAVE
     // atomics, 8 lanes x 8 strided columns per instruction -- 16 (instruction, line) pairs per wave and line, which L2 serialises at
@@ -1399,7 +1415,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     // ms/step against the A-stationary kernel + a separate statistics pass over its output (forward convolutions +46 us, BatchNorm -64 us and 8
     // launches; EPI_STATS_OFF_ASTAT=0 restores the round-2 arrangement; statistics from the A-stationary epilogue itself cost more than either)
     static const bool stats_off_astat = [] { const char* e = getenv("EPI_STATS_OFF_ASTAT"); return !(e && e[0] == '0'); }();
-    if (!want_red.z && !(want_stats && stats_off_astat && !a.bias) &&
+    if (!want_red.z && !(want_stats && stats_off_astat && !a.bias) && !half_addend &&
         !out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
         const unsigned grid = (unsigned)((a.M + AS_BM - 1) / AS_BM);
@@ -1454,6 +1470,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     }
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
     if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+    if (half_addend && pl.nsplit > 1) return EPI_ERR_UNSUPPORTED;          // (epi_conv2d_bwd_data_half_addend_ok tells the caller beforehand)
     if (pl.nsplit > 1) {
         if (!workspace || (size_t)pl.nsplit * nphase * a.M * a.N * sizeof(float) > workspace_bytes) return EPI_ERR_WORKSPACE;
         a.slabs = (float*)workspace;
@@ -2506,8 +2523,9 @@ extern "C" int epi_conv2d_fwd_f32(const void* x, const void* w, void* y, int B, 
 
 static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                int KW, int stride, int pad, const void* addend, void* workspace, size_t workspace_bytes,
-                               epi_stream_t stream, bool out_f32, const EpiBnReduce* red = nullptr, int* red_done = nullptr) {
+                               epi_stream_t stream, bool out_f32, const EpiBnReduce* red = nullptr, int* red_done = nullptr, int addend_step = 1) {
     if (red_done) *red_done = 0;
+    if (addend_step != 1 && addend_step != 2) return EPI_ERR_INVALID_ARGUMENT;
     if (!dy || !w_bwd || !dx || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
         return EPI_ERR_INVALID_ARGUMENT;
     const int Ho = conv_out_dim(H, KH, stride, pad), Wo = conv_out_dim(W, KW, stride, pad);
@@ -2517,6 +2535,7 @@ static int conv2d_bwd_data_impl(const void* dy, const void* w_bwd, void* dx, int
     GemmArgs a = {};
     a.A = (const unsigned short*)dy; a.Bt = (const unsigned short*)w_bwd; a.C = dx; a.N = Cin; a.ldc = Cin;
     a.addend = (const unsigned short*)addend;
+    a.addend_step = addend ? addend_step : 1; a.add_h = H; a.add_w = W;
     a.br = bnred_args(red);
     if (stride == 1) {
         a.M = B * H * W; a.K = KH * KW * Cout; a.ldb = KH * KW * Cout;
@@ -2553,10 +2572,18 @@ extern "C" int epi_conv2d_bwd_data(const void* dy, const void* w_bwd, void* dx, 
 }
 // the same with the fused BatchNorm-backward reduction of the layer that produced this convolution's input (EpiBnReduce): dx becomes dz
 extern "C" int epi_conv2d_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
-                                         int KW, int stride, int pad, const void* addend, const EpiBnReduce* red, int* red_done,
+                                         int KW, int stride, int pad, const void* addend, int addend_step, const EpiBnReduce* red, int* red_done,
                                          void* workspace, size_t workspace_bytes, epi_stream_t stream) {
-    if (!red_done) return EPI_ERR_INVALID_ARGUMENT;
-    return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, addend, workspace, workspace_bytes, stream, false, red, red_done);
+    if (red && !red_done) return EPI_ERR_INVALID_ARGUMENT;
+    return conv2d_bwd_data_impl(dy, w_bwd, dx, B, H, W, Cin, Cout, KH, KW, stride, pad, addend, workspace, workspace_bytes, stream, false, red, red_done,
+                                addend_step);
+}
+// 1 when epi_conv2d_bwd_data_bnred takes a half-resolution addend (addend_step 2) for this 1x1 / stride-1 backward-data problem: an unsplit launch
+// on 16-byte rows (the plan decides; a caller that gets 0 materialises the full-resolution addend as before)
+extern "C" int epi_conv2d_bwd_data_half_addend_ok(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ((H | W) & 1) || Cin % 8 || Cout % 8) return 0;
+    const GemmPlan pl = gemm_plan(B * H * W, Cin, Cout, Cin, 1, false);
+    return pl.nsplit == 1 ? 1 : 0;
 }
 extern "C" int epi_conv2d_bwd_data_f32(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
                                        int KW, int stride, int pad, void* workspace, size_t workspace_bytes, epi_stream_t stream) {

@@ -946,9 +946,11 @@ struct StageGrads { Tensor dx, dw, dgamma, dbeta, dres; };
 // pre: state of dy (link_state: 1 = already dz with the sums in the accumulator).  feeds / feeds_link: the BatchNorm stage whose output
 // this stage consumed -- inside the same node (feeds) or in the producing node (feeds_link): its reduction is fused into this stage's
 // backward-data launch where the library can (*fed = true: dx is that layer's dz).
+// addend_step 2: `addend` is the half-resolution gradient of the even pixels (a 1x1 stride-2 projection's backward-data left at half resolution).
+// half_dx: this stage IS such a projection -- return its input gradient at half resolution (a plain 1x1 backward-data on the output grid).
 StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, bool need_dw, const Tensor& addend, int pre = 0,
                           const StageSaved* feeds = nullptr, const c10::intrusive_ptr<BnLink>& feeds_link = c10::intrusive_ptr<BnLink>(),
-                          bool* fed = nullptr) {
+                          bool* fed = nullptr, int addend_step = 1, bool half_dx = false) {
     if (fed) *fed = false;
     BnGrads g = bn_backward(dy, sv.raw, sv.y, sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, sv.has_res, pre);
     const Tensor& x = sv.x;
@@ -957,9 +959,24 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
     const int Ho = (int)sv.raw.size(2), Wo = (int)sv.raw.size(3);
     StageGrads out;
     out.dgamma = g.dgamma; out.dbeta = g.dbeta; out.dres = g.dres;
-    if (need_dx) {
+    if (need_dx && half_dx) {
+        // 1x1 / stride 2 / pad 0: dx is non-zero at the even pixels only, where it is dz * W^T of the matching output pixel -- computed on the OUTPUT grid
+        // (the packed backward weight of a 1x1 stride-2 layer is [Cin][Cout], the stride-1 layout) and handed on at half resolution
+        TORCH_CHECK(sv.wb.defined() && K == 1 && S == 2 && P == 0 && !(H & 1) && !(W & 1), "conv_bn_act: half-resolution input gradient: geometry");
+        out.dx = at::empty({B, Cin, Ho, Wo}, x.options().memory_format(at::MemoryFormat::ChannelsLast));
+        Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, 1, 1, 1, 0), x);
+        ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin, 2.0 * ((double)out.dx.numel() + (double)sv.raw.numel() + (double)sv.wb.numel()),
+                          current_stream(x));
+        check(epi_conv2d_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, Ho, Wo, Cin, Cout, 1, 1, 1, 0, nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                                  current_stream(x)), "epi_conv2d_bwd_data");
+    } else if (need_dx) {
         TORCH_CHECK(sv.wb.defined(), "conv_bn_act: input gradient requested but no backward-data weight was prepared");
-        if (addend.defined()) TORCH_CHECK(nhwc_bf16(addend) && addend.sizes() == x.sizes(), "conv_bn_act: residual-junction addend layout");
+        if (addend.defined() && addend_step == 2) {
+            TORCH_CHECK(nhwc_bf16(addend) && addend.size(0) == B && addend.size(1) == Cin && addend.size(2) * 2 == H && addend.size(3) * 2 == W,
+                        "conv_bn_act: half-resolution addend layout");
+        } else if (addend.defined()) {
+            TORCH_CHECK(nhwc_bf16(addend) && addend.sizes() == x.sizes(), "conv_bn_act: residual-junction addend layout");
+        }
         out.dx = at::empty_like(x);
         Tensor& ws = workspace(epi_conv2d_workspace_bytes(B, H, W, Cin, Cout, K, K, S, P), x);
         ScopedTimer timer("conv_bwd_data", 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K,
@@ -976,10 +993,10 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
             }
         }
         int red_done = 0;
-        if (want)
+        if (want || (addend.defined() && addend_step == 2))
             check(epi_conv2d_bwd_data_bnred(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
-                                            addend.defined() ? addend.data_ptr() : nullptr, &red, &red_done, ws.data_ptr(), (size_t)ws.numel(),
-                                            current_stream(x)), "epi_conv2d_bwd_data_bnred");
+                                            addend.defined() ? addend.data_ptr() : nullptr, addend.defined() ? addend_step : 1, want ? &red : nullptr, &red_done,
+                                            ws.data_ptr(), (size_t)ws.numel(), current_stream(x)), "epi_conv2d_bwd_data_bnred");
         else
             check(epi_conv2d_bwd_data(g.dx.data_ptr(), sv.wb.data_ptr(), out.dx.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
                                       addend.defined() ? addend.data_ptr() : nullptr, ws.data_ptr(), (size_t)ws.numel(), current_stream(x)),
@@ -1288,9 +1305,20 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
                                        &holder->stages[n_main - 2], c10::intrusive_ptr<BnLink>(), &fed);
         link_retire(holder->out_link);
         Tensor shortcut_grad = g[n_main - 1].dres;                     // gradient of the shortcut input
+        int shortcut_step = 1;
         if (holder->has_downsample) {
-            g[n_total - 1] = stage_backward(shortcut_grad, holder->stages[n_total - 1], need_x, need_w(n_total - 1), Tensor());
+            // a 1x1 stride-2 projection in front of a 1x1 stride-1 first stage (every stride-2 Bottleneck): the projection's input gradient is zero at
+            // three pixels of four -- it stays at half resolution and the first stage's backward-data epilogue adds it at the even pixels
+            // (EPI_HALF_SHORTCUT=0: expanded with zeros by the four-phase launch, as in round 2)
+            static const bool half_ok = [] { const char* e = getenv("EPI_HALF_SHORTCUT"); return !(e && e[0] == '0'); }();
+            const StageSaved& ds = holder->stages[n_total - 1];
+            const StageSaved& s0 = holder->stages[0];
+            const bool half = half_ok && need_x && ds.K == 1 && ds.S == 2 && ds.P == 0 && s0.K == 1 && s0.S == 1 && s0.P == 0 && ds.x.defined() &&
+                              !(ds.x.size(2) & 1) && !(ds.x.size(3) & 1) &&
+                              epi_conv2d_bwd_data_half_addend_ok((int)s0.x.size(0), (int)s0.x.size(2), (int)s0.x.size(3), (int)s0.x.size(1), (int)s0.raw.size(1)) != 0;
+            g[n_total - 1] = stage_backward(shortcut_grad, ds, need_x, need_w(n_total - 1), Tensor(), 0, nullptr, c10::intrusive_ptr<BnLink>(), nullptr, 1, half);
             shortcut_grad = g[n_total - 1].dx;                          // undefined when x needs no gradient
+            if (half) shortcut_step = 2;
         }
         Tensor flow = g[n_main - 1].dx;
         for (int i = n_main - 2; i >= 1; --i) {
@@ -1300,7 +1328,8 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         }
         {
             const bool was_fed = fed;
-            g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor(), was_fed ? 1 : 0, nullptr, holder->in_link, &fed);
+            g[0] = stage_backward(flow, holder->stages[0], need_x, need_w(0), need_x ? shortcut_grad : Tensor(), was_fed ? 1 : 0, nullptr, holder->in_link, &fed,
+                                  shortcut_step);
         }
         side_run_jobs();                                              // the unit's weight gradients: second stream, one fork event
         // grouped weight gradients leave when the stage is complete (its first unit carries the downsample projection), when one more

@@ -57,7 +57,8 @@ _SIGNATURES = {
     "epi_conv2d_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "epi_conv2d_pack_weight_bwd_multi": (_i, [_vp, _i, ctypes.c_longlong, _vp]),
     "epi_conv2d_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "epi_conv2d_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_conv2d_bwd_data_half_addend_ok": (_i, [_i, _i, _i, _i, _i]),
     "epi_deconv4x4s2_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_gemm_bf16_bnred": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_bn_act_fwd_dual": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp]),
@@ -868,10 +869,10 @@ def conv2d_pack_weight_bwd(weight, stride=1, padding=0, out=None):
     return out
 
 
-def conv2d_bwd_data_bnred(dy, w_bwd, in_shape, kernel, stride, padding, z, bn, relu=True, y=None, addend=None):
+def conv2d_bwd_data_bnred(dy, w_bwd, in_shape, kernel, stride, padding, z, bn, relu=True, y=None, addend=None, addend_step=1):
     """``conv2d_bwd_data`` with the BatchNorm-backward reduction of the layer that produced this convolution's input in the epilogue
     (epi_conv2d_bwd_data_bnred).  z: that layer's raw output (shape ``in_shape``, channels_last bf16); bn: f32 [4, C] = mean | rstd |
-    scale | shift; y: its saved output when the mask comes from there.  Returns (dx or dz, sums [2, C] f32, fused: bool) -- fused False:
+    scale | shift; y: its saved output when the mask comes from there; addend_step 2: ``addend`` is the half-resolution tensor of the even pixels.  Returns (dx or dz, sums [2, C] f32, fused: bool) -- fused False:
     dx is the plain gradient and sums is zero."""
     lib = load()
     dy = _nhwc_bf16(dy, "dy")
@@ -891,7 +892,7 @@ def conv2d_bwd_data_bnred(dy, w_bwd, in_shape, kernel, stride, padding, z, bn, r
     red = EpiBnReduce(_ptr(z), _ptr(y), _ptr(bn), _ptr(sums), 1 if relu else 0)
     done = ctypes.c_int(0)
     with _on(dy.device):
-        _check(lib.epi_conv2d_bwd_data_bnred(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(addend),
+        _check(lib.epi_conv2d_bwd_data_bnred(_ptr(dy), _ptr(w_bwd), _ptr(dx), b, h, wd, cin, cout, kh, kw, stride, padding, _ptr(addend), addend_step,
                                              ctypes.byref(red), ctypes.byref(done), _ptr(ws), ws.numel(), _stream()), "epi_conv2d_bwd_data_bnred")
     return dx, sums, bool(done.value)
 

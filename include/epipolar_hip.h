@@ -282,9 +282,14 @@ typedef struct EpiBnReduce {
 int epi_bn_act_bwd_reduced(const void* dz, const void* x, long long R, int C, const float* gamma, const float* mean, const float* rstd,
                            const float* scale_shift, const float* dbeta_dgamma, void* dx, float* fwd_sums_clear, float* param_grads,
                            epi_stream_t stream);
+/* addend_step (epi_conv2d_bwd_data_bnred; 1 = as epi_conv2d_bwd_data): 2 = `addend` is [B][H/2][W/2][Cin] and holds the contribution of the EVEN
+ * pixels only -- the shortcut gradient through a 1x1 stride-2 projection (`downsample`, pose3d_resnet.py:130-136), whose backward-data is non-zero at
+ * every other pixel: the projection's gradient stays at half resolution (a plain 1x1 backward-data on the [B][H/2][W/2] grid) and is never expanded with
+ * zeros.  1x1 / stride-1 problems on an unsplit launch only: ask epi_conv2d_bwd_data_half_addend_ok first.  red may be NULL (then red_done may be too). */
 int epi_conv2d_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                              int stride, int pad, const void* addend, const EpiBnReduce* red, int* red_done, void* workspace,
+                              int stride, int pad, const void* addend, int addend_step, const EpiBnReduce* red, int* red_done, void* workspace,
                               size_t workspace_bytes, epi_stream_t stream);
+int epi_conv2d_bwd_data_half_addend_ok(int B, int H, int W, int Cin, int Cout);
 int epi_deconv4x4s2_bwd_data_bnred(const void* dy, const void* w_bwd, void* dx, int B, int H, int W, int Cin, int Cout,
                                    const EpiBnReduce* red, int* red_done, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_gemm_bf16_bnred(const void* A, int lda, const void* Bt, int ldb, void* C, int ldc, int M, int N, int K, const EpiBnReduce* red,

@@ -648,6 +648,37 @@ def test_conv2d_bwd_data_with_fused_batchnorm_backward_reduction(case):
     assert float(((sums2.double() - ref2).abs() / scale2).max()) <= 2e-6
 
 
+@pytest.mark.parametrize("with_red", [False, True])
+def test_conv2d_bwd_data_half_resolution_addend(with_red):
+    """addend_step 2: the shortcut gradient through a 1x1 stride-2 projection handed over at half resolution (the even pixels) must give exactly
+    what the zero-expanded full-resolution addend gives -- with and without the fused BatchNorm-backward reduction in the same epilogue."""
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(77)
+    b, cin, cout, h = 8, 256, 128, 32                     # a stride-2 Bottleneck's first stage: dx [8, 256, 32, 32] from dy [8, 128, 32, 32]
+    assert hip.load().epi_conv2d_bwd_data_half_addend_ok(b, h, h, cin, cout) == 1
+    assert hip.load().epi_conv2d_bwd_data_half_addend_ok(1, 8, 8, cin, 2048) == 0            # few rows, deep K: a split launch
+    dy = _rand((b, cout, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    w = _rand((cout, cin, 1, 1), gen, scale=(2.0 / cin) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    half = _rand((b, cin, h // 2, h // 2), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    full = torch.zeros((b, cin, h, h), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    full[:, :, ::2, ::2] = half
+    z = _rand((b, cin, h, h), gen).to(dev).contiguous(memory_format=torch.channels_last)
+    y = torch.relu(z.float() + _rand((b, cin, h, h), gen).to(dev).float()).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    bn = torch.stack([torch.randn(cin, generator=gen) * 0.2, torch.rand(cin, generator=gen) + 0.5, torch.randn(cin, generator=gen),
+                      torch.randn(cin, generator=gen) * 0.3]).to(dev).contiguous()
+    wb = hip.conv2d_pack_weight_bwd(w, 1, 0)
+    if with_red:
+        ref, ref_s, f1 = hip.conv2d_bwd_data_bnred(dy, wb, (b, cin, h, h), 1, 1, 0, z, bn, relu=True, y=y, addend=full)
+        got, got_s, f2 = hip.conv2d_bwd_data_bnred(dy, wb, (b, cin, h, h), 1, 1, 0, z, bn, relu=True, y=y, addend=half, addend_step=2)
+        assert f1 and f2 and torch.equal(got, ref)
+        assert float((got_s - ref_s).abs().max()) <= 1e-4 * float(ref_s.abs().max())          # (atomics order)
+    else:
+        ref = hip.conv2d_bwd_data(dy, wb, (b, cin, h, h), 1, 1, 0, addend=full)
+        got, _, fused = hip.conv2d_bwd_data_bnred(dy, wb, (b, cin, h, h), 1, 1, 0, z, bn, relu=False, y=None, addend=half, addend_step=2)
+        assert fused and torch.equal(got, ref)
+
+
 def test_fused_batchnorm_backward_reduction_in_the_network():
     """The whole pose network, one backward pass with the reductions fused into the backward-data launches (across autograd nodes:
     unit -> unit, head -> backbone, final layer -> head) and one without: the fused pass must actually happen (counted by the glue),
