@@ -1966,9 +1966,11 @@ static TnPlan tn_plan(int R, int I, int J) {
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
     auto fills = [](int n) { const int t = (n + 255) / 256; return n >= 192 && t * 256 <= n + n / 4; };
     const int ov = gemm_tile_override();
-    // EPI_TN_SLOTS=<percent>: plan as if the chip held that share of its workgroup slots (measurement switch: a smaller footprint
-    // for weight-gradient launches that run beside the critical path on the second stream)
-    static const int slot_percent = [] { const char* e = getenv("EPI_TN_SLOTS"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
+    // EPI_TN_SLOTS=<percent>: plan as if the chip held that share of its workgroup slots -- a smaller footprint for the per-layer weight-gradient
+    // launches (deconvolution head, final convolution, stem), which run beside the backward chain on the second stream.  Default 70 since round 3:
+    // 6.534 -> 6.462 ms/step over three boxes (100: 6.529 / 6.539 / 6.474, 70: 6.440 / 6.484 / 6.415; 60: 6.424, 50: 6.463, 40: 6.527).  Round 2
+    // measured the opposite on its per-layer backbone launches (7.67 / 7.73 vs 7.65 ms for 50 / 70): those are grouped now (group_plan).
+    static const int slot_percent = [] { const char* e = getenv("EPI_TN_SLOTS"); const int v = e ? atoi(e) : 70; return v >= 10 && v <= 100 ? v : 70; }();
     TnPlan best = {0, 0, 1, 0};
     double best_t = 1e30;
     for (const Cfg& c : cfgs) {
@@ -2159,7 +2161,9 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
     static const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
     for (int cls = 0; cls < 2; ++cls) {
         const double t_tile = cls ? 0.7 : 1.0, t_fixed = cls ? 3.0 : 4.0;
-        const long long slots = cls ? 768 : 512;
+        // EPI_TN_GROUP_SLOTS=<percent>: the same knob for the grouped launches (measured: 100 / 70 / 50 / 35 -> 6.440 / 6.441 / 6.466 / 6.509 ms: off)
+        static const int group_percent = [] { const char* e = getenv("EPI_TN_GROUP_SLOTS"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
+        const long long slots = (cls ? 768 : 512) * group_percent / 100;
         double best_t = 1e30;
         int best_T = 1 << 30;
         for (int T : cand) {
