@@ -568,6 +568,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_dual_kernel(const T* __re
     }
 }
 
+// The per-channel part of a BatchNorm forward call alone (bn_derive for every channel with the lead's side effects): saved statistics, scale / shift,
+// running estimates, the accumulator hand-over -- for a consumer that applies the affine itself (the stem's max-pool, csrc/pool.hip)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnAffine a, int C) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float sc, sh;
+        bn_derive(a, C, c, true, sc, sh);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.num_batches && a.sums) a.num_batches[0] += 1;
+}
+
 template <typename T>
 static int bn_act_fwd_impl(const void* x, const void* residual, long long R, int C, const float* gamma, const float* beta,
                            float eps, float momentum, int training, int relu, float* running_mean, float* running_var,
@@ -628,6 +638,17 @@ static void bn_affine_from(const EpiBnLayer& l, long long R, int C, int training
     a->sums = training ? l.sums_ws : nullptr; a->ncopies = epi_bn_sum_copies(C); a->R = R; a->inv_r = 1.0 / (double)R; a->gamma = l.gamma; a->beta = l.beta;
     a->eps = eps; a->momentum = momentum; a->running_mean = l.running_mean; a->running_var = l.running_var; a->num_batches = l.num_batches_tracked;
     a->mean = l.mean; a->rstd = l.rstd; a->scale = l.scale_shift; a->shift = l.scale_shift + C; a->bwd_sums = training ? l.bwd_sums : nullptr;
+}
+// training: 2 = the producer delivered the batch sums into layer->sums_ws (the only training mode: there is no tensor here to take them from), 0 = running statistics
+extern "C" int epi_bn_finalize(const EpiBnLayer* layer, long long R, int C, float eps, float momentum, int training, epi_stream_t stream) {
+    if (!layer || !layer->gamma || !layer->beta || !layer->scale_shift || R <= 0 || C <= 0 || (training != 0 && training != 2)) return EPI_ERR_INVALID_ARGUMENT;
+    if (training && (!layer->mean || !layer->rstd || !layer->sums_ws)) return EPI_ERR_INVALID_ARGUMENT;
+    if (!training && (!layer->running_mean || !layer->running_var)) return EPI_ERR_INVALID_ARGUMENT;
+    BnAffine a;
+    bn_affine_from(*layer, R, C, training, eps, momentum, &a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, C);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
 }
 extern "C" int epi_bn_act_fwd_dual(const void* x, const void* x_proj, long long R, int C, const EpiBnLayer* main_bn, const EpiBnLayer* proj_bn,
                                    float eps, float momentum, int training, void* y, epi_stream_t stream) {

@@ -20,8 +20,14 @@ __device__ __forceinline__ long long pool_block(long long lin, long long total) 
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// one thread: 8 consecutive channels (16 bytes) of one output pixel
-__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+// one thread: 8 consecutive channels (16 bytes) of one output pixel.
+// AFFINE: x is the RAW stem convolution output and every value read becomes bf16(relu(x * scale[c] + shift[c])) first -- the stem's BatchNorm +
+// ReLU applied on the way into the pool (pose3d_resnet.py:186-188: `x = self.maxpool(self.relu(self.bn1(self.conv1(x))))`): the 67 MB
+// normalised tensor, whose only reader is this pool, is never written.  The rounding to bf16 before the comparison makes the result the one the
+// two-pass form gives, bit for bit.
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned short* __restrict__ x, const float* __restrict__ scale_shift,
+                                                               unsigned short* __restrict__ y,
                                                                unsigned char* __restrict__ pos, int H, int W, int C8, int Ho, int Wo, long long total) {
     const long long t = pool_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (t >= total) return;
@@ -36,6 +42,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned sh
     const unsigned int first = (unsigned int)((oh == 0 ? 1 : 0) * 3 + (ow == 0 ? 1 : 0));
 #pragma unroll
     for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bits[k] = 0xff80u; where[k] = first; }
+    float sc[8], sh[8];
+    if (AFFINE) {
+        const int C = C8 * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale_shift[c8 * 8 + k]; sh[k] = scale_shift[C + c8 * 8 + k]; }
+    }
     const unsigned short* xn = x + n * H * W * (long long)(C8 * 8) + c8 * 8;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -49,8 +61,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const unsigned sh
             const unsigned int wd[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const unsigned int b = (k & 1) ? (wd[k >> 1] >> 16) : (wd[k >> 1] & 0xffffu);
-                const float f = __uint_as_float(b << 16);
+                unsigned int b = (k & 1) ? (wd[k >> 1] >> 16) : (wd[k >> 1] & 0xffffu);
+                float f = __uint_as_float(b << 16);
+                if (AFFINE) {
+                    b = f32_to_bf16(fmaxf(f * sc[k] + sh[k], 0.f));
+                    f = __uint_as_float(b << 16);
+                }
                 if (f > best[k] || f != f) { best[k] = f; bits[k] = b; where[k] = kh * 3 + kw; }
             }
         }
@@ -117,8 +133,21 @@ extern "C" int epi_maxpool3x3s2_fwd(const void* x, void* y, void* pos, int B, in
     const int Ho = pool_out(H), Wo = pool_out(W);
     const long long total = (long long)B * Ho * Wo * (C / 8);
     if ((total + 255) / 256 > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(epi::maxpool3x3s2_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)x, (unsigned short*)y, (unsigned char*)pos, H, W, C / 8, Ho, Wo, total);
+    hipLaunchKernelGGL(epi::maxpool3x3s2_fwd_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, (const float*)nullptr, (unsigned short*)y, (unsigned char*)pos, H, W, C / 8, Ho, Wo, total);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
+// y = maxpool(bf16(relu(x * scale + shift))): scale_shift [2C] f32 = the `scale_shift` epi_bn_finalize (or epi_bn_act_fwd) wrote
+extern "C" int epi_maxpool3x3s2_bn_relu_fwd(const void* x, const float* scale_shift, void* y, void* pos, int B, int H, int W, int C, epi_stream_t stream) {
+    if (!x || !scale_shift || !y || !pos || B <= 0 || H <= 0 || W <= 0 || C <= 0) return EPI_ERR_INVALID_ARGUMENT;
+    if (C % 8 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) || (reinterpret_cast<uintptr_t>(pos) & 7u)) return EPI_ERR_UNSUPPORTED;
+    const int Ho = pool_out(H), Wo = pool_out(W);
+    const long long total = (long long)B * Ho * Wo * (C / 8);
+    if ((total + 255) / 256 > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(epi::maxpool3x3s2_fwd_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, scale_shift, (unsigned short*)y, (unsigned char*)pos, H, W, C / 8, Ho, Wo, total);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }

@@ -1122,8 +1122,11 @@ Tensor conv_bn_act(Tensor x, Tensor w, c10::optional<Tensor> w_bwd, int64_t stri
 // rounds 1-2 left it to MIOpen.  x: [B, 3, H, W] f32 or bf16, NCHW or channels_last; needs no gradient.  w: [C, 3, 7, 7] bf16 training copy
 // or fp32 master.  The weight gradient is a TN GEMM on the second stream followed by a 9 408-element re-ordering into the parameter's layout.
 struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
+    // pool: also the stem's MaxPool2d(3, 2, 1) (pose3d_resnet.py:104,186), applied to bf16(relu(bn(conv))) straight from the RAW convolution output
+    // (epi_bn_finalize + epi_maxpool3x3s2_bn_relu_fwd): the normalised 67 MB tensor, whose only reader is the pool, is never written
     static Tensor forward(AutogradContext* ctx, Tensor x, Tensor w, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var,
-                          Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
+                          Tensor num_batches, Tensor sums_ws, Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu,
+                          bool pool) {
         TORCH_CHECK(x.is_cuda() && w.is_cuda(), "stem_conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
         TORCH_CHECK(x.dim() == 4 && x.size(1) == 3 && w.dim() == 4 && w.size(1) == 3 && w.size(2) == 7 && w.size(3) == 7, "stem_conv_bn_act: shapes");
         TORCH_CHECK(x.scalar_type() == at::kFloat || x.scalar_type() == at::kBFloat16, "stem_conv_bn_act: image dtype");
@@ -1160,14 +1163,40 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
                                     training ? &sums_done : nullptr, ws.data_ptr(), (size_t)ws.numel(), st), "epi_stem7x7s2_fwd");
         }
         BnBuffers b{gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags};
-        Tensor stats, y;
-        if (training && !sums_done) {
-            flags.data_ptr<int>()[0] = 0;
-            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, false);
+        Tensor stats, y, pos;
+        const bool pooled = pool && relu && (!training || sums_done) && Cout % 8 == 0;
+        if (pooled) {
+            const int Hc = H / 2, Wc = W / 2, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+            stats = at::empty({4 * (int64_t)Cout}, gamma.options().dtype(at::kFloat));
+            float* sp = stats.data_ptr<float>();
+            EpiBnLayer l;
+            l.gamma = gamma.data_ptr<float>(); l.beta = beta.data_ptr<float>(); l.running_mean = running_mean.data_ptr<float>();
+            l.running_var = running_var.data_ptr<float>(); l.num_batches_tracked = reinterpret_cast<long long*>(num_batches.data_ptr<int64_t>());
+            l.mean = sp; l.rstd = sp + Cout; l.scale_shift = sp + 2 * Cout; l.sums_ws = sums_ws.data_ptr<float>(); l.bwd_sums = bwd_sums.data_ptr<float>();
+            check(epi_bn_finalize(&l, (long long)B * Hc * Wc, Cout, (float)eps, (float)momentum, training ? 2 : 0, st), "epi_bn_finalize");
+            y = at::empty({B, Cout, Hp, Wp}, raw.options().memory_format(at::MemoryFormat::ChannelsLast));
+            pos = at::empty({B, Hp, Wp, Cout}, raw.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+            ScopedTimer timer("maxpool_fwd", 0.0, 2.0 * (double)raw.numel() + 3.0 * (double)y.numel(), st);
+            check(epi_maxpool3x3s2_bn_relu_fwd(raw.data_ptr(), sp + 2 * Cout, y.data_ptr(), pos.data_ptr(), B, Hc, Wc, Cout, st), "epi_maxpool3x3s2_bn_relu_fwd");
         } else {
-            y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, training);
+            if (training && !sums_done) {
+                flags.data_ptr<int>()[0] = 0;
+                y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, false);
+            } else {
+                y = bn_forward(raw, Tensor(), b, training, momentum, eps, relu, &stats, training);
+            }
+            if (pool) {                 // (the fused form was not applicable: the two passes)
+                const int64_t Hc = y.size(2), Wc = y.size(3), Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+                Tensor yp = at::empty({B, Cout, Hp, Wp}, y.options().memory_format(at::MemoryFormat::ChannelsLast));
+                pos = at::empty({B, Hp, Wp, Cout}, y.options().dtype(at::kByte).memory_format(at::MemoryFormat::Contiguous));
+                ScopedTimer timer("maxpool_fwd", 0.0, 2.0 * (double)y.numel() + 3.0 * (double)yp.numel(), st);
+                check(epi_maxpool3x3s2_fwd(y.data_ptr(), yp.data_ptr(), pos.data_ptr(), B, (int)Hc, (int)Wc, Cout, st), "epi_maxpool3x3s2_fwd");
+                y = yp;
+            }
         }
         ctx->saved_data["training"] = training;
+        ctx->saved_data["pool"] = pool;
+        if (pool && training) ctx->saved_data["pos"] = pos;
         if (training) {
             auto holder = c10::make_intrusive<SavedHolder>();
             holder->stages.resize(1);
@@ -1188,7 +1217,17 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
         TORCH_CHECK(!holder->stages.empty(), "stem_conv_bn_act: backward called twice (the fused nodes free their activations in backward)");
         g_side.jobs.clear();
         const StageSaved& sv = holder->stages[0];
-        BnGrads g = bn_backward(grads[0], sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false);
+        Tensor dy = grads[0];
+        if (ctx->saved_data["pool"].toBool()) {         // the pool's backward first: dy of the BatchNorm output from the pooled gradient and the window positions
+            const Tensor pos = ctx->saved_data["pos"].toTensor();
+            if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
+            Tensor dfull = at::empty_like(sv.raw);
+            ScopedTimer timer("maxpool_bwd", 0.0, 3.0 * (double)dy.numel() + 2.0 * (double)dfull.numel(), current_stream(dy));
+            check(epi_maxpool3x3s2_bwd(dy.data_ptr(), pos.data_ptr(), dfull.data_ptr(), (int)sv.raw.size(0), (int)sv.raw.size(2), (int)sv.raw.size(3),
+                                       (int)sv.raw.size(1), current_stream(dy)), "epi_maxpool3x3s2_bwd");
+            dy = dfull;
+        }
+        BnGrads g = bn_backward(dy, sv.raw, Tensor(), sv.stats, sv.gamma, sv.sums_ws, sv.bwd_sums, sv.flags, sv.relu, false);
         const int H = sv.K, W = sv.S, B = sv.P, Cout = (int)sv.raw.size(1);
         Tensor dw;
         if (ctx->needs_input_grad(1)) {
@@ -1218,13 +1257,13 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
         }
         side_run_jobs();
         holder->stages.clear();
-        return {Tensor(), dw, g.dgamma, g.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+        return {Tensor(), dw, g.dgamma, g.dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     }
 };
 
 Tensor stem_conv_bn_act(Tensor x, Tensor w, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var, Tensor num_batches, Tensor sums_ws,
-                        Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu) {
-    return StemConvBnAct::apply(x, w, gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags, training, momentum, eps, relu);
+                        Tensor bwd_sums, Tensor flags, bool training, double momentum, double eps, bool relu, bool pool) {
+    return StemConvBnAct::apply(x, w, gamma, beta, running_mean, running_var, num_batches, sums_ws, bwd_sums, flags, training, momentum, eps, relu, pool);
 }
 
 // ---- A whole residual unit (BasicBlock / Bottleneck, pose3d_resnet.py:18-88) as ONE autograd node ------------------------------

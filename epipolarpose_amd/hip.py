@@ -61,6 +61,8 @@ _SIGNATURES = {
     "epi_conv2d_bwd_data_half_addend_ok": (_i, [_i, _i, _i, _i, _i]),
     "epi_deconv4x4s2_bwd_data_bnred": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_gemm_bf16_bnred": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_bn_finalize": (_i, [_vp, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _vp]),
+    "epi_maxpool3x3s2_bn_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "epi_bn_act_fwd_dual": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _vp, _vp]),
     "epi_bn_act_bwd_reduced": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_conv2d_bwd_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, ctypes.c_size_t, _vp]),

@@ -36,6 +36,7 @@ MAXPOOL_BACKEND = os.environ.get("EPI_MAXPOOL", "hip")       # "torch": the libr
 # Backend of the 7x7 stem convolution (EPI_STEM): "hip" (default, round 3) = the implicit-GEMM kernels on the space-to-depth image,
 # conv -> BatchNorm -> ReLU one C++ autograd node; "miopen" = nn.Conv2d through MIOpen + the fused BatchNorm module (rounds 1-2)
 STEM_BACKEND = os.environ.get("EPI_STEM", "hip")
+STEM_POOL = os.environ.get("EPI_STEM_POOL", "1") != "0"      # the stem's max-pool inside the stem node (BatchNorm + ReLU applied on the way in)
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -176,21 +177,23 @@ class PoseResNet(nn.Module):
         layers = [self.layer1, self.layer2, self.layer3, self.layer4]
         return layers[n - 1], [self.conv1, self.bn1] + layers[:n]
 
-    def stem(self, x):
+    def stem(self, x, pool=False):
+        """conv1 -> bn1 -> relu (pose3d_resnet.py:186-188); ``pool``: also the max-pool, inside the same node (the normalised tensor is then never
+        written: csrc/torch_glue.cpp StemConvBnAct).  Returns (tensor, pooled)."""
         conv, bn = self.conv1, self.bn1
         if (STEM_BACKEND == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and conv.out_channels % 8 == 0):
             w = sync_training_copy(conv) if getattr(conv, "weight_lp", None) is not None else conv.weight
             g, b, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
-            return hip.glue().stem_conv_bn_act(x, w, g, b, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, bn.training, bn.momentum, bn.eps, bn.relu)
-        return bn(conv(x))
+            pool = bool(pool and bn.relu)
+            return hip.glue().stem_conv_bn_act(x, w, g, b, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, bn.training, bn.momentum, bn.eps, bn.relu, pool), pool
+        return bn(conv(x)), False
 
     def features(self, x):
-        x = self.stem(x)
-        if x.is_cuda and x.shape[1] % 8 == 0 and MAXPOOL_BACKEND == "hip":      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
-            x = hip.glue().maxpool3x3s2(x)
-        else:
-            x = self.maxpool(x)
+        own_pool = x.is_cuda and self.conv1.out_channels % 8 == 0 and MAXPOOL_BACKEND == "hip"      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
+        x, pooled = self.stem(x, pool=own_pool and STEM_POOL)
+        if not pooled:
+            x = hip.glue().maxpool3x3s2(x) if own_pool else self.maxpool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
     def forward(self, x):

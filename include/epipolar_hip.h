@@ -259,6 +259,13 @@ typedef struct EpiBnLayer {
 } EpiBnLayer;
 int epi_bn_act_fwd_dual(const void* x, const void* x_proj, long long R, int C, const EpiBnLayer* main_bn, const EpiBnLayer* proj_bn,
                         float eps, float momentum, int training, void* y, epi_stream_t stream);
+/* The stem's `self.maxpool(self.relu(self.bn1(...)))` (pose3d_resnet.py:186-188) without the normalised tensor in between: epi_bn_finalize does the
+ * per-channel part of epi_bn_act_fwd alone (statistics from sums_ws -- training 2: the producer delivered them; 0: running statistics --, scale / shift,
+ * running estimates, accumulator hand-over), epi_maxpool3x3s2_bn_relu_fwd pools bf16(relu(x * scale + shift)) straight from the raw convolution output
+ * (same result and window positions as epi_bn_act_fwd + epi_maxpool3x3s2_fwd, bit for bit).  Backward: epi_maxpool3x3s2_bwd, then epi_bn_act_bwd
+ * with the mask from x (y = NULL). */
+int epi_bn_finalize(const EpiBnLayer* layer, long long R, int C, float eps, float momentum, int training, epi_stream_t stream);
+int epi_maxpool3x3s2_bn_relu_fwd(const void* x, const float* scale_shift, void* y, void* pos, int B, int H, int W, int C, epi_stream_t stream);
 
 /* ---- The BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's dy ---------------------------
  * (autograd of `out = relu(bn(conv(x)) [+ residual])`, pose3d_resnet.py:33-46,68-88,186-199: the gradient of a BatchNorm output is

@@ -551,7 +551,7 @@ def test_stem_convolution_vs_torch_fp32(layout):
     bn = hip_bn_module(cout, gamma, beta, dev)
     wp = torch.nn.Parameter(wcl.clone())
     g_, b_, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
-    out = hip.glue().stem_conv_bn_act(xin, wp, g_, b_, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, True, 0.1, 1e-5, True)
+    out = hip.glue().stem_conv_bn_act(xin, wp, g_, b_, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, True, 0.1, 1e-5, True, False)
     wf, gf, bf_ = wr.detach().clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     refo = F.relu(F.batch_norm(F.conv2d(xr, wf, stride=2, padding=3), None, None, gf, bf_, True, 0.1, 1e-5))
     assert (out.float() - refo).abs().max().item() <= 3e-2 * refo.abs().max().item()
@@ -562,6 +562,51 @@ def test_stem_convolution_vs_torch_fp32(layout):
     for got, want, what in ((wp.grad, wf.grad, "dw"), (bn.weight.grad, gf.grad, "dgamma"), (bn.bias.grad, bf_.grad, "dbeta")):
         got, want = got.float(), want.float()
         assert float((got - want).norm()) <= 4e-2 * float(want.norm()) + 1e-6, (what, float((got - want).norm()), float(want.norm()))
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_stem_node_with_the_pool_inside(training):
+    """stem_conv_bn_act(..., pool=True): BatchNorm + ReLU applied on the way into the 3x3 stride-2 max-pool (epi_bn_finalize +
+    epi_maxpool3x3s2_bn_relu_fwd; the normalised tensor is never written) against the two-pass form of the same kernels (stem node, then the
+    max-pool node): the same values rounded at the same place -> bit-identical outputs, statistics and input-side gradients."""
+    import copy
+    from epipolarpose_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(41)
+    b, cout, h = 4, 64, 64
+    x = _rand((b, 3, h, h), gen).float().to(dev)
+    w0 = _rand((cout, 3, 7, 7), gen, scale=(2.0 / 147) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.rand(cout, generator=gen) + 0.5).to(dev), (torch.randn(cout, generator=gen) * 0.1).to(dev)
+    outs = []
+    for pool in (True, False):
+        bn = hip_bn_module(cout, gamma, beta, dev)
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.1, generator=None)
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, cout))
+            bn.running_var.copy_(torch.linspace(0.5, 1.5, cout))
+        bn.train(training)
+        wp = torch.nn.Parameter(w0.clone())
+        g_, b_, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
+        y = hip.glue().stem_conv_bn_act(x, wp, g_, b_, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, training, 0.1, 1e-5, True, pool)
+        if not pool:
+            y = hip.glue().maxpool3x3s2(y)
+        grads = None
+        if training:
+            dy = _rand(tuple(y.shape), torch.Generator().manual_seed(42)).to(dev).contiguous(memory_format=torch.channels_last)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            grads = (wp.grad.float().clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        outs.append((y.detach().clone(), grads, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    (ya, ga, ma, va, na), (yb, gb, mb, vb, nb) = outs
+    assert ya.shape == (b, cout, h // 4, h // 4) and torch.equal(ya, yb)
+    assert na == nb
+    if training:
+        # the batch statistics come from the same epilogue atomics in both forms (their order varies run to run: last-bit differences)
+        assert float((ma - mb).abs().max()) <= 1e-6 and float((va - vb).abs().max()) <= 1e-6
+        for u, v in zip(ga, gb):
+            assert float((u - v).norm()) <= 2e-3 * float(v.norm()) + 1e-9
+    else:
+        assert torch.equal(ma, mb) and torch.equal(va, vb)
 
 
 def hip_bn_module(c, gamma, beta, dev):

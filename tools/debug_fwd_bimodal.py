@@ -17,7 +17,7 @@ def run():
     outs = []
     with torch.no_grad() if False else torch.enable_grad():
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            t = m.stem(x); outs.append(("stem", t))
+            t, _ = m.stem(x); outs.append(("stem", t))
             t = hip.glue().maxpool3x3s2(t); outs.append(("pool", t))
             for ln in ("layer1", "layer2", "layer3", "layer4"):
                 for bi, blk in enumerate(getattr(m, ln)):
