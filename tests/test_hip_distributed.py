@@ -46,3 +46,68 @@ def test_two_ranks_on_one_device_bucketed_path(tmp_path, layers):
     assert r0["min_cos"] >= lo and r0["median_cos"] >= med, (r0["median_cos"], r0["worst"])
     assert 0.8 <= r0["norm_ratio_range"][0] and r0["norm_ratio_range"][1] <= 1.25, r0["norm_ratio_range"]
     assert all(l == l and l < 10 for l in r0["losses"] + r1["losses"])
+
+
+def test_stock_ddp_wrapper_sees_finished_gradients():
+    """torch's DistributedDataParallel registers its reducer as a post-hook of every AccumulateGrad node and copies the gradient
+    into its buckets INSIDE the backward pass.  A weight gradient that is still in flight on the second stream (or unreduced in slabs) at that moment would
+    be copied half-written.  The glue looks at acc->post_hooks() (gradient_consumed_after_backward) and keeps such gradients on the main stream with an
+    immediate reduction: a DDP-wrapped network (world size 1, gloo, fp32 master weights used directly) must produce the gradients of the unwrapped one."""
+    import copy
+    import torch
+    import torch.distributed as dist
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.EXTRA.NUM_LAYERS = 18
+    j = 4
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, 16, [128, 128]
+    torch.manual_seed(11)
+    base = get_pose_net(cfg, is_train=False).to(dev).train()
+    x = torch.randn(16, 3, 128, 128, device=dev)
+    gt = (torch.rand(16, 3 * j, device=dev) - 0.5) * 0.4
+    vis = torch.ones(16, 3 * j, device=dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    # a well-conditioned state first (tests/test_hip_step_in_backward.py: at random initialisation two runs of the same code differ by tens of per cent)
+    opt = torch.optim.Adam(base.parameters(), lr=1e-2)
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            crit(base(x), gt, vis).backward()
+        opt.step()
+    torch.cuda.synchronize()
+
+    def grads(m):
+        for p in m.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            crit(m(x), gt, vis).backward()
+        torch.cuda.synchronize()
+        return {k.replace("module.", ""): p.grad.detach().float().clone() for k, p in m.named_parameters()}
+
+    plain_a, plain_b = grads(copy.deepcopy(base)), grads(copy.deepcopy(base))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
+        grads(ddp)                       # (the first pass builds the reducer's bucket order)
+        wrapped = grads(ddp)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert set(wrapped) == set(plain_a)
+
+    def cos(a, b):
+        a, b = a.reshape(-1).double(), b.reshape(-1).double()
+        return float(a @ b / (a.norm() * b.norm() + 1e-300))
+    noise = min(cos(plain_a[k], plain_b[k]) for k in plain_a)
+    worst = min((cos(wrapped[k], plain_a[k]), k) for k in plain_a)
+    # a gradient copied before its kernel (or its slab sum) had finished is garbage or half a sum: cosine far below the run-to-run level
+    assert worst[0] >= min(0.99, noise - 0.02), (worst, noise)
+    for k in plain_a:
+        ratio = float(wrapped[k].norm() / (plain_a[k].norm() + 1e-30))
+        assert 0.9 <= ratio <= 1.1, (k, ratio)
