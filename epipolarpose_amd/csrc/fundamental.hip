@@ -14,7 +14,7 @@
 
 namespace epi {
 
-__device__ __forceinline__ float fm_error(const double* __restrict__ F, double x1, double y1, double x2, double y2) {
+__host__ __device__ __forceinline__ float fm_error(const double* __restrict__ F, double x1, double y1, double x2, double y2) {      // (host: tests/hostcheck)
     double a = F[0] * x1 + F[1] * y1 + F[2];
     double b = F[3] * x1 + F[4] * y1 + F[5];
     double c = F[6] * x1 + F[7] * y1 + F[8];

@@ -9,7 +9,7 @@ OUT = os.path.join(HERE, "_build", "libhostcheck.so")
 def build(force=False):
     src = os.path.join(HERE, "hostcheck.hip")
     csrc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "epipolarpose_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in ("selfsup.hip", "linalg3.h", "common.h")]
+    deps = [src] + [os.path.join(csrc, f) for f in ("selfsup.hip", "fundamental.hip", "linalg3.h", "common.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

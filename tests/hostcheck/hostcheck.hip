@@ -2,6 +2,12 @@
 // `pytest -m "not gpu"` can compare it with the oracle without a GPU.  Built by tests/hostcheck/build.py into
 // tests/hostcheck/_build/libhostcheck.so; never linked into, loaded by, or shipped with the product library.
 #include "../../epipolarpose_amd/csrc/selfsup.hip"
+#include "../../epipolarpose_amd/csrc/fundamental.hip"
+
+// csrc/fundamental.hip: the symmetric epipolar error of the LMedS scoring kernels, one pair at a time
+extern "C" void hostcheck_fm_errors(const double* F, const double* u1, const double* u2, int n, float* err) {
+    for (int i = 0; i < n; ++i) err[i] = epi::fm_error(F, u1[2 * i], u1[2 * i + 1], u2[2 * i], u2[2 * i + 1]);
+}
 
 extern "C" void hostcheck_correct_matches(const double* F, const double* u1, const double* u2, int n, double* o1, double* o2) {
     double Fm[3][3];

@@ -265,3 +265,23 @@ def test_oracle_lmeds_median_and_error():
     off = u2 + [0.0, 7.0]
     e2 = o_tri.fm_compute_error(f / f[2, 2], u1.astype(np.float32), off.astype(np.float32))
     np.testing.assert_allclose(np.sqrt(e2), _sym_epi_dist(f, u1.astype(np.float32).astype(float), off.astype(np.float32).astype(float)), rtol=1e-5)
+
+
+def test_hostcheck_lmeds_error_matches_oracle(hostlib):
+    """csrc/fundamental.hip fm_error compiled for the host: the float32 symmetric epipolar error the scoring kernels compute per pair == the oracle's
+    (the same float64 arithmetic, rounded to float32 once), and the median taken from it picks the oracle's candidate."""
+    _, u1, u2, p1, p2 = _scene(31, n=41, noise=1.0)
+    i1, i2 = np.float32(np.int32(u1)), np.float32(np.int32(u2))
+    a, b = np.ascontiguousarray(i1, np.float64), np.ascontiguousarray(i2, np.float64)
+    rng = np.random.default_rng(32)
+    ft = o_tri.fundamental_from_projections(p1, p2)
+    cands = [ft / ft[2, 2], ft / ft[2, 2] + 1e-7 * rng.normal(size=(3, 3)), rng.normal(size=(3, 3))]
+    meds = []
+    for f in cands:
+        f = np.ascontiguousarray(f, np.float64)
+        err = np.zeros(len(a), np.float32)
+        hostlib.hostcheck_fm_errors(_dp(f), _dp(a), _dp(b), len(a), err.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        ref = o_tri.fm_compute_error(f, i1, i2)
+        np.testing.assert_allclose(err, ref, rtol=2e-6, atol=1e-12)
+        meds.append(o_tri.fm_median(err))
+    assert int(np.argmin(meds)) == int(np.argmin([o_tri.fm_median(o_tri.fm_compute_error(f, i1, i2)) for f in cands]))
