@@ -112,6 +112,7 @@ struct GemmArgs {
     GemmBnRed br;          // unsplit bf16 launches on the coalesced epilogue only (launch_gemm decides and reports)
     int addend_step;       // 2: `addend` is [B][add_h / 2][add_w / 2][ldc] and holds the contribution of the EVEN pixels of the [B][add_h][add_w] output only
     int add_h, add_w;      //    (the shortcut gradient through a 1x1 stride-2 projection: every other pixel receives none); plain rows, coalesced epilogue only
+    int store_policy;      // coalesced epilogue's result stores: 0 plain, 1 non-temporal (nt) -- epi_gemm_store_policy
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -197,7 +198,215 @@ __device__ __forceinline__ uint4v bnred_apply(const GemmBnRed& br, uint4v o, uin
     return r;
 }
 
+// -DEPI_GEMM_TRACE (tools/gemm_lab.hip's trace build only): wave 0 of every workgroup stamps s_memtime at its phase boundaries
+//   0 entry | 1 s_memrealtime at entry | 2 staging roles computed | 3 first K tile landed | 4 K loop done | 5 tile parked in LDS |
+//   6 stores issued | 7 stores drained (+ statistics) | 8 s_memrealtime at exit | 9 HW_ID | 10 XCC_ID | 11 K tiles
+#ifdef EPI_GEMM_TRACE
+constexpr int GEMM_TRACE_WGS = 8192, GEMM_TRACE_SLOTS = 16;
+__device__ unsigned long long epi_gemm_trace[GEMM_TRACE_WGS * GEMM_TRACE_SLOTS];
+#define GEMM_STAMP_V(i, v)                                                                                               \
+    do {                                                                                                                 \
+        const int wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                                  \
+        if (threadIdx.x == 0 && wg_ < GEMM_TRACE_WGS) epi_gemm_trace[wg_ * GEMM_TRACE_SLOTS + (i)] = (v);               \
+    } while (0)
+#define GEMM_STAMP(i) GEMM_STAMP_V(i, __builtin_amdgcn_s_memtime())
+#else
+#define GEMM_STAMP_V(i, v) do {} while (0)
+#define GEMM_STAMP(i) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Coalesced bf16 epilogue shared by head_gemm_kernel and conv_patch_kernel (N % 8 == 0, 16-byte aligned rows).
+// The wave parks its (TM*32) x 64 bf16 sub-tile in its own slice of the (now idle) staging LDS -- 8-byte units XOR-swizzled by (row & 15) so
+// the 16 rows of a ds_write_b64 lane group hit 16 different bank pairs -- and writes it out as whole 128-byte row segments (8 lanes x 16 B per
+// row, 8 rows per instruction) instead of 8-byte pieces of 32 different rows.  The caller's last barrier separated the final fragment reads from
+// these writes; afterwards each wave only touches its own region (LDS ops of a wave are ordered).
+// Optional, all decided by WAVE-UNIFORM flags that are tested ONCE (round 4: the round-3 form tested p.bias per element and the row mapping /
+// addend / statistics flags per copied row -- ~300 branches per wave, 3.3 us of a workgroup's life on the phase trace, tools/gemm_trace.hip):
+//   * bias: added to the accumulators before the park;
+//   * residual-junction addend: requested before the park, consumed after the LDS round trip;
+//   * BatchNorm statistics of the bf16-ROUNDED outputs (p.stats: the convolution feeds a training-mode BatchNorm): 8 columns per lane over the
+//     rows it copies, reduced over the 8 row lanes with three shuffles, combined over the workgroup's wave rows through LDS, then ONE contiguous
+//     fp32 atomic per column and workgroup (what serialises in L2 is the number of (instruction, 128-byte line) pairs per line);
+//   * RED (compile time): the fused BatchNorm-backward reduction (GemmBnRed), whose two sums take the statistics' route.
+// ---------------------------------------------------------------------------------------------------------------
+// (the fields of GemmArgs the epilogue reads, BY VALUE: a reference to the kernel argument itself would make the compiler copy all of it to
+//  scratch in the instantiations that also index its tap tables dynamically)
+struct EpiArgs {
+    void* C;
+    const float* bias;
+    const unsigned short* addend;
+    float* stats;
+    int M, N, ldc, stats_copies, addend_step, add_h, add_w, store_policy;
+    GemmScatter sc;
+    GemmBnRed br;
+};
+#define EPI_ARGS_OF(p) EpiArgs{(p).C, (p).bias, (p).addend, (p).stats, (p).M, (p).N, (p).ldc, (p).stats_copies, (p).addend_step, (p).add_h, (p).add_w, (p).store_policy, (p).sc, (p).br}
+template <int TM, int WM, int WN, int THREADS, bool RED, bool RED_PREFETCH = true>
+__device__ __forceinline__ void coalesced_epilogue(const EpiArgs p, f32x16 (&acc)[TM][2], char* smem, int m0, int n0, int tile_m, int wm, int wn, int wid,
+                                                   int lane, int tid, int sc_oy, int sc_ox) {
+    constexpr int GBN = WN * 64, ROWS = TM * 4;
+    const int frow = lane & 31, fhalf = lane >> 5, c8 = lane & 7, r8 = lane >> 3;
+    char* mine = smem + wid * (TM * 32 * 128);
+    const int n = n0 + wn * 64 + c8 * 8;
+    const int m_first = m0 + wm * (TM * 32) + r8;          // the row this lane copies in read-back iteration `it` is m_first + 8 * it
+    const bool col_ok = n < p.N;
+    const bool scatter = p.sc.enabled != 0, has_add = p.addend != nullptr, half_add = p.addend_step == 2, nt_stores = p.store_policy == 1;
+    // element offset of (copied row of iteration it, column n) in C (and in the addend / z / y, which share C's row mapping); ok: inside the matrix
+    auto row_off = [&](int it, bool& ok, auto sc_c) __attribute__((always_inline)) -> long long {
+        const int m = m_first + 8 * it;
+        ok = col_ok && m < p.M;
+        if (!decltype(sc_c)::value) return (long long)m * p.ldc + n;
+        const int hw = p.sc.Hg * p.sc.Wg;
+        const int b = m / hw, rem = m - b * hw;
+        const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
+        return (((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox) * p.ldc + n;
+    };
+    // the residual-junction addend of a plain row m (addend_step 2: the half-resolution tensor that holds the even pixels only)
+    auto addend_at = [&](int m, long long off) __attribute__((always_inline)) -> uint4v {
+        if (!half_add) return *reinterpret_cast<const uint4v*>(p.addend + off);
+        const int hw = p.add_h * p.add_w;
+        const int b = m / hw, rem = m - b * hw;
+        const int yy = rem / p.add_w, xx = rem - yy * p.add_w;
+        if ((yy | xx) & 1) return uint4v{0u, 0u, 0u, 0u};
+        const long long ar = ((long long)b * (p.add_h >> 1) + (yy >> 1)) * (p.add_w >> 1) + (xx >> 1);
+        return *reinterpret_cast<const uint4v*>(p.addend + ar * p.ldc + n);
+    };
+    constexpr bool AD_EARLY = !(RED && (TM >= 4 || !RED_PREFETCH));   // (the 256-row tile / the patch kernel with the fused reduction: no registers for the addend rows)
+    constexpr bool RED_EARLY = RED && RED_PREFETCH && TM <= 2;   // z / y of all rows requested before the park too: their latency hides behind it
+                                                                 // (RED_PREFETCH = false: the patch kernel's register budget has no room for them)
+    uint4v ad[AD_EARLY ? ROWS : 1];
+    uint4v zpre[RED_EARLY ? ROWS : 1], ypre[RED_EARLY ? ROWS : 1];
+    auto prefetch = [&](auto sc_c) __attribute__((always_inline)) {
+        if (AD_EARLY && has_add) {
+#pragma unroll
+            for (int it = 0; it < ROWS; ++it) {
+                bool ok;
+                const long long off = row_off(it, ok, sc_c);
+                ad[it] = ok ? addend_at(m_first + 8 * it, off) : uint4v{0u, 0u, 0u, 0u};
+            }
+        }
+        if (RED_EARLY) {
+            const bool use_y = p.br.relu && p.br.y;
+#pragma unroll
+            for (int it = 0; it < ROWS; ++it) {
+                bool ok;
+                const long long off = row_off(it, ok, sc_c);
+                zpre[it] = ok ? *reinterpret_cast<const uint4v*>(p.br.z + off) : uint4v{0u, 0u, 0u, 0u};
+                ypre[it] = (ok && use_y) ? *reinterpret_cast<const uint4v*>(p.br.y + off) : uint4v{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    if (RED_EARLY || (AD_EARLY && has_add)) { if (scatter) prefetch(std::true_type{}); else prefetch(std::false_type{}); }
+    // ---- park: lane holds, for tile (ti, tj): row ti*32 + (lane & 31) of the wave's sub-tile, columns tj*32 + 8*q + 4*(lane >> 5) + e (reg 4*q + e).
+    //      Two compile-time copies (with / without the bias add: rare, the head's final layer when it leaves the A-stationary kernel); the
+    //      accumulators are only READ -- a conditional in-place update would keep a second copy of all of them live ----
+    auto park = [&](auto bias_c) __attribute__((always_inline)) {
+        constexpr bool BIAS = decltype(bias_c)::value;
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float b[4] = {0.f, 0.f, 0.f, 0.f};
+                if (BIAS) {
+                    const int nq = n0 + wn * 64 + tj * 32 + 8 * q + 4 * fhalf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = nq + e < p.N ? p.bias[nq + e] : 0.f;
+                }
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti) {
+                    const int row = ti * 32 + frow;
+                    uint2 t;
+                    if (BIAS) {
+                        t.x = pack_bf16x2(acc[ti][tj][4 * q] + b[0], acc[ti][tj][4 * q + 1] + b[1]);
+                        t.y = pack_bf16x2(acc[ti][tj][4 * q + 2] + b[2], acc[ti][tj][4 * q + 3] + b[3]);
+                    } else {
+                        t.x = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
+                        t.y = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
+                    }
+                    const int unit = tj * 8 + 2 * q + fhalf;
+                    *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
+                }
+            }
+    };
+    if (p.bias) park(std::true_type{}); else park(std::false_type{});
+    GEMM_STAMP(5);
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+    BnRedCols rcols;
+    if (RED) bnred_cols(p.br, p.N, n, rcols);
+    // ---- read back + store; STATS / ADD are compile-time copies of the loop, selected once ----
+    auto copy_rows = [&](auto stats_c, auto add_c, auto sc_c) __attribute__((always_inline)) {
+        constexpr bool STATS = decltype(stats_c)::value, ADD = decltype(add_c)::value;
+#pragma unroll
+        for (int it = 0; it < ROWS; ++it) {
+            // (RED: at most four rows' z / y tiles in flight per lane -- the scheduler would otherwise hoist all TM*4 loads to the top)
+            if (RED && !RED_EARLY && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
+            const int row = it * 8 + r8, sw = row & 15;
+            const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
+            const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
+            bool ok;
+            const long long off = row_off(it, ok, sc_c);
+            if (!ok) continue;
+            if (STATS) {
+                const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
+                    ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
+                    ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
+                }
+            }
+            uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+            if (ADD) o = add_bf16x8(o, AD_EARLY ? ad[it] : addend_at(m_first + 8 * it, off));
+            if (RED) o = RED_EARLY ? bnred_apply(p.br, o, zpre[it], ypre[it], rcols, ssum, ssq) : bnred_row(p.br, o, off, rcols, ssum, ssq);
+            uint4v* dst = reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + off);
+            if (nt_stores) __builtin_nontemporal_store(o, dst);
+            else *dst = o;
+        }
+    };
+    const bool has_stats = !RED && p.stats != nullptr;
+    auto copy_sc = [&](auto sc_c) __attribute__((always_inline)) {
+        if (has_stats) { if (has_add) copy_rows(std::true_type{}, std::true_type{}, sc_c); else copy_rows(std::true_type{}, std::false_type{}, sc_c); }
+        else if (has_add) copy_rows(std::false_type{}, std::true_type{}, sc_c);
+        else copy_rows(std::false_type{}, std::false_type{}, sc_c);
+    };
+    if (scatter) copy_sc(std::true_type{}); else copy_sc(std::false_type{});
+    GEMM_STAMP(6);
+    if (has_stats || RED) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
+        }
+        float* st = reinterpret_cast<float*>(smem + WM * WN * (TM * 32 * 128));    // [WM][sum | sq][GBN], behind the waves' park slices
+        if (lane < 8) {
+            float* row = st + wm * (2 * GBN) + wn * 64 + c8 * 8;
+            *reinterpret_cast<float4v*>(row) = float4v{ssum[0], ssum[1], ssum[2], ssum[3]};
+            *reinterpret_cast<float4v*>(row + 4) = float4v{ssum[4], ssum[5], ssum[6], ssum[7]};
+            *reinterpret_cast<float4v*>(row + GBN) = float4v{ssq[0], ssq[1], ssq[2], ssq[3]};
+            *reinterpret_cast<float4v*>(row + GBN + 4) = float4v{ssq[4], ssq[5], ssq[6], ssq[7]};
+        }
+        __syncthreads();
+        float* dst = RED ? p.br.sums : p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N;
+        for (int t = tid; t < 2 * GBN; t += THREADS) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) v += st[w * (2 * GBN) + t];
+            const int which = t / GBN, col = n0 + (t % GBN);
+            if (col < p.N) atomicAdd(dst + which * p.N + col, v);
+        }
+    }
+#ifdef EPI_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_STAMP(7);
+    GEMM_STAMP_V(8, __builtin_amdgcn_s_memrealtime());
+#endif
+}
+
 enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's rows are addressed (compile-time: keeps the K loop branch-free)
+
 
 // RED: the instantiation with the fused BatchNorm-backward reduction (GemmBnRed) in the coalesced epilogue -- a separate one, so that the
 // registers its epilogue needs (column parameters, the z / y tiles in flight) never enter the allocation of the other launches
@@ -206,6 +415,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
     constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM, AP = Cfg::AP, BP = Cfg::BP;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    GEMM_STAMP(0);
+    GEMM_STAMP_V(1, __builtin_amdgcn_s_memrealtime());
+    GEMM_STAMP_V(9, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+    GEMM_STAMP_V(10, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
     const int wm = wid / Cfg::WN, wn = wid % Cfg::WN;
     const int tiles_n = (p.N + GBN - 1) / GBN;
     // logical id: tile_n fastest, then tile_m, then split, then phase -> neighbours share the A panel (and B)
@@ -272,11 +485,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         b_ptr[ps] = Bt + (long long)(b_ok[ps] ? n : 0) * ldb + b_chunk[ps];
     }
     const char* zero_src = reinterpret_cast<const char*>(epi_zero_chunk);
+    // K tiles are issued strictly in sequence, so the position of the NEXT tile to be issued is running state: k_run (the k0 arguments below
+    // are kept for readability only).  (Round 4 measured a per-M-tile ROTATION of that sequence and padded row pitches against the idea that
+    // the power-of-two row pitches make all workgroups hit the same few L2 / memory channels at once: no effect at any pitch --
+    // profiles/r04_probe_pitch_rotation.txt -- so every workgroup starts at k_begin.)
+    const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;     // 0: a phase without taps / an empty split (zeros)
+    int k_run = k_begin;
     // gather state of the NEXT K tile to be issued (wave-uniform): filter tap, channel offset inside the tap, pixel shift
-    int g_tap = MODE == A_PLAIN ? 0 : k_begin / p.ga.Cs;
-    int g_c0 = MODE == A_PLAIN ? 0 : k_begin - g_tap * p.ga.Cs;
+    int g_tap = MODE == A_PLAIN ? 0 : k_run / p.ga.Cs;
+    int g_c0 = MODE == A_PLAIN ? 0 : k_run - g_tap * p.ga.Cs;
     int g_shift = (MODE == A_PLAIN || ntaps == 0) ? 0 : tap_dy[min(g_tap, ntaps - 1)] * p.ga.Ws + tap_dx[min(g_tap, ntaps - 1)];
-    auto issue_a = [&](int ps, int k0, int buf) {
+    auto issue_a = [&](int ps, int, int buf) {
+        const int k0 = k_run;
         char* a_s = smem + buf * Cfg::STAGE_BYTES + __builtin_amdgcn_readfirstlane(wid) * (AP * 1024);
         const void* src;
         if (MODE != A_PLAIN) {       // K tiles never straddle a tap (Cs % 64 == 0) and K has no tail in the gather modes
@@ -288,12 +508,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         }
         glds16(src, a_s + ps * 1024);
     };
-    auto issue_b = [&](int ps, int k0, int buf) {
+    auto issue_b = [&](int ps, int, int buf) {
+        const int k0 = k_run;
         char* b_s = smem + buf * Cfg::STAGE_BYTES + Cfg::A_BYTES + __builtin_amdgcn_readfirstlane(wid) * (BP * 1024);
         const bool ok = b_ok[ps] && (MODE != A_PLAIN || k0 + b_chunk[ps] < k_end);
         glds16(ok ? reinterpret_cast<const void*>(b_ptr[ps] + k0) : reinterpret_cast<const void*>(zero_src), b_s + ps * 1024);
     };
     auto advance_gather = [&]() {    // after all pieces of one K tile were issued
+        k_run += GBK;
         if (MODE != A_PLAIN) {
             g_c0 += GBK;
             if (g_c0 >= p.ga.Cs) {
@@ -320,7 +542,6 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = k_end > k_begin ? (k_end - k_begin + GBK - 1) / GBK : 0;     // 0: a phase without taps / an empty split (zeros)
     const int frow = lane & 31, fhalf = lane >> 5;
     const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
     // fragment address of (row + 32*t, k step ks): rows 32 apart share the swizzle term -> + t*4096; the k step flips
@@ -364,6 +585,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                     acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][tj], af[ks & 1][ti], acc[ti][tj], 0, 0, 0);
         }
     };
+    GEMM_STAMP(2);
+    GEMM_STAMP_V(11, (unsigned long long)nk);
     if constexpr (Cfg::NSTAGE > 2) {
         // ---- pipelined loop: tiles kt+1 .. kt+S-2 stay in flight across the barrier of tile kt ----
         // RAW: a wave's `s_waitcnt vmcnt(N)` retires ITS pieces of tile kt (DMA completes in issue order), the barrier that
@@ -377,6 +600,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         for (; kt + (S - 2) < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * DPT) : "memory");
             __builtin_amdgcn_s_barrier();
+#ifdef EPI_GEMM_TRACE
+            if (kt == 0) GEMM_STAMP(3);
+#endif
             const int nxt = kt + S - 1;
             compute_tile(kt % S, nxt < nk, k_begin + nxt * GBK, nxt % S);
         }
@@ -391,6 +617,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
     } else {
         if (nk > 0) issue_tile(k_begin, 0);
         __syncthreads();                               // drains the DMA (vmcnt(0)) before the first fragment reads
+        GEMM_STAMP(3);
         // 2-stage loop.  The next tile's DMA: 4-wave tiles (two workgroups per CU) issue ALL of it right at the top, so that it
         // has the whole tile's MFMA time to land before the closing barrier; the 8-wave 256^2 tile (one workgroup owns the CU)
         // spreads it a quarter per k step between the MFMA groups, so that its waves are never all in a load-only phase.
@@ -403,6 +630,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         }
     }
 
+    GEMM_STAMP(4);
     // ---- epilogue: lane holds, for tile (ti, tj): row m = wm*TM*32 + ti*32 + (lane & 31),
     //      columns n = wn*64 + tj*32 + 8*q + 4*(lane >> 5) + e   for reg = 4*q + e ----
     if (gridDim.y > 1) {        // split-K partial: fp32, plain rows, finished by splitk_finish_kernel
@@ -424,138 +652,19 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
                     }
                 }
         }
+#ifdef EPI_GEMM_TRACE
+        GEMM_STAMP(6);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(7);
+        GEMM_STAMP_V(8, __builtin_amdgcn_s_memrealtime());
+#endif
         return;
     }
-    if (!OUT_F32 && p.coalesce) {
-        // Coalesced epilogue (bf16 result, N % 8 == 0, 16-byte aligned rows): the wave parks its (TM*32) x 64 bf16 sub-tile in its own slice of the (now idle) staging LDS
-        // -- 8-byte units XOR-swizzled by (row & 15) so the 16 rows of a ds_write_b64 lane group hit 16 different bank
-        // pairs -- and writes it out as whole 128-byte row segments (8 lanes x 16 B per row, 8 rows per instruction)
-        // instead of 8-byte pieces of 32 different rows.  The main loop's final barrier already separated the last
-        // fragment reads from these writes; afterwards each wave only touches its own region (LDS ops of a wave are ordered).
-        // When the caller wants BatchNorm statistics (p.stats: the convolution feeds a training-mode BatchNorm), the same
-        // read-back accumulates per-column sum and sum of squares of the bf16-ROUNDED outputs: 8 columns per lane over the
-        // rows it copies, reduced over the 8 row lanes with three shuffles, one fp32 atomic per column and wave.
-        char* mine = smem + wid * (TM * 32 * 128);
-        const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
-        // output row of read-back iteration `it` (rows it*8 + (lane >> 3) of the wave's sub-tile); -1: outside the matrix
-        auto out_row = [&](int it) -> long long {
-            const int m = m0 + wm * (TM * 32) + it * 8 + (lane >> 3);
-            if (m >= p.M || n >= p.N) return -1;
-            if (!p.sc.enabled) return m;
-            const int hw = p.sc.Hg * p.sc.Wg;
-            const int b = m / hw, rem = m - b * hw;
-            const int i = rem / p.sc.Wg, j = rem - i * p.sc.Wg;
-            return ((long long)b * p.sc.Ho + i * p.sc.so + sc_oy) * p.sc.Wo + j * p.sc.so + sc_ox;
-        };
-        // residual-junction addend: requested NOW, consumed after the LDS round trip below (its latency hides behind the park)
-        // the residual-junction addend of output row `orow`, columns n .. n + 7 (addend_step 2: the half-resolution tensor of the even pixels)
-        auto addend_at = [&](long long orow) -> uint4v {
-            if (p.addend_step != 2) return *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n);
-            const int hw = p.add_h * p.add_w;
-            const int b = (int)(orow / hw), rem = (int)(orow - (long long)b * hw);
-            const int yy = rem / p.add_w, xx = rem - yy * p.add_w;
-            if ((yy | xx) & 1) return uint4v{0u, 0u, 0u, 0u};
-            const long long ar = ((long long)b * (p.add_h >> 1) + (yy >> 1)) * (p.add_w >> 1) + (xx >> 1);
-            return *reinterpret_cast<const uint4v*>(p.addend + ar * p.ldc + n);
-        };
-        constexpr bool AD_EARLY = !(RED && TM >= 4);       // (the 256-row tile with the fused reduction: no registers for 16 rows of addend)
-        constexpr bool RED_EARLY = RED && !OUT_F32 && TM <= 2;   // z / y of all rows requested here too: their latency hides behind the park
-        uint4v ad[TM * 4];
-        if (AD_EARLY && p.addend) {
-#pragma unroll
-            for (int it = 0; it < TM * 4; ++it) {
-                const long long orow = out_row(it);
-                ad[it] = orow >= 0 ? addend_at(orow) : uint4v{0u, 0u, 0u, 0u};
-            }
+    if constexpr (!OUT_F32) {
+        if (p.coalesce) {           // bf16 result, N % 8 == 0, 16-byte aligned rows: whole 128-byte row segments through LDS
+            coalesced_epilogue<TM, Cfg::WM, Cfg::WN, Cfg::THREADS, RED>(EPI_ARGS_OF(p), acc, smem, m0, n0, tile_m, wm, wn, wid, lane, tid, sc_oy, sc_ox);
+            return;
         }
-        uint4v zpre[RED_EARLY ? TM * 4 : 1], ypre[RED_EARLY ? TM * 4 : 1];
-        if (RED_EARLY) {
-            const bool use_y = p.br.relu && p.br.y;
-#pragma unroll
-            for (int it = 0; it < TM * 4; ++it) {
-                const long long orow = out_row(it);
-                zpre[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.br.z + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
-                ypre[it] = (orow >= 0 && use_y) ? *reinterpret_cast<const uint4v*>(p.br.y + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
-            }
-        }
-#pragma unroll
-        for (int ti = 0; ti < TM; ++ti) {
-            const int row = ti * 32 + frow;
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + tj * 32 + 8 * q + 4 * fhalf;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[ti][tj][4 * q + e];
-                        if (p.bias && n + e < p.N) v[e] += p.bias[n + e];
-                    }
-                    uint2 t;
-                    t.x = pack_bf16x2(v[0], v[1]);
-                    t.y = pack_bf16x2(v[2], v[3]);
-                    const int unit = tj * 8 + 2 * q + fhalf;
-                    *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
-                }
-        }
-        float ssum[8], ssq[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
-        constexpr bool red = RED && !OUT_F32;          // fused BatchNorm-backward reduction (GemmBnRed): the two sums reuse the statistics' route
-        BnRedCols rcols;
-        if (red) bnred_cols(p.br, p.N, n, rcols);
-#pragma unroll
-        for (int it = 0; it < TM * 4; ++it) {
-            // (RED: at most four rows' z / y tiles in flight per lane -- the scheduler would otherwise hoist all TM*4 loads to the top)
-            if (red && !RED_EARLY && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
-            const int row = it * 8 + (lane >> 3), sw = row & 15;
-            const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
-            const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
-            const long long orow = out_row(it);
-            if (orow < 0) continue;
-            if (p.stats) {
-                const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
-                    ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
-                    ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
-                }
-            }
-            uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-            if (p.addend) o = add_bf16x8(o, AD_EARLY ? ad[it] : addend_at(orow));
-            if (red) o = RED_EARLY ? bnred_apply(p.br, o, zpre[it], ypre[it], rcols, ssum, ssq) : bnred_row(p.br, o, orow * p.ldc + n, rcols, ssum, ssq);
-            *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
-        }
-        if (p.stats || red) {
-            // reduce over the 8 row lanes, combine the workgroup's WM wave rows through LDS (a region behind the park slices), then
-            // ONE contiguous fp32 atomic per column and workgroup: what serialises in L2 is the number of (instruction, 128-byte
-            // line) pairs per line -- M-tiles x 1 this way, against M-tiles x WM x 16 with per-wave strided atomics (measured: 9 ns each)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
-            }
-            float* st = reinterpret_cast<float*>(smem + Cfg::WM * Cfg::WN * (TM * 32 * 128));    // [WM][sum | sq][GBN]
-            if (lane < 8) {
-                float* row = st + wm * (2 * GBN) + wn * 64 + c8 * 8;
-                *reinterpret_cast<float4v*>(row) = float4v{ssum[0], ssum[1], ssum[2], ssum[3]};
-                *reinterpret_cast<float4v*>(row + 4) = float4v{ssum[4], ssum[5], ssum[6], ssum[7]};
-                *reinterpret_cast<float4v*>(row + GBN) = float4v{ssq[0], ssq[1], ssq[2], ssq[3]};
-                *reinterpret_cast<float4v*>(row + GBN + 4) = float4v{ssq[4], ssq[5], ssq[6], ssq[7]};
-            }
-            __syncthreads();
-            for (int t = tid; t < 2 * GBN; t += Cfg::THREADS) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
-                const int which = t / GBN, col = n0 + (t % GBN);
-                float* dst = red ? p.br.sums : p.stats + (long long)((m0 / GBM) % p.stats_copies) * 2 * p.N;
-                if (col < p.N) atomicAdd(dst + which * p.N + col, v);
-            }
-        }
-        return;
     }
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti) {
@@ -681,6 +790,10 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
     }
     char* stage = smem + AS_RING * BTILE + wid * 4096;
     const int c8 = lane & 7;
+    // the slice loop exists in four compile-time copies (residual addend x BatchNorm statistics), selected ONCE: tested per slice and per
+    // copied row these wave-uniform flags were ~15 branches per slice beside 8 .. 32 MFMAs
+    auto slices = [&](auto add_c, auto stats_c) __attribute__((always_inline)) {
+    constexpr bool ADD = decltype(add_c)::value, STATS = decltype(stats_c)::value;
     for (int nt = 0; nt < n_tiles; ++nt) {
         f32x16 acc[2];
 #pragma unroll
@@ -704,7 +817,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
         // registers allow it (K <= 128: the stationary A fragments leave room); loaded at its use otherwise
         uint4v ad[4];
         auto load_addend = [&]() {
-            if (!p.addend) return;
+            if (!ADD) return;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int m = m0 + it * 8 + (lane >> 3), nn = nt * AS_BN + (lane & 7) * 8;
@@ -754,9 +867,9 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
             const int m = m0 + row;
             if (m < p.M && n < p.N) {
                 uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-                if (p.addend) o = add_bf16x8(o, KSTEPS <= 8 ? ad[it] : *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + n));
+                if (ADD) o = add_bf16x8(o, KSTEPS <= 8 ? ad[it] : *reinterpret_cast<const uint4v*>(p.addend + (long long)m * p.ldc + n));
                 *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + (long long)m * p.ldc + n) = o;
-                if (p.stats) {      // BatchNorm statistics of the bf16-rounded outputs (see head_gemm_kernel's epilogue)
+                if (STATS) {      // BatchNorm statistics of the bf16-rounded outputs (see coalesced_epilogue)
                     const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -767,7 +880,7 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
                 }
             }
         }
-        if (p.stats) {          // reduce over the 8 row lanes, then one LDS atomic per column and wave
+        if (STATS) {          // reduce over the 8 row lanes, then one LDS atomic per column and wave
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -782,6 +895,10 @@ __global__ __launch_bounds__(AS_THREADS, 1) void head_gemm_astat_kernel(GemmArgs
             }
         }
     }
+    };
+    if (p.addend) { if (p.stats) slices(std::true_type{}, std::true_type{}); else slices(std::true_type{}, std::false_type{}); }
+    else if (p.stats) slices(std::false_type{}, std::true_type{});
+    else slices(std::false_type{}, std::false_type{});
     if (p.stats) {              // every wave's LDS atomics are in: one global atomic per column and workgroup
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         float* dst = p.stats + (long long)(blockIdx.x % p.stats_copies) * 2 * p.N;
@@ -1004,88 +1121,9 @@ __global__ __launch_bounds__(Cfg::THREADS, SINGLE ? 4 : 2) void conv_patch_kerne
 #endif
         return;
     }
-    // bf16 result through the wave's own LDS slice as whole 128-byte row segments; residual addend and BatchNorm statistics as in
-    // head_gemm_kernel's coalesced epilogue
-    char* mine = smem + wid * (TM * 32 * 128);
-    const int c8 = lane & 7, n = n0 + wn * 64 + c8 * 8;
-    auto out_row = [&](int it) -> long long {
-        const int m = m0 + wm * (TM * 32) + it * 8 + (lane >> 3);
-        return (m >= p.M || n >= p.N) ? -1 : m;
-    };
-    uint4v ad[TM * 4];
-    if (p.addend) {
-#pragma unroll
-        for (int it = 0; it < TM * 4; ++it) {
-            const long long orow = out_row(it);
-            ad[it] = orow >= 0 ? *reinterpret_cast<const uint4v*>(p.addend + orow * p.ldc + n) : uint4v{0u, 0u, 0u, 0u};
-        }
-    }
-#pragma unroll
-    for (int ti = 0; ti < TM; ++ti) {
-        const int row = ti * 32 + frow;
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint2 t;
-                t.x = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
-                t.y = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
-                const int unit = tj * 8 + 2 * q + fhalf;
-                *reinterpret_cast<uint2*>(mine + row * 128 + ((unit ^ (row & 15)) << 3)) = t;
-            }
-    }
-    float ssum[8], ssq[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
-    constexpr bool red = RED;                          // fused BatchNorm-backward reduction (GemmBnRed), as in head_gemm_kernel
-    BnRedCols rcols;
-    if (red) bnred_cols(p.br, p.N, n, rcols);
-#pragma unroll
-    for (int it = 0; it < TM * 4; ++it) {
-        if (red && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
-        const int row = it * 8 + (lane >> 3), sw = row & 15;
-        const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
-        const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
-        const long long orow = out_row(it);
-        if (orow < 0) continue;
-        if (p.stats) {
-            const unsigned int w4[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = __uint_as_float(w4[k] << 16), b = __uint_as_float(w4[k] & 0xffff0000u);
-                ssum[2 * k] += a; ssq[2 * k] = fmaf(a, a, ssq[2 * k]);
-                ssum[2 * k + 1] += b; ssq[2 * k + 1] = fmaf(b, b, ssq[2 * k + 1]);
-            }
-        }
-        uint4v o; o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-        if (p.addend) o = add_bf16x8(o, ad[it]);
-        if (red) o = bnred_row(p.br, o, orow * p.ldc + n, rcols, ssum, ssq);
-        *reinterpret_cast<uint4v*>(reinterpret_cast<unsigned short*>(p.C) + orow * p.ldc + n) = o;
-    }
-    if (p.stats || red) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-            for (int o = 8; o < 64; o <<= 1) { ssum[k] += __shfl_xor(ssum[k], o, 64); ssq[k] += __shfl_xor(ssq[k], o, 64); }
-        }
-        float* st = reinterpret_cast<float*>(smem + NW * (TM * 32 * 128));    // [WM][sum | sq][GBN], behind the waves' slices
-        if (lane < 8) {
-            float* row = st + wm * (2 * GBN) + wn * 64 + c8 * 8;
-            *reinterpret_cast<float4v*>(row) = float4v{ssum[0], ssum[1], ssum[2], ssum[3]};
-            *reinterpret_cast<float4v*>(row + 4) = float4v{ssum[4], ssum[5], ssum[6], ssum[7]};
-            *reinterpret_cast<float4v*>(row + GBN) = float4v{ssq[0], ssq[1], ssq[2], ssq[3]};
-            *reinterpret_cast<float4v*>(row + GBN + 4) = float4v{ssq[4], ssq[5], ssq[6], ssq[7]};
-        }
-        __syncthreads();
-        for (int t = tid; t < 2 * GBN; t += Cfg::THREADS) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < Cfg::WM; ++w) v += st[w * (2 * GBN) + t];
-            const int which = t / GBN, col = n0 + (t % GBN);
-            float* dst = red ? p.br.sums : p.stats + (long long)(tile_m % p.stats_copies) * 2 * p.N;
-            if (col < p.N) atomicAdd(dst + which * p.N + col, v);
-        }
-    }
+    // bf16 result through the wave's own LDS slice as whole 128-byte row segments; residual addend, BatchNorm statistics and the fused
+    // BatchNorm-backward reduction as in head_gemm_kernel (plain rows: p.sc is off on this kernel)
+    coalesced_epilogue<TM, Cfg::WM, Cfg::WN, Cfg::THREADS, RED, false>(EPI_ARGS_OF(p), acc, smem, m0, n0, tile_m, wm, wn, wid, lane, tid, 0, 0);
 #ifdef EPI_PATCH_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PATCH_STAMP(4 + step_no);
@@ -1179,13 +1217,15 @@ enum { CFG_SMALL = 0, CFG_TALL = 1, CFG_BIG = 2, CFG_HALF = 3, CFG_QUARTER = 4 }
 struct GemmPlan { int cfg; int nsplit, kps; long long tiles; int pipe; };
 
 // EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
+static int g_tile_force_fwd();
 static int gemm_tile_override() {
     static const int v = [] {
         const char* e = getenv("EPI_GEMM_TILE");
         if (!e) return 0;
         return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
     }();
-    return v;
+    const int f = g_tile_force_fwd();
+    return f == 1 || f == 2 ? f : v;
 }
 
 // Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
@@ -1193,10 +1233,33 @@ static int gemm_tile_override() {
 // EPI_GEMM_PIPE: 0 (default) never, 1 when a workgroup's K loop has >= 6 tiles, 2 always (where a pipelined variant exists).
 // Measured on MI355X (profiles/r02_conv_layers_c_pipelined_ab.txt): the ring removes the DMA-latency stall but these GEMMs are bound by
 // the global->LDS fill itself (32 KB per 128x128x64 tile step, ~23 GB/s per CU = ~6 TB/s over the chip), so it gains nothing here
+static int g_pipe_force_fwd();
 static int gemm_pipe_mode() {
     static const int v = [] { const char* e = getenv("EPI_GEMM_PIPE"); return e ? atoi(e) : 0; }();
-    return v;
+    const int f = g_pipe_force_fwd();
+    return f >= 0 ? f : v;
 }
+
+// tile / pipeline overrides at run time (tuning hook; -1 only queries): tile 0 by shape, 1 small, 2 big, 3 half, 4 quarter; pipe as EPI_GEMM_PIPE
+static int g_store_policy = -1;
+static int gemm_store_policy() {
+    if (g_store_policy < 0) { const char* e = getenv("EPI_GEMM_STORES"); g_store_policy = (e && e[0] == 'n') ? 1 : 0; }       // EPI_GEMM_STORES=nt
+    return g_store_policy;
+}
+extern "C" int epi_gemm_store_policy(int v) {
+    const int before = gemm_store_policy();
+    if (v >= 0) g_store_policy = v;
+    return before;
+}
+static int g_tile_force = 0, g_pipe_force = -1;
+extern "C" int epi_gemm_tune(int tile, int pipe) {
+    if (tile >= 0) g_tile_force = tile;
+    if (pipe >= -1) g_pipe_force = pipe;
+    return g_tile_force;
+}
+
+static int g_tile_force_fwd() { return g_tile_force; }
+static int g_pipe_force_fwd() { return g_pipe_force; }
 
 static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pipe = false) {
     GemmPlan pl;
@@ -1250,7 +1313,8 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
     // smaller tile is taken; 0 = never, the default -- measured per layer and in the step (profiles/r02_conv_layers_g_*): a few layers
     // gain 1 .. 5 us, the stride-2 3x3 layers lose 30 us, the step 7.64 (off) / 7.70 (384) / 7.81 ms (640))
     static const long long fill_env = [] { const char* e = getenv("EPI_GEMM_FILL"); return e ? atoll(e) : 0LL; }();
-    if (cfg == CFG_SMALL && ov == 0 && !out_f32 && fill_env > 0) {
+    if (cfg == CFG_SMALL && !out_f32 && (g_tile_force == 3 || g_tile_force == 4)) cfg = g_tile_force == 3 ? CFG_HALF : CFG_QUARTER;
+    else if (cfg == CFG_SMALL && ov == 0 && !out_f32 && fill_env > 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase;
         const long long t64x128 = (long long)((M + 63) / 64) * ((N + 127) / 128) * nphase;
         if (t128 < fill_env) cfg = t64x128 < fill_env ? CFG_QUARTER : CFG_HALF;
@@ -1297,6 +1361,18 @@ static int launch_gemm_cfg(const GemmArgs& a, const GemmPlan& pl, int nphase, hi
     if (a.ga.enabled) return launch_gemm_mode<OUT_F32, Cfg, A_GATHER, RED>(a, pl, nphase, st);
     return launch_gemm_mode<OUT_F32, Cfg, A_PLAIN, RED>(a, pl, nphase, st);
 }
+
+#ifdef EPI_GEMM_TRACE
+extern "C" int epi_gemm_trace_read(unsigned long long* out, int clear) {
+    const size_t bytes = sizeof(unsigned long long) * epi::GEMM_TRACE_WGS * epi::GEMM_TRACE_SLOTS;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(epi::epi_gemm_trace), bytes) != hipSuccess) return 1;
+    if (clear) {
+        static unsigned long long zeros[epi::GEMM_TRACE_WGS * epi::GEMM_TRACE_SLOTS];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(epi::epi_gemm_trace), zeros, bytes) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef EPI_PATCH_TRACE
 extern "C" int epi_patch_trace_read(unsigned long long* out, int clear) {
@@ -1382,6 +1458,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
                        int* red_done = nullptr) {
     if (stats_done) *stats_done = 0;
     if (red_done) *red_done = 0;
+    a.store_policy = gemm_store_policy();
     // EPI_BN_BWD_FUSE=0: never (A/B measurements)
     static const bool fuse_red = [] { const char* e = getenv("EPI_BN_BWD_FUSE"); return !(e && e[0] == '0'); }();
     GemmBnRed want_red = a.br;

@@ -9,7 +9,10 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libepipolar_hip.so")
+# EPI_LIB_DIR: load libepipolar_hip.so (and the glue extension beside it) from another directory -- same-box A/B runs of two builds
+# (tools/ab_bench.sh); unset: the in-tree build.
+_LIB_DIR = os.environ.get("EPI_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib")
+_LIB_PATH = os.path.join(_LIB_DIR, "libepipolar_hip.so")
 _lib = None
 
 EPI_F32, EPI_BF16, EPI_F64 = 0, 1, 2
@@ -620,7 +623,7 @@ def glue():
         import importlib.util
         from . import build as _build
         load()
-        path = _build.glue_path()
+        path = os.path.join(_LIB_DIR, os.path.basename(_build.glue_path()))
         if not os.path.exists(path):
             raise RuntimeError("epipolarpose_amd: %s is missing -- run `python -m epipolarpose_amd.build` (hipcc + g++, gfx950); "
                                "there is no Python/CPU fallback for the fused BatchNorm" % path)

@@ -1,0 +1,219 @@
+// GEMM laboratory (gfx950): answers, on the GPU box, WHERE the time of the small implicit-GEMM launches goes.
+//
+//   gemm_lab probe            synthetic fill probe with the GEMM's REAL addressing (rows of a power-of-two pitch, every workgroup walking the
+//                             same K offsets in lock step) against padded pitches and against a per-workgroup K rotation
+//   gemm_lab gemm             the real kernels through the C ABI (libepipolar_hip.so): ResNet-50 layer shapes at batch 32, padded pitches,
+//                             tile / pipeline overrides, operands rotating through > 600 MB of buffers (nothing L2- or MALL-resident) or warm
+//   gemm_lab conv             3x3 layers through epi_conv2d_fwd: patch kernel vs generic gather kernel, rotation on / off
+//
+// Every figure is the mean over back-to-back launches on one stream between two HIP events (no host work between launches).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/gemm_lab_bin tools/gemm_lab.hip -Lepipolarpose_amd/_lib -lepipolar_hip -Wl,-rpath,'$ORIGIN/../epipolarpose_amd/_lib'
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <functional>
+#include <algorithm>
+#include "../include/epipolar_hip.h"
+
+extern "C" int epi_gemm_tune(int tile, int pipe);
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        const float v = ((int)(h & 0xffff) - 32768) * (1.0f / 65536.0f);      // [-0.5, 0.5)
+        p[i] = (unsigned short)(__float_as_uint(v) >> 16);
+    }
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// The NT kernel's staging pattern without the MFMAs: workgroup w = (tile_m, tile_n) with tile_n fastest over `tiles_n`; per K step it stages
+// rows [tile_m*128, +128) of A (pitch bytes apart) and rows [tile_n*128, +128) of B, 128 bytes of each row, at byte offset kt*128 of the row;
+// 2 LDS stages, vmcnt(0) + barrier per step (the CfgSmall loop).  rot: M tile t starts at K tile (t * rot) % nk.
+__global__ void __launch_bounds__(256) nt_fill_kernel(const char* __restrict__ A, const char* __restrict__ B, size_t pitch, int nk, int tiles_n, int rot,
+                                                      unsigned int* sink) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware order as in the real kernel: logical id contiguous per XCD
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+    const char* a_row[4];
+    const char* b_row[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (wave * 4 + p) * 8 + (lane >> 3);
+        a_row[p] = A + ((size_t)tile_m * 128 + row) * pitch + (lane & 7) * 16;
+        b_row[p] = B + ((size_t)tile_n * 128 + row) * pitch + (lane & 7) * 16;
+    }
+    int kt = rot ? (int)(((long long)tile_m * rot) % nk) : 0;
+    unsigned int acc = 0;
+    auto issue = [&](int buf) {
+        char* dst = lds + buf * 32768 + wave * 4096;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dma16(a_row[p] + (size_t)kt * 128, dst + p * 1024);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dma16(b_row[p] + (size_t)kt * 128, dst + 16384 + p * 1024);
+        kt = kt + 1 == nk ? 0 : kt + 1;
+    };
+    issue(0);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) issue((t + 1) & 1);
+        acc += *reinterpret_cast<const unsigned int*>(lds + (t & 1) * 32768 + threadIdx.x * 4);
+        __syncthreads();
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static double time_launches(int reps, const std::function<void(int)>& launch) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch(i);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < reps; ++i) launch(i + 3);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms * 1e3 / reps;      // us per launch
+}
+
+static char* g_arena = nullptr;
+static size_t g_arena_bytes = 0;
+static unsigned int* g_sink = nullptr;
+
+static void probe() {
+    printf("# probe: 128x128-tile staging pattern of the NT kernel without MFMAs, 2 stages, 32 KiB per workgroup and K step, nk = 16 K steps\n");
+    printf("# pitch = row pitch in bytes of both operands (A: 8192+ rows, B: 256 rows); wgs = workgroups (tiles_n = 2); rot = K rotation multiplier\n");
+    printf("# fresh = operands rotate through %zu MiB (no L2 / MALL reuse between launches); us per launch | GB/s per busy CU | TB/s\n", g_arena_bytes >> 20);
+    const size_t pitches[] = {512, 1024, 2048, 4096, 2048 + 128, 4096 + 128, 2048 + 256};
+    const int wgss[] = {128, 256, 512};
+    for (size_t pitch : pitches) {
+        for (int wgs : wgss) {
+            const int nk = (int)std::min<size_t>(16, pitch / 128);
+            const size_t a_bytes = (size_t)(wgs / 2) * 128 * pitch, b_bytes = 256 * pitch;
+            const size_t set = (a_bytes + b_bytes + 4095) / 4096 * 4096;
+            const int nset_fresh = (int)std::min<size_t>(64, g_arena_bytes / set);
+            for (int fresh = 0; fresh < 2; ++fresh)
+                for (int rot = 0; rot < 2; ++rot) {
+                    const int nset = fresh ? nset_fresh : 1;
+                    const double us = time_launches(40, [&](int i) {
+                        const char* base = g_arena + (size_t)(i % nset) * set;
+                        hipLaunchKernelGGL(nt_fill_kernel, dim3(wgs), dim3(256), 65536, 0, base, base + a_bytes, pitch, nk, 2, rot, g_sink);
+                    });
+                    const double bytes = (double)wgs * nk * 32768.0;
+                    const int busy = std::min(wgs, 256);
+                    printf("pitch %5zu  wgs %4d  %s  rot %d   %7.2f us   %6.1f GB/s/CU   %5.2f TB/s\n", pitch, wgs, fresh ? "fresh" : "warm ", rot, us,
+                           bytes / us * 1e-3 / busy, bytes / us * 1e-6);
+                }
+        }
+    }
+}
+
+struct Shape { const char* name; int M, N, K; };
+
+static void gemm_battery(bool quick) {
+    const Shape shapes[] = {
+        {"l1.c1  256->64  ", 131072, 64, 256},   {"l1.c3  64->256  ", 131072, 256, 64},   {"l2.c1  512->128 ", 32768, 128, 512},
+        {"l2.c3  128->512 ", 32768, 512, 128},   {"l3.0c1 512->256 ", 32768, 256, 512},   {"l3.c1  1024->256", 8192, 256, 1024},
+        {"l3.c3  256->1024", 8192, 1024, 256},   {"l4.0c1 1024->512", 8192, 512, 1024},   {"l4.c1  2048->512", 2048, 512, 2048},
+        {"l4.c3  512->2048", 2048, 2048, 512},   {"fin.dX 1088->256", 131072, 256, 1088},
+    };
+    printf("# gemm: C[M][N] = A[M][K] * Bt[N][K]^T bf16 through epi_gemm_bf16; us per launch, fresh operands (rotating sets) | warm (one set)\n");
+    printf("# cfg: tile 0 = by shape, 3 half 64x128, 4 quarter 64x64; pipe 2 = 4-stage ring; pad = lda/ldb + 64 elements\n");
+    for (const Shape& s : shapes) {
+        struct Var { const char* name; int tile, pipe, pad; };
+        std::vector<Var> vars = {{"default        ", 0, 0, 0}, {"pad64          ", 0, 0, 64}, {"pipe2          ", 0, 2, 0}};
+        if (!quick) {
+            vars.push_back({"half           ", 3, 0, 0});
+            vars.push_back({"quarter        ", 4, 0, 0});
+        }
+        for (const Var& v : vars) {
+            const int lda = s.K + v.pad, ldb = s.K + v.pad, ldc = s.N;
+            const size_t a_bytes = (size_t)s.M * lda * 2, b_bytes = (size_t)s.N * ldb * 2, c_bytes = (size_t)s.M * ldc * 2;
+            const size_t ws_bytes = epi_gemm_workspace_bytes(s.M, s.N, s.K, 1);
+            const size_t set = ((a_bytes + b_bytes + c_bytes + 4095) / 4096) * 4096;
+            if (ws_bytes + set > g_arena_bytes) { printf("%s %s  (arena too small)\n", s.name, v.name); continue; }
+            char* ws = g_arena;
+            char* sets = g_arena + (ws_bytes + 4095) / 4096 * 4096;
+            const int nfresh = (int)std::max<size_t>(1, std::min<size_t>(48, (g_arena_bytes - (sets - g_arena)) / set));
+            hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (unsigned short*)g_arena, g_arena_bytes / 2, 12345u);     // (results of earlier variants are operands now)
+            epi_gemm_tune(v.tile, v.pipe);
+            double us[2];
+            int rc = 0;
+            for (int fresh = 1; fresh >= 0; --fresh) {
+                const int nset = fresh ? nfresh : 1;
+                us[fresh] = time_launches(fresh ? 40 : 40, [&](int i) {
+                    char* base = sets + (size_t)(i % nset) * set;
+                    rc |= epi_gemm_bf16(base, lda, base + a_bytes, ldb, base + a_bytes + b_bytes, ldc, EPI_BF16, s.M, s.N, s.K, nullptr, ws, ws_bytes, 0);
+                });
+            }
+            const double flop = 2.0 * s.M * s.N * s.K, bytes = (double)a_bytes + b_bytes + c_bytes;
+            printf("%s %s  fresh %7.2f us (%6.1f TF, %5.2f TB/s)   warm %7.2f us (%6.1f TF)   rc %d  sets %d\n", s.name, v.name, us[1], flop / us[1] * 1e-6,
+                   bytes / us[1] * 1e-6, us[0], flop / us[0] * 1e-6, rc, nfresh);
+        }
+        epi_gemm_tune(0, -1);
+    }
+}
+
+static void conv_battery() {
+    struct CS { const char* name; int B, H, W, Cin, Cout, k, stride; };
+    const CS shapes[] = {{"l1.c2 64 3x3 ", 32, 64, 64, 64, 64, 3, 1},   {"l2.c2 128 3x3", 32, 32, 32, 128, 128, 3, 1}, {"l3.c2 256 3x3", 32, 16, 16, 256, 256, 3, 1},
+                         {"l4.c2 512 3x3", 32, 8, 8, 512, 512, 3, 1},  {"l2.0c2 s2    ", 32, 64, 64, 128, 128, 3, 2}, {"l3.0c2 s2    ", 32, 32, 32, 256, 256, 3, 2},
+                         {"l4.0c2 s2    ", 32, 16, 16, 512, 512, 3, 2}, {"l3.ds 1x1 s2 ", 32, 32, 32, 512, 1024, 1, 2}, {"l4.ds 1x1 s2 ", 32, 16, 16, 1024, 2048, 1, 2}};
+    printf("# conv: epi_conv2d_fwd (no BatchNorm sums), fresh operands; patch = conv_patch_kernel (mode 2) / generic gather kernel (mode 0)\n");
+    for (const CS& s : shapes) {
+        const int pad = s.k / 2, Ho = (s.H + 2 * pad - s.k) / s.stride + 1, Wo = (s.W + 2 * pad - s.k) / s.stride + 1;
+        const size_t x_bytes = (size_t)s.B * s.H * s.W * s.Cin * 2, w_bytes = (size_t)s.Cout * s.k * s.k * s.Cin * 2, y_bytes = (size_t)s.B * Ho * Wo * s.Cout * 2;
+        const size_t ws_bytes = epi_conv2d_workspace_bytes(s.B, s.H, s.W, s.Cin, s.Cout, s.k, s.k, s.stride, pad);
+        const size_t set = ((x_bytes + w_bytes + y_bytes + 4095) / 4096) * 4096;
+        char* ws = g_arena;
+        char* sets = g_arena + (ws_bytes + 4095) / 4096 * 4096;
+        const int nfresh = (int)std::max<size_t>(1, std::min<size_t>(48, (g_arena_bytes - (sets - g_arena)) / set));
+        for (int patch = 2; patch >= 0; patch -= 2) {
+            {
+                if (patch == 2 && (s.stride != 1 || s.k != 3)) continue;
+                hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (unsigned short*)g_arena, g_arena_bytes / 2, 12345u);
+                epi_conv3x3_patch_mode(patch);
+                int rc = 0;
+                const double us = time_launches(40, [&](int i) {
+                    char* base = sets + (size_t)(i % nfresh) * set;
+                    rc |= epi_conv2d_fwd(base, base + x_bytes, base + x_bytes + w_bytes, s.B, s.H, s.W, s.Cin, s.Cout, s.k, s.k, s.stride, pad, nullptr, nullptr, ws, ws_bytes, 0);
+                });
+                const double flop = 2.0 * s.B * Ho * Wo * s.Cout * s.k * s.k * s.Cin;
+                printf("%s  %s   %7.2f us (%6.1f TF)  rc %d\n", s.name, patch == 2 ? "patch  " : "generic", us, flop / us * 1e-6, rc);
+            }
+        }
+    }
+    epi_conv3x3_patch_mode(2);
+}
+
+int main(int argc, char** argv) {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("# %s, %d CUs\n", prop.name, prop.multiProcessorCount);
+    g_arena_bytes = (size_t)1536 << 20;
+    CK(hipMalloc(&g_arena, g_arena_bytes));
+    CK(hipMalloc(&g_sink, 64));
+    hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (unsigned short*)g_arena, g_arena_bytes / 2, 12345u);
+    CK(hipDeviceSynchronize());
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    const char* what = argc > 1 ? argv[1] : "all";
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+    if (!strcmp(what, "probe") || !strcmp(what, "all")) probe();
+    if (!strcmp(what, "gemm") || !strcmp(what, "all")) gemm_battery(quick);
+    if (!strcmp(what, "conv") || !strcmp(what, "all")) conv_battery();
+    return 0;
+}
