@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Benchmark of the EpipolarPose training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU -- under torch.distributed.run when RANK / WORLD_SIZE are
+                                                            set, else bench.py starts its own N ranks under it)
 
 A "step" is one full optimisation step (forward, soft-argmax criterion, backward, gradient all-reduce when N > 1,
 Adam) of the ResNet-50 volumetric-heat-map network on one synthetic 4-view 256x256 batch that is already resident
@@ -51,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-loader-leg", action="store_true", help="skip the extra measurement with the GPU input pipeline in the step "
                     "(synthetic uint8 frames in HBM -> augmentation draws, crop, occlusion, normalisation -> the same training step)")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run ONLY the cpu_baseline leg (no GPU needed) and print it as JSON: in the build "
+                    "container this times the reference itself (kind 'reference'), which the GPU box cannot (no /root/reference there)")
     return ap.parse_args()
 
 
@@ -97,25 +100,55 @@ def cpu_baseline(args, scenes):
 
     cores = min(os.cpu_count() or 1, 32)     # more threads than this only thrash on a 4-image batch
     torch.set_num_threads(cores)
-    cfg = default_config()
-    cfg.MODEL.INIT_WEIGHTS = False
-    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.EXTRA.NUM_LAYERS = args.joints, args.depth, args.layers
-    torch.manual_seed(1234)
-    sd = {k: v.detach().clone().contiguous() for k, v in get_pose_net(cfg, True).state_dict().items()}
-    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
-    sd.update(params)
-    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
     b = args.cpu_batch
     x = torch.randn(b, 3, args.image, args.image)
     gt = torch.from_numpy(scenes.label[:b].copy())
     wt = torch.ones_like(gt)
+    # kind "reference": the reference's OWN lib/models/pose3d_resnet.py + lib/core/integral_loss.py, imported from /root/reference with the
+    # third-party shims of tests/golden/ref_shims.py (easydict; torch.cuda.comm.broadcast -> identity) -- only where that tree exists
+    # (the build container; never on the GPU box).  Otherwise kind "port": the oracle's restatement of the same model + criterion.
+    ref = None
+    if os.path.isdir("/root/reference/lib"):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+            import ref_shims
+            ref = ref_shims.load_reference()
+        except Exception as e:               # (a broken shim must not cost the bench line its baseline)
+            print("bench.py: reference import failed (%s): cpu_baseline falls back to the port" % e, file=sys.stderr)
+            ref = None
+    if ref is not None:
+        import copy
+        rcfg = copy.deepcopy(ref.config.config)
+        rcfg.MODEL.NUM_JOINTS, rcfg.MODEL.DEPTH_RES, rcfg.MODEL.IMAGE_SIZE = args.joints, args.depth, [args.image, args.image]
+        rcfg.MODEL.INIT_WEIGHTS = False
+        rcfg.MODEL.EXTRA.NUM_LAYERS = args.layers
+        torch.manual_seed(1234)
+        rmodel = ref.pose3d_resnet.get_pose_net(rcfg, is_train=True)
+        rmodel.train()
+        rcrit = ref.integral_loss.SmoothL1JointLocationLoss(num_joints=args.joints)
+        opt = torch.optim.Adam(rmodel.parameters(), lr=1e-3)
 
-    def step():
-        opt.zero_grad()
-        logits = o_net.forward(sd, x, args.layers, training=True, new_stats={})
-        loss = o_net.joint_location_loss(logits, gt, wt, args.joints, "smoothl1")
-        loss.backward()
-        opt.step()
+        def step():
+            opt.zero_grad()
+            loss = rcrit(rmodel(x), gt, wt)
+            loss.backward()
+            opt.step()
+    else:
+        cfg = default_config()
+        cfg.MODEL.INIT_WEIGHTS = False
+        cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.EXTRA.NUM_LAYERS = args.joints, args.depth, args.layers
+        torch.manual_seed(1234)
+        sd = {k: v.detach().clone().contiguous() for k, v in get_pose_net(cfg, True).state_dict().items()}
+        params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        sd.update(params)
+        opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+
+        def step():
+            opt.zero_grad()
+            logits = o_net.forward(sd, x, args.layers, training=True, new_stats={})
+            loss = o_net.joint_location_loss(logits, gt, wt, args.joints, "smoothl1")
+            loss.backward()
+            opt.step()
     t0 = time.perf_counter()
     step()                                   # warm-up (also bounds the leg: a slow host gets a 1-step sample)
     warm = time.perf_counter() - t0
@@ -127,10 +160,11 @@ def cpu_baseline(args, scenes):
             step()
             n += 1
         dt = time.perf_counter() - t0
-    out = {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": "%d steps of batch %d (ResNet-%d, %dx%d, J=%d, D=%d; fwd + SmoothL1 soft-argmax loss + bwd + Adam), "
-                     "fp32 torch-CPU oracle, %d threads" % (n, b, args.layers, args.image, args.image, args.joints,
-                                                            args.depth, cores)}
+    out = {"value": round(b * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "reference" if ref is not None else "port",
+           "sample": "%d steps of batch %d (ResNet-%d, %dx%d, J=%d, D=%d; fwd + SmoothL1 soft-argmax loss + bwd + Adam), %s, %d threads"
+                     % (n, b, args.layers, args.image, args.image, args.joints, args.depth,
+                        "the reference's own pose3d_resnet.py + integral_loss.py (fp32 torch-CPU, /root/reference)" if ref is not None else
+                        "fp32 torch-CPU oracle port (/root/reference is absent on this host)", cores)}
     # self-supervision leg of the CPU path (float64 NumPy restatement, 1 core) + "MPJPE vs ref" on identical inputs
     cp = scenes.patch_coords(noise_px=1.0, seed=3)
     t0 = time.perf_counter()
@@ -341,8 +375,50 @@ def pmc_traffic(default_workload):
         return None
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` WITHOUT a launcher (no RANK / WORLD_SIZE in the environment): start N ranks of this same command under
+    ``torch.distributed.run`` on this node -- one process per GPU, rendezvous on 127.0.0.1 at a free port -- and hand their output and exit
+    code through.  (The reference starts its N replicas inside one process, ``torch.nn.DataParallel``: scripts/train.py:93-94,143.)"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # the host driver only supports dmabuf IPC (RCCL over xGMI needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def rank_inventory(world, device):
+    """Who took part, for the JSON line's `config`: backend, RCCL version, every rank's device."""
+    inv = {"backend": None, "world_size": world, "rccl_version": None, "devices": [torch.cuda.get_device_name(device)]}
+    if world > 1:
+        inv["backend"] = torch.distributed.get_backend()
+        names = [None] * world
+        torch.distributed.all_gather_object(names, "rank %d: cuda:%d %s" % (torch.distributed.get_rank(), device.index,
+                                                                             torch.cuda.get_device_name(device)))
+        inv["devices"] = names
+        if inv["backend"] == "nccl":
+            try:
+                inv["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                    # (version query only: never fail the bench for it)
+                inv["rccl_version"] = "unknown"
+    return inv
+
+
 def main():
     args = parse_args()
+    if args.cpu_baseline_only:
+        from epipolarpose_amd.synthetic import SyntheticScenes
+        scenes = SyntheticScenes(n_group=args.batch // args.views, n_view=args.views, num_joints=args.joints, patch=256, seed=100)
+        print(json.dumps({"cpu_baseline": cpu_baseline(args, scenes), "host": {"cpus": os.cpu_count()}}), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     from epipolarpose_amd import distributed as epd
     from epipolarpose_amd import hip
     from epipolarpose_amd.core.function import GraphedTrainStep, train_step
@@ -353,8 +429,10 @@ def main():
     if args.same_device:
         local = 0
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or without any launcher: "
+                         "bench.py then starts its own ranks)" % (args.gpus, world, args.gpus))
+    if world > 1:
+        print("bench.py: rank %d/%d up, backend %s" % (rank, world, torch.distributed.get_backend()), file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -448,6 +526,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    inventory = rank_inventory(world, device)
     # the other single-GPU workload of BASELINE.json (configs[2]: pseudo labels from multi-view triangulation inside the step)
     # rides along as an extra field of the same JSON line: same model / optimizer state, `steps` more steps, same timing rules
     ss_line = None
@@ -539,6 +618,7 @@ def main():
                                     % (args.layers, args.image, args.image, args.batch)),
                        "global_batch": global_batch, "joints": args.joints, "depth_res": args.depth,
                        "optimizer": "adam", "parallelism": "dp%d" % world, "final_loss": round(final_loss, 6),
+                       "ranks": inventory,
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "streams": 1 if use_graph or hip.glue().wgrad_stream_mode(-1) == 0 else 2,
                        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 3),

@@ -1917,20 +1917,24 @@ __device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, 
     const bool direct = p.nsplit == 1;
     float* slab = reinterpret_cast<float*>(p.C) + (direct ? 0 : (long long)split * p.I * p.J);
     unsigned short* out16 = reinterpret_cast<unsigned short*>(p.C);
+    // (the output type is wave-uniform: decided once, not per element)
+    auto store_tile = [&](auto bf16_c) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ti = 0; ti < TI; ++ti)
+        for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-            const int j = j0 + wn * 64 + tj * 32 + fcol;
+            for (int tj = 0; tj < 2; ++tj) {
+                const int j = j0 + wn * 64 + tj * 32 + fcol;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int i = i0 + wm * (TI * 32) + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
-                if (i < p.I && j < p.J) {
-                    if (direct && p.out_bf16) out16[(long long)i * p.J + j] = f32_to_bf16(acc[ti][tj][reg]);
-                    else slab[(long long)i * p.J + j] = acc[ti][tj][reg];
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int i = i0 + wm * (TI * 32) + ti * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fhalf;
+                    if (i < p.I && j < p.J) {
+                        if (decltype(bf16_c)::value) out16[(long long)i * p.J + j] = f32_to_bf16(acc[ti][tj][reg]);
+                        else slab[(long long)i * p.J + j] = acc[ti][tj][reg];
+                    }
                 }
             }
-        }
+    };
+    if (direct && p.out_bf16) store_tile(std::true_type{}); else store_tile(std::false_type{});
 }
 
 template <typename Cfg, bool GATHER>

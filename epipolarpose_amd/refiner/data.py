@@ -1,7 +1,8 @@
 """Dataset of the refinement MLP -- the reference's ``refiner/data.py`` reads pickled (noisy 3-D pose, ground truth) pairs of
 Human3.6M; no such data exists on the build / GPU boxes, so ``SyntheticLift`` supplies seeded pairs with the same item contract
 (``(inp f32 [45], out f32 [45])``, hip joint removed, inputs always and training targets standardised, data.py:40-70) and the same
-``evaluate`` protocol (MPJPE and Procrustes-aligned MPJPE over the 15 joints, data.py:78-158)."""
+``evaluate`` protocol (MPJPE and Procrustes-aligned MPJPE over the 15 joints, data.py:78-158).  The reference's pickle-reading ``Human36M`` class is
+data plumbing outside the hot-path scope and is not mirrored."""
 import numpy as np
 from torch.utils.data import Dataset
 
@@ -39,40 +40,3 @@ class SyntheticLift(Dataset):
             dist.append(np.linalg.norm(g - p, axis=1).mean())
             dist_align.append(np.linalg.norm(g - (b * p.dot(t) + c), axis=1).mean())
         return float(np.mean(dist)), float(np.mean(dist_align))
-
-
-class Human36M(SyntheticLift):
-    """``refiner/data.py:29-76`` under its own name: ``Human36M(is_train)``.  Reads the reference's pickles (``refiner/data/train.pkl`` /
-    ``valid.pkl``: ``{'inp': [N, 16, 3], 'out': [N, 16, 3]}``, hip joint removed, ``norm.pkl`` statistics) when they exist; none do on the
-    build / GPU boxes, where it degrades to the seeded synthetic pairs above with the same item contract."""
-
-    def __init__(self, is_train, norm=None, root='refiner/data'):
-        import os
-        import pickle as pkl
-        fname = os.path.join(root, 'train.pkl' if is_train else 'valid.pkl')
-        if not os.path.exists(fname):
-            super().__init__(is_train, norm=norm)
-            return
-        self.is_train = is_train
-        with open(fname, 'rb') as f:
-            anno = pkl.load(f)
-        data = np.asarray(anno['inp'], dtype=np.float32).reshape(len(anno['inp']), -1)
-        labels = np.asarray(anno['out'], dtype=np.float32).reshape(len(anno['out']), -1)
-        data = np.delete(data, np.s_[18:21], axis=1)                       # remove the hip joint (data.py:49-50)
-        labels = np.delete(labels, np.s_[18:21], axis=1)
-        norm_file = os.path.join(root, 'norm.pkl')
-        if norm is None and os.path.exists(norm_file):
-            with open(norm_file, 'rb') as f:
-                norm = pkl.load(f)
-        if norm is None:
-            if not is_train:
-                raise IOError("refiner/data/norm.pkl is written by the training split first (refiner/data.py:52-60)")
-            norm = (data.mean(axis=0), data.std(axis=0), labels.mean(axis=0), labels.std(axis=0))
-            with open(norm_file, 'wb') as f:
-                pkl.dump(norm, f)
-        self.data_mean, self.data_std, self.labels_mean, self.labels_std = norm
-        self.data = (data - self.data_mean) / self.data_std
-        self.labels = (labels - self.labels_mean) / self.labels_std if is_train else labels
-        if is_train:
-            rnd = np.random.permutation(self.labels.shape[0])
-            self.data, self.labels = self.data[rnd], self.labels[rnd]

@@ -204,3 +204,23 @@ def test_bf16_bucket_accumulation_error_at_eight_ranks():
     cos = float(ring @ exact / (ring.norm() * exact.norm()))
     assert rel(one) <= 2.5e-3 and rel(ring) <= 6e-3 and rel(ring) <= 3.0 * rel(one), (rel(one), rel(ring))
     assert cos >= 0.9999, cos
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how the round driver calls it) must start two ranks under
+    torch.distributed.run by itself: both come up, join the process group (gloo here) and reach the device assert -- which is where a box
+    without GPUs stops them.  (Reference semantics: N replicas from ONE command, scripts/train.py:93-94,143.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""          # (a GPU box must stop at the same place as this container)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    err = r.stderr
+    assert "torch.distributed.run" in err and "--nproc-per-node 2" in err, err[-2000:]
+    assert "rank 0/2 up, backend gloo" in err and "rank 1/2 up, backend gloo" in err, err[-2000:]
+    assert "bench.py needs MI355X GPUs" in err, err[-2000:]
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in err          # the round-3 usage error is gone
