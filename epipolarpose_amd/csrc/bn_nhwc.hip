@@ -30,9 +30,11 @@ constexpr int BN_RLANES = BN_THREADS / 8;   // 32 row lanes
 
 // Storage type T: unsigned short = bf16 (the training path) or float (the fp32-grade verification mode, models/precise.py: the same
 // kernels, 16 bytes = 4 channels per lane instead of 8).  V = channels per lane, SLAB = 8 V channels per workgroup column.
+// det_part (deterministic mode, csrc/capi.hip): [row blocks][2C] partial sums, one plain store per channel and workgroup instead of the atomic;
+// ordered_sum_kernel then adds the row blocks in index order
 template <int V>
 __device__ __forceinline__ void slab_reduce_and_add(const float (&s)[V], const float (&q)[V], int g, int rl, int slab, int C,
-                                                    float* __restrict__ sums, float* red /* [32][16 V] */) {
+                                                    float* __restrict__ sums, float* red /* [32][16 V] */, float* __restrict__ det_part = nullptr) {
     constexpr int SLAB = 8 * V;
 #pragma unroll
     for (int k = 0; k < V; ++k) { red[rl * (2 * SLAB) + g * V + k] = s[k]; red[rl * (2 * SLAB) + SLAB + g * V + k] = q[k]; }
@@ -42,15 +44,27 @@ __device__ __forceinline__ void slab_reduce_and_add(const float (&s)[V], const f
 #pragma unroll 8
         for (int l = 0; l < BN_RLANES; ++l) t += red[l * (2 * SLAB) + threadIdx.x];
         const int which = threadIdx.x / SLAB, ch = slab * SLAB + (threadIdx.x % SLAB);
-        if (ch < C) atomicAdd(sums + which * C + ch, t);
+        if (ch < C) {
+            if (det_part) det_part[(long long)blockIdx.y * 2 * C + which * C + ch] = t;
+            else atomicAdd(sums + which * C + ch, t);
+        }
     }
+}
+
+// dst[i] += part[0][i] + part[1][i] + ... (index order), i < n
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t = 0.f;
+    for (int k = 0; k < nblocks; ++k) t += part[(long long)k * n + i];
+    dst[i] += t;
 }
 
 // sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)
 // (ncopies accumulator copies [ncopies][2C], row block b adds into copy b % ncopies: fewer atomics per 128-byte line; 1 = plain [2C])
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long long R, int C,
-                                                              int rows_per_wg, float* __restrict__ sums, int ncopies) {
+                                                              int rows_per_wg, float* __restrict__ sums, int ncopies, float* __restrict__ det_part) {
     constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
     __shared__ float red[BN_RLANES * 2 * SLAB];
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
             for (int k = 0; k < V; ++k) { s[k] += v[k]; q[k] = fmaf(v[k], v[k], q[k]); }
         }
     }
-    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums + (long long)(blockIdx.y % ncopies) * 2 * C, red);
+    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums + (long long)(blockIdx.y % ncopies) * 2 * C, red, det_part);
 }
 
 // Per-channel affine of one BatchNorm call, derived inside the apply kernel.
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
                                                                    const T* __restrict__ y, long long R, int C,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                   int rows_per_wg, float* __restrict__ sums) {
+                                                                   int rows_per_wg, float* __restrict__ sums, float* __restrict__ det_part) {
     constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
     __shared__ float red[BN_RLANES * 2 * SLAB];
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
             accum(xv, gv, yv);
         }
     }
-    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums, red);
+    slab_reduce_and_add<V>(s, q, g, rl, slab, C, sums, red, det_part);
 }
 
 // dx = gamma*rstd * (dz - dbeta/R - xhat * dgamma/R);  dres = dz (residual branch gradient) when requested
@@ -474,6 +488,24 @@ static inline int bn_2d_mode() {
 
 using namespace epi;
 
+// One statistics pass: sums_ws [ncopies][2C] += per-channel (sum, sum of squares) of x.  Deterministic mode: per-row-block partials into the
+// library's scratch, then added in index order into copy 0.
+template <typename T>
+static int launch_stats(const T* x, long long R, int C, float* sums, int ncopies, hipStream_t st, bool column_sums = false) {
+    int rpw = 0;
+    dim3 rgrid;
+    reduce_blocking(R, C, &rpw, &rgrid, 8 * Elem<T>::VEC);
+    float* part = nullptr;
+    if (deterministic()) {
+        part = det_scratch((size_t)rgrid.y * 2 * C, column_sums);
+        if (!part) return EPI_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, x, R, C, rpw, sums, ncopies, part);
+    if (part) hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, part, (int)rgrid.y, 2 * C, sums);
+    EPI_CHECK_LAUNCH();
+    return EPI_OK;
+}
+
 // The forward statistics accumulator sums_ws is [epi_bn_sum_copies(C)][2C]: producers (the statistics kernel's row blocks, a
 // convolution epilogue's M tiles) spread their atomics over the copies; the apply kernel adds the copies up.  One copy for wide
 // layers (few rows, so few producers -- and every apply workgroup reads all of them).
@@ -591,11 +623,8 @@ static int bn_act_fwd_impl(const void* x, const void* residual, long long R, int
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (training && training != 2) {             // 2: the producer already accumulated the batch sums into sums_ws
-        int rpw = 0;
-        dim3 rgrid;
-        reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
-        hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)x, R, C, rpw, sums_ws, epi_bn_sum_copies(C));
-        EPI_CHECK_LAUNCH();
+        const int rc = launch_stats<T>((const T*)x, R, C, sums_ws, epi_bn_sum_copies(C), st);
+        if (rc != EPI_OK) return rc;
     }
     const long long nvec = R * (C / V);
     const dim3 grid(stream_grid(nvec)), block(BN_THREADS);
@@ -663,14 +692,10 @@ extern "C" int epi_bn_act_fwd_dual(const void* x, const void* x_proj, long long 
     }
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    int rpw = 0;
-    dim3 rgrid;
-    reduce_blocking(R, C, &rpw, &rgrid, 8 * V);
     if (training == 1)            // (2: both producers already accumulated their batch sums)
         for (int k = 0; k < 2; ++k) {
-            hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)(k ? x_proj : x), R, C, rpw, (k ? proj_bn : main_bn)->sums_ws,
-                               epi_bn_sum_copies(C));
-            EPI_CHECK_LAUNCH();
+            const int rc = launch_stats<T>((const T*)(k ? x_proj : x), R, C, (k ? proj_bn : main_bn)->sums_ws, epi_bn_sum_copies(C), st);
+            if (rc != EPI_OK) return rc;
         }
     BnAffine a, d;
     bn_affine_from(*main_bn, R, C, training, eps, momentum, &a);
@@ -709,11 +734,17 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long lo
     const T *dys = (const T*)dy, *xs = (const T*)x, *ys = (const T*)y;
     const float *sc = scale_shift, *sh = scale_shift + C;
     if (!reduced) {
-#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma)
+        float* part = nullptr;
+        if (deterministic()) {           // per-row-block partial sums, added in index order (csrc/capi.hip)
+            part = det_scratch((size_t)rgrid.y * 2 * C);
+            if (!part) return EPI_ERR_WORKSPACE;
+        }
+#define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma, part)
         if (mask == BN_MASK_NONE) EPI_BN_RED(BN_MASK_NONE);
         else if (mask == BN_MASK_FROM_X) EPI_BN_RED(BN_MASK_FROM_X);
         else EPI_BN_RED(BN_MASK_FROM_Y);
 #undef EPI_BN_RED
+        if (part) hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, part, (int)rgrid.y, 2 * C, dbeta_dgamma);
         EPI_CHECK_LAUNCH();
     }
     const long long nvec = R * (C / V);
@@ -763,13 +794,7 @@ template <typename T>
 static int column_sums_impl(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
     if (!x || !sums) return EPI_ERR_INVALID_ARGUMENT;
     if (!bn_shape_ok(R, C)) return EPI_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    int rpw = 0;
-    dim3 rgrid;
-    reduce_blocking(R, C, &rpw, &rgrid, 8 * Elem<T>::VEC);
-    hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, (const T*)x, R, C, rpw, sums, 1);
-    EPI_CHECK_LAUNCH();
-    return EPI_OK;
+    return launch_stats<T>((const T*)x, R, C, sums, 1, (hipStream_t)stream, true);
 }
 extern "C" int epi_column_sums_bf16(const void* x, long long R, int C, float* sums, epi_stream_t stream) {
     return column_sums_impl<unsigned short>(x, R, C, sums, stream);

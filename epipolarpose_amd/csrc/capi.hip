@@ -13,3 +13,28 @@ extern "C" const char* epi_status_string(int status) {
         default: return "unknown status";
     }
 }
+
+// ---- deterministic mode: the reference's CUDNN.DETERMINISTIC key (lib/core/config.py:21, scripts/train.py:80) ----
+// Off (default): BatchNorm batch sums and the BatchNorm-backward sums are accumulated with fp32 atomics from GEMM epilogues / reduction workgroups
+// in whatever order the workgroups finish -- two runs of the same step differ in the last bits, and a flipped bf16 rounding early in the network
+// moves the loss of a random-weight network by up to 0.6 %.
+// On: (a) no GEMM epilogue accumulates column sums (launch_gemm withholds the fused statistics / reduction and reports *_done = 0, so the callers
+// run their own passes); (b) those passes write one partial sum per workgroup into the scratch below and a second, single-pass kernel adds them in
+// index order.  Costs ~60 extra launches per ResNet-50 step.  The scratch has two halves: one for the BatchNorm passes, which the callers must keep
+// on ONE stream (the training path does: they are links of the forward / backward chain), one for epi_column_sums_* (the final layer's bias
+// gradient, which the training path runs on its weight-gradient stream).  Bit-identical reruns: tests/test_hip_deterministic.py.
+namespace epi {
+static int g_det = 0;
+static float* g_det_buf = nullptr;
+static const size_t DET_FLOATS = (size_t)4 << 20;       // 16 MB per half: 1024 row blocks x 2 x 2048 channels
+bool deterministic() { return g_det != 0; }
+float* det_scratch(size_t floats, bool column_sums) { return (g_det && floats <= DET_FLOATS) ? g_det_buf + (column_sums ? DET_FLOATS : 0) : nullptr; }
+}  // namespace epi
+
+extern "C" int epi_set_deterministic(int on) {
+    const int before = epi::g_det;
+    if (on < 0) return before;              // query
+    if (on && !epi::g_det_buf && hipMalloc(&epi::g_det_buf, 2 * epi::DET_FLOATS * sizeof(float)) != hipSuccess) return -1;
+    epi::g_det = on ? 1 : 0;
+    return before;
+}

@@ -1244,7 +1244,9 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
                 check(epi_stem7x7s2_unpack_weight_grad(dwp.data_ptr<float>(), Cout, w_cl ? 1 : 0, dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, st),
                       "epi_stem7x7s2_unpack_weight_grad");
             };
-            if (side_mode() != 0 && first_gradient_of_pass(sv.w) && gradient_consumed_after_backward(sv.w)) {
+            const bool first_use = first_gradient_of_pass(sv.w);
+            if (!first_use) flush_pending_reduces();                  // (the model used twice in one graph: the first gradient must be final before the engine adds this one)
+            if (side_mode() != 0 && first_use && gradient_consumed_after_backward(sv.w)) {
                 g_side.jobs.push_back(SideStream::Job{sv.x, g.dx, dw, [=](epi_stream_t st) {
                     launch(st, side_workspace(ws_bytes, s2d));
                     g_side.keep.push_back(dwp);
@@ -1499,7 +1501,11 @@ struct DeconvBnAct : public torch::autograd::Function<DeconvBnAct> {
             dw = at::empty_strided({Cin, Cout, 4, 4}, {16 * (int64_t)Cout, 1, 4 * (int64_t)Cout, (int64_t)Cout},
                                    x.options().dtype(sv.w_f32 ? at::kFloat : at::kBFloat16));
             const size_t slab_bytes = epi_gemm_tn_workspace_bytes(B * H * W, Cin, Cout, 16);
-            const bool on_side = side_mode() != 0 && gradient_consumed_after_backward(sv.w);
+            // (a layer used twice in one graph: the engine adds the second gradient to the first on the main stream, so the first must be final
+            //  by then -- everything pending is joined and this one stays on the main stream, as in stage_backward)
+            const bool first_use = first_gradient_of_pass(sv.w);
+            if (!first_use) flush_pending_reduces();
+            const bool on_side = side_mode() != 0 && first_use && gradient_consumed_after_backward(sv.w);
             const Tensor xin = x, dyin = g.dx, dwout = dw;
             const bool w_f32 = sv.w_f32;
             auto launch = [=](epi_stream_t st, Tensor& ws) {
@@ -1594,7 +1600,9 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
             Tensor sums = at::zeros({2 * (int64_t)Cout}, x.options().dtype(at::kFloat));
             db = sums.slice(0, 0, Cout);
             const Tensor bias_leaf = saved[3];
-            if (side_mode() != 0 && bias_leaf.defined() && gradient_consumed_after_backward(bias_leaf)) {
+            const bool first_bias = bias_leaf.defined() && first_gradient_of_pass(bias_leaf);
+            if (bias_leaf.defined() && !first_bias) flush_pending_reduces();          // (second use of the layer in this graph, see the weight below)
+            if (side_mode() != 0 && first_bias && gradient_consumed_after_backward(bias_leaf)) {
                 const Tensor dyin = dy, out = sums;
                 g_side.jobs.push_back(SideStream::Job{dy, sums, db, [=](epi_stream_t st) {
                     check(epi_column_sums_bf16(dyin.data_ptr(), (long long)M, Cout, out.data_ptr<float>(), st), "epi_column_sums_bf16");
@@ -1608,7 +1616,11 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
             // the weight gradient of a 1x1 convolution: dW[co][ci] = sum_m dy[m][co] x[m][ci] (bf16 or fp32 result, split sums deferrable)
             dw = at::empty({Cout, Cin, 1, 1}, x.options().dtype(w_f32 ? at::kFloat : at::kBFloat16).memory_format(at::MemoryFormat::Contiguous));
             const size_t slab_bytes = epi_gemm_tn_workspace_bytes(M, Cout, Cin, 1);
-            const bool after_pass = gradient_consumed_after_backward(w);
+            // a second use of this layer in one graph (the model called on two inputs before one backward): w.grad() is still undefined, yet the
+            // engine adds this gradient to the first one on the main stream -- join what is pending, no second stream, no deferred sum
+            const bool first_use = first_gradient_of_pass(w);
+            if (!first_use) flush_pending_reduces();
+            const bool after_pass = first_use && gradient_consumed_after_backward(w);
             const bool may_defer = slab_bytes && defer_enabled() && after_pass;
             void* slabs = may_defer ? pending_slab_alloc(slab_bytes, x) : nullptr;
             const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);

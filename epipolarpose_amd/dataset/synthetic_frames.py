@@ -167,8 +167,9 @@ class FramePatchLoader:
         meta = {k2: torch.from_numpy(np.ascontiguousarray(sc.meta[k2][idx])) for k2 in ("center_x", "center_y", "width", "height", "R", "T", "f", "c",
                                                                                            "projection_matrix")}
         meta["scale"], meta["rot"] = torch.from_numpy(p["scale"].copy()), torch.from_numpy(p["rot"].copy())
-        # (label / weight are views of the slot's device buffer: valid until the slot comes round again, four batches later)
-        return data, views["label"], views["weight"], meta
+        # label / weight are CLONES (a few KB): the views into the slot's device buffer would be overwritten when the slot comes round again four
+        # batches later, silently corrupting whatever a caller kept (a validation loop collecting labels)
+        return data, views["label"].clone(), views["weight"].clone(), meta
 
     def __iter__(self):
         order = np.arange(self.frames.n_group)

@@ -132,9 +132,10 @@ class BucketedGradSync:
         leaves its empty holder on the tensor, which the glue would otherwise read as "somebody consumes this gradient inside the pass"
         and keep the weight gradient on the main stream, one launch per layer -- measured 8.0 instead of 7.05 ms/step on the forced
         bucket path before this declaration existed."""
+        self._declared_free = list(params)
         if any(p.is_cuda for _, plist, _ in self.buckets for p in plist):
             from . import hip
-            hip.glue().declare_hook_free(list(params))
+            hip.glue().declare_hook_free(self._declared_free)
 
     def _make_bucket(self, plist, grad_dtype):
         total = sum(p.numel() for p in plist)
@@ -255,6 +256,19 @@ class BucketedGradSync:
         self._handles = []
         self._launched = set()
         self._deferred = []
+        self._recheck_hook_free()
+
+    def _recheck_hook_free(self):
+        """A parameter declared hook-free must STAY hook-free: if somebody registered a post-accumulate hook on one of them since (an
+        optimizer-in-backward, a user hook), the glue would still leave its gradient on the second stream / unreduced and that hook would read
+        an unfinished tensor.  Checked before every backward pass (a dict-length test per parameter); a parameter that grew a live hook is
+        withdrawn from the declaration and takes the safe path from this pass on."""
+        declared = getattr(self, "_declared_free", None)
+        if not declared:
+            return
+        still = [p for p in declared if not getattr(p, "_post_accumulate_grad_hooks", None)]
+        if len(still) != len(declared):
+            self._declare_hook_free(still)
 
     def finish(self):
         """Wait for the in-flight all-reduces; gradients become the mean over ranks.  Call between backward() and

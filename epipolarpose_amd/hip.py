@@ -77,6 +77,9 @@ _SIGNATURES = {
     "epi_wgrad_group": (_i, [_vp, _i, _vp, _sz, _vp, _vp]),
     "epi_bn_sum_copies": (_i, [_i]),
     "epi_conv3x3_patch_mode": (_i, [_i]),
+    "epi_gemm_tune": (_i, [_i, _i]),
+    "epi_gemm_store_policy": (_i, [_i]),
+    "epi_set_deterministic": (_i, [_i]),
     "epi_bn_act_fwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _i, _i, _vp, _vp, _vp, _vp,
                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "epi_bn_act_bwd": (_i, [_vp, _vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -135,7 +138,11 @@ def load():
                                "(there is no CPU fallback)" % _LIB_PATH)
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                if os.environ.get("EPI_LIB_DIR"):      # an older build loaded for an A/B run: entry points added since are simply absent
+                    continue
+                raise RuntimeError("%s does not export %s: stale build -- run `python -m epipolarpose_amd.build`" % (_LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
         _lib = lib
@@ -836,6 +843,22 @@ def conv3x3_patch_mode(mode=-1):
     """Kernel choice for 3x3 / stride-1 convolutions (0 generic gather kernel, 1 patch kernel where it needs no channel split, 2 patch
     kernel always -- the default); sets ``mode`` when 0 .. 2 and returns the previous mode (epipolar_hip.h)."""
     return int(load().epi_conv3x3_patch_mode(int(mode)))
+
+
+def set_deterministic(on=True):
+    """The reference's ``CUDNN.DETERMINISTIC`` (lib/core/config.py:21; scripts/train.py:80 hands it to ``torch.backends.cudnn.deterministic``):
+    every cross-workgroup sum of the library in a fixed order -- BatchNorm statistics and the BatchNorm-backward sums by their own passes with
+    ordered partial sums instead of fp32 atomics from the GEMM epilogues (``epi_set_deterministic``, epipolar_hip.h).  The weight gradients stay
+    on their second stream (their values do not depend on timing).  Two runs of the same step are then bit-identical
+    (tests/test_hip_deterministic.py).  Returns the previous setting."""
+    before = int(load().epi_set_deterministic(1 if on else 0))
+    if before < 0:
+        raise RuntimeError("epi_set_deterministic: could not allocate the partial-sum scratch")
+    return bool(before)
+
+
+def is_deterministic():
+    return bool(load().epi_set_deterministic(-1))
 
 
 def bn_sum_copies(channels):

@@ -43,6 +43,14 @@ enum epi_loss_kind { EPI_LOSS_L1 = 0, EPI_LOSS_L2 = 1, EPI_LOSS_SMOOTH_L1 = 2 };
 const char* epi_version(void);
 const char* epi_status_string(int status);
 
+/* Deterministic mode -- the reference's CUDNN.DETERMINISTIC key (lib/core/config.py:21, scripts/train.py:80: torch.backends.cudnn.deterministic).
+ * on = 1: every cross-workgroup floating-point sum of the library runs in a fixed order (no fp32 atomics): the GEMM launches withhold their fused
+ * BatchNorm statistics / BatchNorm-backward sums (*_done = 0: the caller's own pass runs), and those passes write per-workgroup partial sums to a
+ * library-owned 32 MB scratch (allocated by the first enabling call) that a second kernel adds in index order.  The caller must keep all BatchNorm
+ * passes (epi_bn_act_*) on ONE stream while it is on, and all epi_column_sums_* calls on one stream (they have their own half of the scratch).  on = 0: atomics (default).  on < 0: query.  Returns the previous setting (-1: the
+ * scratch could not be allocated).  Bit-identical reruns of a training step: tests/test_hip_deterministic.py. */
+int epi_set_deterministic(int on);
+
 /* ------------------------------------------------------------------------------------------------
  * Integral regression (soft-argmax) -- replaces lib/core/integral_loss.py:49-86
  * (softmax_integral_tensor + generate_3d_integral_preds_tensor): global softmax over each joint's
@@ -322,6 +330,12 @@ size_t epi_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int KH
  * chunks; 2 (default; EPI_CONV3X3_PATCH overrides): always.  Sets the mode (other values only query) and returns the previous one.  Same results
  * either way (fp32 accumulation over the same products; the summation order differs). */
 int epi_conv3x3_patch_mode(int mode);
+/* Tuning hooks of the NT implicit-GEMM launches (tools/gemm_lab.hip, tools/gemm_trace.hip; results never depend on them beyond fp32 summation
+ * order).  epi_gemm_tune: tile 0 by shape | 1 128x128 | 2 256x256 | 3 64x128 | 4 64x64 (negative: keep), pipe -1 per EPI_GEMM_PIPE | 0 two LDS
+ * stages | 1 ring when the K loop has >= 6 tiles | 2 ring always (< -1: keep); returns the tile override in force.  epi_gemm_store_policy: result
+ * stores of the coalesced epilogue 0 plain | 1 non-temporal (negative: query; EPI_GEMM_STORES=nt sets the default); returns the previous policy. */
+int epi_gemm_tune(int tile, int pipe);
+int epi_gemm_store_policy(int policy);
 /* bn_sums [epi_bn_sum_copies(Cout)][2*Cout] f32 or NULL: the accumulator of the BatchNorm that follows (sums_ws of epi_bn_act_fwd, ZERO on entry).  When
  * the launch can do it (unsplit result), the GEMM epilogue adds the per-channel (sum, sum of squares) of the bf16 outputs and sets
  * *bn_sums_done = 1 -- pass training = 2 to epi_bn_act_fwd then (its statistics pass is skipped); otherwise *bn_sums_done = 0 and

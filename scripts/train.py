@@ -83,6 +83,9 @@ def main(argv=None):
 
     torch.backends.cudnn.benchmark = config.CUDNN.BENCHMARK              # MIOpen find mode
     torch.backends.cudnn.deterministic = config.CUDNN.DETERMINISTIC
+    if config.CUDNN.DETERMINISTIC and torch.cuda.is_available():
+        from epipolarpose_amd import hip as _hip
+        _hip.set_deterministic(True)          # ordered BatchNorm sums instead of atomics: bit-identical reruns (epipolar_hip.h)
     torch.backends.cudnn.enabled = config.CUDNN.ENABLED
     # GPUS (config / --gpus): the reference hands the id list to nn.DataParallel (train.py:93-94).  Here one PROCESS drives one GPU:
     # a single process honours a single id; several ids need `python -m torch.distributed.run --nproc-per-node N scripts/train.py ...`

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--image", type=int, default=64)
     ap.add_argument("--pretrain", type=int, default=8)
+    ap.add_argument("--deterministic", type=int, default=1, help="1: the library's deterministic mode (ordered BatchNorm sums) on both ranks and for the "
+                    "single-process reference: the comparison is then free of the run-to-run noise of the atomics and can be held tight")
     a = ap.parse_args()
     from epipolarpose_amd import distributed as epd
     from epipolarpose_amd import hip
@@ -36,6 +38,8 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     hip.load()
+    if a.deterministic:
+        hip.set_deterministic(True)
     j, d, image, b = 4, 16, a.image, 8                  # per rank: 2 groups x 4 views
     cfg = default_config()
     cfg.MODEL.INIT_WEIGHTS = False

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_shims                                   # noqa: E402
 from det_weights import fill_state_dict, seeded_array   # noqa: E402
 from make_golden_cases import (BIG_HEAD_STD, DLOGITS_STRIDE, INTEGRAL_CASES, LOGIT_STRIDE, NETWORK_BIG_CASES, NETWORK_CASES,   # noqa: E402
-                               TRAJECTORY_CASES, TRAJECTORY_HEAD_STD)
+                               TRAJECTORY_CASES, TRAJECTORY_HEAD_STD, golden_grad_keys, grad_stride)
 from epipolarpose_amd.synthetic import SyntheticScenes  # noqa: E402
 
 REF = ref_shims.load_reference()
@@ -257,10 +257,13 @@ def gen_network():
         out[name + "/bn1.running_mean"] = sd["bn1.running_mean"].numpy()
         out[name + "/deconv_layers.7.running_var"] = sd["deconv_layers.7.running_var"].numpy()
         grads = {k: p.grad for k, p in model.named_parameters()}
-        for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.7.weight",
-                  "deconv_layers.0.weight", "conv1.weight"):
+        legacy = ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.7.weight", "deconv_layers.0.weight", "conv1.weight")
+        for k in golden_grad_keys(grads.keys()):
             g = grads[k].numpy()
-            out[name + "/grad/" + k] = g if g.size <= 70000 else g.reshape(-1)[:: max(1, g.size // 50000)]
+            if k in legacy:       # (rounds 1-3 layout: the whole tensor when small)
+                out[name + "/grad/" + k] = g if g.size <= 70000 else g.reshape(-1)[:: max(1, g.size // 50000)]
+            else:
+                out[name + "/grad/" + k] = g.reshape(-1)[:: grad_stride(k, g.size)].copy()
         out[name + "/gradnorm"] = np.array([float(g.norm()) for g in grads.values()])
     save("network.npz", **out)
 
@@ -297,10 +300,9 @@ def gen_network_big():
         out[name + "/bn1.running_mean"] = sd["bn1.running_mean"].numpy()
         out[name + "/deconv_layers.7.running_var"] = sd["deconv_layers.7.running_var"].numpy()
         grads = {k: p.grad for k, p in model.named_parameters()}
-        for k in ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.0.weight", "layer3.0.conv2.weight",
-                  "layer1.0.conv1.weight", "conv1.weight"):
+        for k in golden_grad_keys(grads.keys()):
             g = grads[k].numpy()
-            out[name + "/grad/" + k] = g.reshape(-1)[:: max(1, g.size // 50000)].copy()
+            out[name + "/grad/" + k] = g.reshape(-1)[:: grad_stride(k, g.size)].copy()
         print(name, "loss", loss.item(), flush=True)
     save("network_big.npz", **out)
 

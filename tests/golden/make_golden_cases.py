@@ -27,3 +27,32 @@ TRAJECTORY_CASES = [
     ("r50_128_b8", 50, 128, 17, 32, 8, 20, 1e-3),        # the bench network at a quarter of the pixels, 2 groups x 4 views
 ]
 TRAJECTORY_HEAD_STD = 0.001
+
+
+# Gradient tensors stored per network golden (round 4: >= 20 per case -- one group per ResNet stage, the stem, EVERY head tensor).  The first
+# GRAD_KEYS_50K entries keep the round-1..3 sub-sampling (every max(1, size // 50000)-th element); the rest store every
+# max(1, size // GRAD_CAP)-th element.  grad_stride(name, size) is the rule generator and tests share.
+GRAD_KEYS_50K = ("final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.7.weight", "deconv_layers.0.weight",
+                 "layer3.0.conv2.weight", "layer1.0.conv1.weight", "conv1.weight")
+GRAD_CAP = 8192
+
+
+def golden_grad_keys(names):
+    """The parameters whose gradients a network golden stores, out of the model's parameter names (ResNet-18 .. 152)."""
+    names = list(names)
+    have = set(names)
+    picks = [k for k in GRAD_KEYS_50K if k in have]
+    extra = ["bn1.weight", "bn1.bias"]
+    for s in (1, 2, 3, 4):
+        last = max(int(n.split(".")[1]) for n in names if n.startswith("layer%d." % s))
+        extra += ["layer%d.0.conv1.weight" % s, "layer%d.0.conv2.weight" % s, "layer%d.0.conv3.weight" % s, "layer%d.0.bn2.weight" % s,
+                  "layer%d.0.downsample.0.weight" % s, "layer%d.%d.conv2.weight" % (s, last), "layer%d.%d.bn1.bias" % (s, last)]
+    extra += [n for n in names if n.startswith(("deconv_layers.", "final_layer."))]
+    for k in extra:
+        if k in have and k not in picks:
+            picks.append(k)
+    return picks
+
+
+def grad_stride(name, size):
+    return max(1, size // (50000 if name in GRAD_KEYS_50K else GRAD_CAP))

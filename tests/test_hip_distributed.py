@@ -23,6 +23,9 @@ def _free_port():
     return port
 
 
+FLOORS = {18: (0.999, 0.9999), 50: (0.999, 0.9999)}     # (min, median) cosine over all parameters; measured 0.999996 / 1.0 for both (call r04f)
+
+
 @pytest.mark.parametrize("layers", [18, 50])
 def test_two_ranks_on_one_device_bucketed_path(tmp_path, layers):
     out = str(tmp_path / "report.json")
@@ -39,10 +42,11 @@ def test_two_ranks_on_one_device_bucketed_path(tmp_path, layers):
     assert r0["params_identical_across_ranks"] and r1["params_identical_across_ranks"]
     assert r0["learning_done"] and r0["hooks_after"] == r0["buckets"] <= 6          # one learned hook per bucket after the first step
     assert set(r0["bucket_dtypes"]) == {"torch.float32", "torch.bfloat16"}
-    # bf16 activations + fp32 atomics make two runs of the same gradient differ by a few per cent in the early layers (see
-    # tests/test_hip_conv.py); a bucket that left before its gradient was final, a missing 1/N or a dropped shard is O(1)
-    # measured on MI355X: ResNet-18 min 0.9998 / median 0.99999; ResNet-50 (bf16 noise floor of 50 layers at batch 8) min 0.77 / median 0.92
-    lo, med = (0.99, 0.999) if layers == 18 else (0.6, 0.85)
+    # Both ranks and the single-process reference run in the library's deterministic mode (ordered BatchNorm sums, round 4): what is left between
+    # the two is the fp32 summation order of the weight gradients (grouped launches vs one per layer) and the bf16 sum of the two ranks' bucket
+    # contents.  Rounds 2-3 ran with atomics and had to accept the run-to-run noise of 50 bf16 layers at batch 8 (ResNet-50: min 0.77 / median
+    # 0.92); a bucket that left before its gradient was final, a missing 1/N or a dropped shard is O(1).
+    lo, med = FLOORS[layers]
     assert r0["min_cos"] >= lo and r0["median_cos"] >= med, (r0["median_cos"], r0["worst"])
     assert 0.8 <= r0["norm_ratio_range"][0] and r0["norm_ratio_range"][1] <= 1.25, r0["norm_ratio_range"]
     assert all(l == l and l < 10 for l in r0["losses"] + r1["losses"])

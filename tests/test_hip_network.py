@@ -30,15 +30,30 @@ def cosine(a, b):
 
 # Gradients.  At these golden states (random weights, batch 2 .. 4) the early-layer gradients of the network are a small difference of
 # large, nearly equal terms (dz - mean(dz) under training-mode BatchNorm with a diffuse soft-argmax): NO bf16 run reproduces them -- stock
-# PyTorch-ROCm kernels under bf16 autocast reach cosines of 0.0 .. 0.9 against the fp32 reference there (logged to
-# gpurun_out/bf16_limited_pairs.json).  Round 3 moved the proof that the gradients are RIGHT to tests/test_hip_precise.py, which has no
-# such clause: the fp32-grade mode of the same kernels reproduces these very golden gradients (cosine >= 0.999 at the bench shape, loss to
-# 1e-7), and the bf16 training path is then compared with it at a trained, well-conditioned state.  What stays here is the yardstick
-# "as good as any bf16 implementation" on the pairs where that is measurable: wherever stock bf16 reaches 0.9, ours must reach
-# min(0.99, stock - 0.01) with the norm within 15 %; the other pairs are logged, required to be finite, and nothing else is claimed.
+# PyTorch-ROCm kernels under bf16 autocast reach cosines of 0.0 .. 0.9 against the fp32 reference there.  So the bf16 path's gradients are
+# NOT compared at the random-weight goldens any more (rounds 1-3 did, with a clause that skipped every pair stock bf16 could not reach):
+#   * that the gradients are RIGHT at the golden states is proven by the fp32-grade mode of the same kernels against the live-reference
+#     golden gradients, 37 .. 42 tensors per configuration (tests/test_hip_precise.py: cosine >= 0.999 at the bench shape, loss to 1e-7);
+#   * the bf16 PRODUCT path is held, for EVERY parameter and with no escape clause, to that fp32-grade mode at a trained, well-conditioned
+#     state of the same configuration (tests/trained_state.py) -- the check below.
+# (min cosine, 5th percentile, median) floors per configuration, set from the values measured on MI355X (gpurun_out/network_trained_state.json)
+# measured (call r04f, batch of the golden case): r18 0.987 / 0.991 / 0.999, r50 (128 x 128, batch 4) 0.857 / 0.879 / 0.969, cfg1 0.979 / 0.983 / 0.998,
+# cfg2 (batch 4) 0.922 / 0.932 / 0.986; ResNet-152 at its golden batch of 2 stays ill-conditioned after 10 steps (0.07 / 0.32 / 0.71 with the loss
+# equal to 6e-5), so configuration 5 is checked at batch 8.  The bench configuration itself at batch 32: tests/test_hip_precise.py.
+# (second run, call r04i: r18 0.978 / 0.986 / 0.999, r50 0.836 / 0.896 / 0.964, cfg1 0.975 / 0.981 / 0.998, cfg2 0.865 / 0.903 / 0.986, cfg5 at batch 8
+#  0.778 / 0.842 / 0.934; floors = the lower of the two runs minus a margin for the run-to-run variation of the trained state itself)
+TRAINED_FLOORS = {"r18": (0.94, 0.96, 0.99), "r50": (0.75, 0.82, 0.94), "cfg1_r18_128": (0.94, 0.95, 0.99), "cfg2_r50_256": (0.80, 0.85, 0.97),
+                  "cfg5_r152_384": (0.65, 0.75, 0.90)}
+TRAINED_BATCH = {"cfg5_r152_384": 8}
+TRAINED_REPORT = {}
+LOSS_REL = {}
+# loss of the bf16 path against the live reference's fp32 loss, forward in deterministic mode (measured: 4e-4 r18, 6.6e-3 r50 -- a bf16 error of
+# THAT random-weight state, identical in every run --, <= 2e-6 at the full configurations, whose N(0, 0.001) head makes the loss insensitive)
+LOSS_RTOL = {"r50": 1e-2}
+LOSS_RTOL_DEFAULT = 2e-3
 
 
-def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_std=None):
+def _check_network(g, name, layers, image, j, d, b, stride, head_std=None):
     from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss, softmax_integral_tensor
     from epipolarpose_amd.models.pose3d_resnet import get_pose_net
     from oracle import network as o_net
@@ -78,8 +93,13 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
         slack = max(0.05, 3.0 * float(np.sqrt(2.0 * bad_stock * (1.0 - bad_stock) / xyz.size)))
         assert bad_ours <= bad_stock + slack, (bad_ours, bad_stock, slack)
     model.train()
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        logits = model(x)
+    from epipolarpose_amd import hip
+    hip.set_deterministic(True)          # ordered BatchNorm sums (the reference's CUDNN.DETERMINISTIC): one fixed bf16 result instead of a run-to-run spread
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits = model(x)
+    finally:
+        hip.set_deterministic(False)
     ref = g[name + "/logits_train"]
     ref_max = float(g[name + "/logits_train_absmax"]) if stride else np.abs(ref).max()
     # Training-mode BatchNorm over a small batch at 2x2 .. 12x12 spatial amplifies bf16 rounding through the whole depth, so
@@ -97,58 +117,52 @@ def _check_network(g, name, layers, image, j, d, b, stride, limited_log, head_st
     assert c_ours >= min(0.99, c_stock - 0.01), (c_ours, c_stock)
     gt = torch.from_numpy(seeded_array("gt/" + name, (b, 3 * j), scale=0.2)).to(dev)
     loss = SmoothL1JointLocationLoss(num_joints=j)(logits, gt, torch.ones(b, 3 * j, device=dev))
-    # bf16 activations, and two runs of the SAME code differ: the order of the statistics' atomics can flip a bf16 rounding in the stem, which moves
-    # the logits of these random-weight goldens by 1 - 3 % (tools/debug_fwd_bimodal.py) and the loss by up to 0.6 % (measured 1e-4 .. 5.9e-3 over
-    # repeated runs of r50).  The fp32-grade mode of the same kernels holds this loss to 3e-7 (tests/test_hip_precise.py).
-    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=1e-2)
+    # bf16 activations.  In the DEFAULT mode two runs of the same code differ: the order of the statistics' atomics can flip a bf16 rounding in the
+    # stem, which moves the logits of these random-weight goldens by 1 - 3 % (tools/debug_fwd_bimodal.py) and the loss by 1e-4 .. 5.9e-3 over
+    # repeated runs of r50 -- rounds 1-3 held the loss to 1e-2 for that reason.  The forward above ran in deterministic mode (one fixed result,
+    # bit-identical reruns: tests/test_hip_deterministic.py).  The fp32-grade mode of the same kernels holds this loss to 3e-7 (tests/test_hip_precise.py).
+    LOSS_REL[name] = abs(loss.item() - float(g[name + "/loss"])) / abs(float(g[name + "/loss"]))
+    np.testing.assert_allclose(loss.item(), g[name + "/loss"], rtol=LOSS_RTOL.get(name, LOSS_RTOL_DEFAULT))
     loss.backward()
     sd = model.state_dict()
     np.testing.assert_allclose(sd["bn1.running_mean"].cpu().numpy(), g[name + "/bn1.running_mean"], atol=2e-3)
     np.testing.assert_allclose(sd["deconv_layers.7.running_var"].cpu().numpy(), g[name + "/deconv_layers.7.running_var"], rtol=5e-2)
     grads = {k: p.grad for k, p in model.named_parameters()}
-    # gradients: same yardstick (deep-layer gradients of ANY bf16 run sit at cosine ~0.96-0.99 against fp32 here)
-    o_net.joint_location_loss(ologits.float(), gt, torch.ones(b, 3 * j, device=dev), j, "smoothl1").backward()
-    for k in sorted(kk[len(name) + 6:] for kk in g if kk.startswith(name + "/grad/")):
-        if k not in grads or k == "deconv_layers.7.weight":
-            continue
-        got = grads[k].float().contiguous().cpu()
-        stock = params[k].grad.float().contiguous().cpu()
-        refg = torch.from_numpy(g[name + "/grad/" + k])
-        assert torch.isfinite(got).all(), k
-        if refg.dim() == 1 and got.dim() > 1:
-            step = max(1, got.numel() // 50000)
-            got, stock = got.reshape(-1)[::step], stock.reshape(-1)[::step]
-        c_ours, c_stock = cosine(got, refg), cosine(stock, refg)
-        if c_stock < 0.9:                       # not measurable in bf16 (see above): logged, proven in test_hip_precise.py
-            limited_log.append((name, k, round(c_stock, 3), round(c_ours, 3)))
-            continue
-        assert c_ours >= min(0.99, c_stock - 0.01), (k, c_ours, c_stock)
-        assert abs(float(got.norm() / refg.norm()) - 1.0) <= 0.15, k
+    for k, gk in grads.items():
+        assert gk is not None and torch.isfinite(gk).all(), k
+    # gradients of the bf16 product path: every parameter, against the fp32-grade mode, at a trained state of THIS configuration
+    from trained_state import bf16_vs_precise_at_trained_state
+    rep = bf16_vs_precise_at_trained_state(layers, image, j, d, TRAINED_BATCH.get(name, b), tag="trained/" + name)
+    TRAINED_REPORT[name] = {k: v for k, v in rep.items() if k != "cos"}
+    lo, p05, med = TRAINED_FLOORS[name]
+    assert rep["n_params"] == len(grads), (rep["n_params"], len(grads))
+    assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= 5e-3 * rep["loss_precise"], rep["worst"]
+    assert rep["head_min_cos"] >= 0.99, rep["head_min_cos"]
+    assert rep["min_cos"] >= lo and rep["p05_cos"] >= p05 and rep["median_cos"] >= med, (rep["min_cos"], rep["p05_cos"], rep["median_cos"], rep["worst"])
 
 
-@pytest.fixture(scope="module")
-def limited_log():
-    log = []
-    yield log
+@pytest.fixture(scope="module", autouse=True)
+def trained_report_file():
+    yield
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(os.path.join("gpurun_out", "bf16_limited_pairs.json"), "w") as f:
-        json.dump(log, f)
+    with open(os.path.join("gpurun_out", "network_trained_state.json"), "w") as f:
+        json.dump({"trained_state": TRAINED_REPORT, "loss_rel_deterministic": LOSS_REL}, f, indent=1, sort_keys=True)
 
 
 @pytest.mark.parametrize("case", NETWORK_CASES, ids=[c[0] for c in NETWORK_CASES])
-def test_network_vs_reference_golden(golden, case, limited_log):
+def test_network_vs_reference_golden(golden, case):
     name, layers, image, j, d, b = case
-    _check_network(golden("network"), name, layers, image, j, d, b, 0, limited_log)
+    _check_network(golden("network"), name, layers, image, j, d, b, 0)
 
 
 @pytest.mark.parametrize("case", NETWORK_BIG_CASES, ids=[c[0] for c in NETWORK_BIG_CASES])
-def test_network_full_configs_vs_reference_golden(golden, case, limited_log):
+def test_network_full_configs_vs_reference_golden(golden, case):
     """BASELINE.json configs 1 (ResNet-18, 128x128), 2 (ResNet-50, 256x256: the bench shape) and 5 (ResNet-152, 384x384) against
     the reference network executed in fp32 (tests/golden/make_golden.py network_big); sub-sampled logits, full decode + loss."""
     name, layers, image, j, d, b = case
-    _check_network(golden("network_big"), name, layers, image, j, d, b, LOGIT_STRIDE, limited_log, head_std=BIG_HEAD_STD)
+    _check_network(golden("network_big"), name, layers, image, j, d, b, LOGIT_STRIDE, head_std=BIG_HEAD_STD)
 
 
 def test_training_reduces_loss_and_ss_step_runs():
@@ -209,3 +223,54 @@ def test_fused_adam_matches_torch_adam():
         assert torch.equal(lp.detach().float(), opt._params[i].detach().to(torch.bfloat16).float())
     sd = opt.state_dict()
     opt.load_state_dict(sd)
+
+
+def test_whole_network_used_twice_in_one_graph():
+    """The model called on TWO inputs before one backward: every layer's weight receives two gradients in one pass, and the autograd engine adds
+    the second to the first on the main stream while `.grad` is still undefined.  The second stream / deferred slab sums must not leave the
+    first one in flight then (round-3 advisor finding: the head nodes DeconvBnAct / Conv1x1Bias and the stem decided with
+    gradient_consumed_after_backward alone).  Reference: the two-stream, deferred configuration against one stream, immediate sums."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    j, d, image, b = 4, 16, 64, 4
+    torch.manual_seed(3)
+    model = get_pose_net(make_cfg(18, image, j, d), is_train=True).to(dev)
+    model.train()
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    gen = torch.Generator().manual_seed(4)
+    xa = torch.randn((b, 3, image, image), generator=gen).to(dev)
+    xb = torch.randn((b, 3, image, image), generator=gen).to(dev)
+    gt = ((torch.rand((b, 3 * j), generator=gen) - 0.5) * 0.4).to(dev)
+    wt = torch.ones(b, 3 * j, device=dev)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def grads():
+        model.load_state_dict(state)                 # (same BatchNorm buffers for every arm)
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = crit(model(xa), gt, wt) + crit(model(xb), gt, wt)
+        loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
+
+    glue = hip.glue()
+    defer0, side0, group0 = glue.defer_wgrad_reduce(False), glue.wgrad_stream_mode(0), glue.wgrad_group_mode(0)
+    try:
+        ref = grads()
+        for defer, side, group in ((True, 1, 2), (True, 1, 0), (False, 1, 2), (True, 0, 2)):
+            glue.defer_wgrad_reduce(defer)
+            glue.wgrad_stream_mode(side)
+            glue.wgrad_group_mode(group)
+            got = grads()
+            for k in ref:
+                assert torch.isfinite(got[k]).all(), (k, defer, side, group)
+                # run-to-run noise of a bf16 network with atomically summed BatchNorm statistics is a few % of the norm; a gradient the engine
+                # summed while one addend was still being written (or whose slab sum never ran) is O(1) wrong
+                assert float((got[k] - ref[k]).norm()) <= 0.15 * float(ref[k].norm()) + 1e-9, (k, defer, side, group)
+                assert cosine(got[k], ref[k]) >= 0.98 or float(ref[k].norm()) < 1e-9, (k, defer, side, group)
+    finally:
+        glue.defer_wgrad_reduce(defer0)
+        glue.wgrad_stream_mode(side0)
+        glue.wgrad_group_mode(group0)

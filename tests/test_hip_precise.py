@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from det_weights import fill_state_dict, seeded_array
-from make_golden_cases import BIG_HEAD_STD, LOGIT_STRIDE, NETWORK_BIG_CASES, TRAJECTORY_CASES, TRAJECTORY_HEAD_STD
+from make_golden_cases import BIG_HEAD_STD, LOGIT_STRIDE, NETWORK_BIG_CASES, TRAJECTORY_CASES, TRAJECTORY_HEAD_STD, grad_stride
 
 pytestmark = pytest.mark.gpu
 
@@ -55,7 +55,10 @@ def test_precise_convolutions_vs_float64(pieces, tol):
     gen = torch.Generator().manual_seed(31 + pieces)
     worst = {}
     # (Cin, Cout, k, stride, H): 1x1, 3x3 stride 1 | 2 (patch-eligible geometry included), the stride-2 projection
-    for cin, cout, k, stride, h in ((64, 64, 1, 1, 16), (64, 64, 3, 1, 16), (128, 128, 3, 2, 16), (256, 512, 1, 2, 8), (512, 128, 1, 1, 8), (64, 256, 1, 1, 16)):
+    # ... and two 64-channel layers at 4 x 128 x 128 = 65 536 rows: from that row count on a bf16 result with N <= 64 takes the 256 x 64 tile,
+    # which has no fp32-result instantiation (rounds 2-3 planned fp32 results for it all the same: wrong layer-1 results from batch 16 on)
+    for cin, cout, k, stride, h in ((64, 64, 1, 1, 16), (64, 64, 3, 1, 16), (128, 128, 3, 2, 16), (256, 512, 1, 2, 8), (512, 128, 1, 1, 8), (64, 256, 1, 1, 16),
+                                    (64, 64, 1, 1, 128), (256, 64, 1, 1, 128)):
         pad = k // 2
         x = torch.randn((4, cin, h, h), generator=gen)
         w = torch.randn((cout, cin, k, k), generator=gen) * (2.0 / (cin * k * k)) ** 0.5
@@ -225,17 +228,20 @@ def test_precise_network_vs_reference_golden(golden, case):
     for k in sorted(kk[len(name) + 6:] for kk in g if kk.startswith(name + "/grad/")):
         refg = torch.from_numpy(g[name + "/grad/" + k])
         got = sd[k].grad.float().contiguous().cpu().reshape(-1)
-        got = got[:: max(1, got.numel() // 50000)]
+        got = got[:: grad_stride(k, got.numel())]
         rep["grad_cos/" + k] = cosine(got, refg)
         rep["grad_norm_ratio/" + k] = float(got.double().norm() / refg.double().norm())
         sg = sd32[k].grad.float().contiguous().cpu().reshape(-1)
-        rep["stock_fp32_grad_cos/" + k] = cosine(sg[:: max(1, sg.numel() // 50000)], refg)
+        rep["stock_fp32_grad_cos/" + k] = cosine(sg[:: grad_stride(k, sg.numel())], refg)
     REPORT["network/" + name] = rep
+    # ResNet-152 at batch 2 (configuration 5): fp32 itself only reaches cosine 0.989 .. 0.993 against the reference there (stock fp32 kernels:
+    # the stock_fp32_* entries), norms to 2 %; the 42 tensors stored since round 4 include the worst-conditioned BatchNorm parameters
+    cos_slack, norm_tol = (6e-3, 3e-2) if layers >= 152 else (1e-3, 5e-3)
     for k, v in rep.items():
         if k.startswith("grad_cos/"):
-            assert v >= min(0.999, rep["stock_fp32_" + k] - 1e-3), (k, v, rep["stock_fp32_" + k])
+            assert v >= min(0.999, rep["stock_fp32_" + k] - cos_slack), (k, v, rep["stock_fp32_" + k])
         if k.startswith("grad_norm_ratio/"):
-            assert abs(v - 1.0) <= 5e-3, (k, v)
+            assert abs(v - 1.0) <= norm_tol, (k, v)
 
 
 # ---- 20 optimisation steps against the live reference's trajectory ------------------------------------------------------------------
@@ -303,72 +309,30 @@ def test_training_trajectory_vs_reference(golden, case):
 
 
 # ---- the bf16 training path against the fp32-grade mode at a trained state -----------------------------------------------------------
-def test_bf16_training_path_vs_precise_at_trained_state():
-    """at random initialisation the early-layer gradients of this network are a tiny difference of large
-    terms and NO bf16 run reproduces them (cosine 0.07 .. 0.1, stock kernels included).  After a few optimisation steps the problem
-    is well conditioned: tools/probe_conditioning.py (reference network, CPU, bf16 autocast against fp32) reaches 0.87 .. 0.95 on the
-    early layers and 1.000 on the head from step 5 on.  Here: 10 Adam steps in the fp32-grade mode, then every parameter gradient of the
-    bf16 training path against the fp32-grade one on the same weights and batch -- no stock-bf16 escape clause."""
-    from epipolarpose_amd.core.config import default_config
-    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
-    from epipolarpose_amd.models import precise
-    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
-    dev = torch.device("cuda:0")
-    layers, image, j, d, b = 50, 128, 17, 32, 8
-    cfg = default_config()
-    cfg.MODEL.INIT_WEIGHTS = False
-    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, d, [image, image]
-    cfg.MODEL.EXTRA.NUM_LAYERS = layers
-    torch.manual_seed(7)
-    model = get_pose_net(cfg, is_train=True).to(dev)              # torch's default initialisation of the backbone ...
-    init = model.state_dict()
-    for k, v in init.items():                                     # ... and the reference's own N(0, 0.001) head (pose3d_resnet.py:222-239)
-        if v.dim() == 4 and (k.startswith("deconv_layers") or k.startswith("final_layer")):
-            v.normal_(0, 0.001)
-    sd = {k: v.detach().clone().float() if v.dtype.is_floating_point else v.detach().clone() for k, v in init.items()}
-    for k, v in sd.items():
-        if v.dtype.is_floating_point and "running" not in k:
-            v.requires_grad_(True)
-    x = torch.from_numpy(seeded_array("img/trained", (b, 3, image, image))).to(dev)
-    gt = torch.from_numpy(seeded_array("gt/trained", (b, 3 * j), scale=0.2)).to(dev)
-    wt = torch.ones(b, 3 * j, device=dev)
-    crit = SmoothL1JointLocationLoss(num_joints=j)
-    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
-    for _ in range(10):
-        opt.zero_grad()
-        crit(precise.forward(sd, x, layers, training=True), gt, wt).backward()
-        opt.step()
-    state = {k: v.detach().clone() for k, v in sd.items()}
-    opt.zero_grad()
-    loss32 = crit(precise.forward(sd, x, layers, training=True), gt, wt)
-    loss32.backward()
-    model.load_state_dict(state)
-    model.train()
-    model.zero_grad()
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        logits = model(x)
-    loss16 = crit(logits, gt, wt)
-    loss16.backward()
-    torch.cuda.synchronize()
-    rep = {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item())}
-    cos = {}
-    for k, p in model.named_parameters():
-        gk = p.grad
-        if gk is None:
-            continue
-        cos[k] = cosine(gk.float().cpu(), sd[k].grad.cpu())
-    rep["cos"] = cos
-    rep["min_cos"] = min(cos.values())
-    rep["n_params"] = len(cos)
-    REPORT["bf16_vs_precise_trained"] = rep
-    assert len(cos) >= 150, len(cos)
-    assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= 2e-3 * rep["loss_precise"], rep
-    head = [v for k, v in cos.items() if k.startswith(("deconv_layers", "final_layer"))]
-    assert min(head) >= 0.995, min(head)
-    # measured on MI355X over several runs (the trained state itself varies run to run: fp32 atomics in the BatchNorm sums): minimum
-    # 0.78 .. 0.87 (one BatchNorm bias of layer1), 5th percentile 0.88 .. 0.90, median 0.97 -- the figures tools/probe_conditioning.py
+# (layers, image, J, D, batch) -> floors (min, 5th percentile, median cosine over all parameter gradients; loss rtol).  "bench" IS the bench
+# configuration (BASELINE.json configs[1]: ResNet-50, 256 x 256, batch 32, D = 64); "small" is the round-3 shape.
+# Measured on MI355X (calls r04f / r04i): small 0.894 / 0.925 .. 0.943 / 0.990 .. 0.993 after 10 steps; bench 0.747 / 0.814 / 0.955 after 10 steps with the
+# losses equal to 5e-5 -- at batch 32 the network leaves its ill-conditioned initial state more slowly (loss 0.98 -> 0.91 in 10 steps), so the bench
+# case trains 30 steps first.  (This case is what found the fp32-result planning defect of rounds 2-3: see csrc/head_gemm.hip gemm_plan.)
+TRAINED_CASES = {
+    "small_r50_128_b8": ((50, 128, 17, 32, 8, 10), (0.75, 0.85, 0.95, 2e-3)),
+    "bench_r50_256_b32": ((50, 256, 17, 64, 32, 30), (0.70, 0.80, 0.93, 2e-3)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TRAINED_CASES))
+def test_bf16_training_path_vs_precise_at_trained_state(case):
+    """every parameter gradient of the bf16 product path against the fp32-grade mode after 10 Adam
+    steps (tests/trained_state.py) -- no stock-bf16 escape clause -- at the round-3 shape AND at the bench configuration itself."""
+    from trained_state import bf16_vs_precise_at_trained_state
+    (layers, image, j, d, b, steps), (min_floor, p05_floor, med_floor, loss_rtol) = TRAINED_CASES[case]
+    rep = bf16_vs_precise_at_trained_state(layers, image, j, d, b, steps=steps)
+    REPORT["bf16_vs_precise_trained/" + case] = rep
+    assert rep["n_params"] >= 150, rep["n_params"]
+    assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= loss_rtol * rep["loss_precise"], rep
+    assert rep["head_min_cos"] >= 0.995, rep["head_min_cos"]
+    # measured on MI355X over several runs (the trained state itself varies run to run: fp32 atomics in the BatchNorm sums), round 3, small shape:
+    # minimum 0.78 .. 0.87 (one BatchNorm bias of layer1), 5th percentile 0.88 .. 0.90, median 0.97 -- the figures tools/probe_conditioning.py
     # gets for stock bf16 autocast on the reference network
-    vals = np.sort(np.asarray(list(cos.values())))
-    rep["p05_cos"], rep["median_cos"] = float(vals[len(vals) // 20]), float(np.median(vals))
-    assert rep["min_cos"] >= 0.65, sorted(cos.items(), key=lambda kv: kv[1])[:5]
-    assert rep["p05_cos"] >= 0.82 and rep["median_cos"] >= 0.93, (rep["p05_cos"], rep["median_cos"])
+    assert rep["min_cos"] >= min_floor, rep["worst"]
+    assert rep["p05_cos"] >= p05_floor and rep["median_cos"] >= med_floor, (rep["p05_cos"], rep["median_cos"])

@@ -1,0 +1,73 @@
+"""Shared by the GPU parity tests: every parameter gradient of the bf16 PRODUCT path against the fp32-grade mode of the same kernels
+(epipolarpose_amd/models/precise.py) at a TRAINED state of the network.
+
+Why a trained state: at the random-weight golden states the early-layer gradients of this network are a tiny difference of large, nearly equal
+terms (dz - mean(dz) under training-mode BatchNorm with a diffuse soft-argmax) and NO bf16 run reproduces them (stock kernels under bf16
+autocast reach cosines of 0.0 .. 0.9 against the fp32 reference there).  After a few optimisation steps the problem is well conditioned
+(tools/probe_conditioning.py: 0.87 .. 0.95 on the early layers, 1.000 on the head from step 5 on, reference network on the CPU).  The fp32-grade
+mode itself is pinned to the live reference's golden vectors (logits, loss, gradients, 20-step trajectories: tests/test_hip_precise.py), so it
+is the on-device stand-in for the reference at states no fixture can hold (a ResNet-50 state is 137 MB)."""
+import numpy as np
+import torch
+
+from det_weights import seeded_array
+
+
+def cosine(a, b):
+    a, b = a.reshape(-1).double(), b.reshape(-1).double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def bf16_vs_precise_at_trained_state(layers, image, j, d, b, steps=10, seed=7, tag="trained"):
+    """`steps` Adam steps in the fp32-grade mode from a seeded initialisation (torch's default backbone initialisation, the reference's own
+    N(0, 0.001) head, pose3d_resnet.py:222-239), then one forward + backward of BOTH paths on the same weights and batch.
+    Returns dict(loss_precise, loss_bf16, cos{param: cosine}, min_cos, p05_cos, median_cos, head_min_cos, n_params)."""
+    from epipolarpose_amd.core.config import default_config
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models import precise
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cfg.MODEL.INIT_WEIGHTS = False
+    cfg.MODEL.NUM_JOINTS, cfg.MODEL.DEPTH_RES, cfg.MODEL.IMAGE_SIZE = j, d, [image, image]
+    cfg.MODEL.EXTRA.NUM_LAYERS = layers
+    torch.manual_seed(seed)
+    model = get_pose_net(cfg, is_train=True).to(dev)
+    init = model.state_dict()
+    for k, v in init.items():
+        if v.dim() == 4 and (k.startswith("deconv_layers") or k.startswith("final_layer")):
+            v.normal_(0, 0.001)
+    sd = {k: v.detach().clone().float() if v.dtype.is_floating_point else v.detach().clone() for k, v in init.items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(True)
+    x = torch.from_numpy(seeded_array("img/" + tag, (b, 3, image, image))).to(dev)
+    gt = torch.from_numpy(seeded_array("gt/" + tag, (b, 3 * j), scale=0.2)).to(dev)
+    wt = torch.ones(b, 3 * j, device=dev)
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=1e-3)
+    for _ in range(steps):
+        opt.zero_grad()
+        crit(precise.forward(sd, x, layers, training=True), gt, wt).backward()
+        opt.step()
+    state = {k: v.detach().clone() for k, v in sd.items()}
+    opt.zero_grad()
+    loss32 = crit(precise.forward(sd, x, layers, training=True), gt, wt)
+    loss32.backward()
+    model.load_state_dict(state)
+    model.train()
+    model.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits = model(x)
+    loss16 = crit(logits, gt, wt)
+    loss16.backward()
+    torch.cuda.synchronize()
+    cos = {}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            cos[k] = cosine(p.grad.float().cpu(), sd[k].grad.cpu())
+    vals = np.sort(np.asarray(list(cos.values())))
+    head = [v for k, v in cos.items() if k.startswith(("deconv_layers", "final_layer"))]
+    return {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item()), "cos": cos, "n_params": len(cos),
+            "min_cos": float(vals[0]), "p05_cos": float(vals[len(vals) // 20]), "median_cos": float(np.median(vals)), "head_min_cos": float(min(head)),
+            "worst": sorted(cos.items(), key=lambda kv: kv[1])[:5]}
