@@ -13,6 +13,7 @@
 // MFMAs, double-buffered LDS (64 KiB -> 2 workgroups / CU), 16-byte chunks XOR-swizzled on the SOURCE address so the
 // lane-linear DMA image is conflict-free for the 16-lane ds_read_b128 groups.
 #include "common.h"
+#include "bn_affine.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -113,6 +114,12 @@ struct GemmArgs {
     int addend_step;       // 2: `addend` is [B][add_h / 2][add_w / 2][ldc] and holds the contribution of the EVEN pixels of the [B][add_h][add_w] output only
     int add_h, add_w;      //    (the shortcut gradient through a 1x1 stride-2 projection: every other pixel receives none); plain rows, coalesced epilogue only
     int store_policy;      // coalesced epilogue's result stores: 0 plain, 1 non-temporal (nt) -- epi_gemm_store_policy
+    // BatchNorm (+ ReLU) of the A operand, applied on the fly (BNIN instantiation, plain rows): A holds the RAW output z of the convolution in front
+    // and this launch computes C = relu(z * scale[k] + shift[k]) x Bt -- the normalised tensor is never written (round 4: one apply launch per
+    // bottleneck interior less).  Every workgroup derives (scale, shift) of all K channels from the batch sums into LDS (bn_derive); workgroup 0 also
+    // writes the saved statistics, updates the running estimates and clears the layer's backward accumulator, as the apply kernel's lead does.
+    int bn_in_on;
+    BnAffine bn_in;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -410,8 +417,23 @@ enum { A_PLAIN = 0, A_GATHER = 1, A_PHASED = 2 };     // how the A operand's row
 
 // RED: the instantiation with the fused BatchNorm-backward reduction (GemmBnRed) in the coalesced epilogue -- a separate one, so that the
 // registers its epilogue needs (column parameters, the z / y tiles in flight) never enter the allocation of the other launches
-template <bool OUT_F32, typename Cfg, int MODE, bool RED = false>
+// the A fragment of eight consecutive k (one lane's operand of a 32x32x16 MFMA) through relu(z * scale + shift); tab: (scale, shift) pairs of those k
+__device__ __forceinline__ bf16x8 bn_in_apply(bf16x8 a, const float4v (&t)[4]) {
+    const uint4v u = __builtin_bit_cast(uint4v, a);
+    const unsigned int w[4] = {u.x, u.y, u.z, u.w};
+    unsigned int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+        o[k] = pack_bf16x2(fmaxf(lo * t[k].x + t[k].y, 0.f), fmaxf(hi * t[k].z + t[k].w, 0.f));      // (the arithmetic of bn_apply2d_kernel)
+    }
+    uint4v r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <bool OUT_F32, typename Cfg, int MODE, bool RED = false, bool BNIN = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel(GemmArgs p) {
+    static_assert(!BNIN || (MODE == A_PLAIN && Cfg::NSTAGE == 2), "BatchNorm on the A operand: plain rows, two-stage loop");
     constexpr int GBM = Cfg::BM, GBN = Cfg::BN, TM = Cfg::TM, AP = Cfg::AP, BP = Cfg::BP;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -543,6 +565,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int frow = lane & 31, fhalf = lane >> 5;
+    // BNIN: (scale, shift) of all K channels of the A operand, behind the staging ring (the epilogue's park and combine areas end below it)
+    float2* bn_tab = reinterpret_cast<float2*>(smem + Cfg::NSTAGE * Cfg::STAGE_BYTES);
+    if (BNIN) {
+        const bool lead = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+        for (int k = tid; k < p.K; k += Cfg::THREADS) {
+            float sc, sh;
+            bn_derive(p.bn_in, p.K, k, lead, sc, sh);
+            bn_tab[k] = float2{sc, sh};
+        }
+        if (lead && tid == 0 && p.bn_in.num_batches && p.bn_in.sums) p.bn_in.num_batches[0] += 1;
+    }
     const int a_frag = lds_off(wm * (TM * 32) + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
     // fragment address of (row + 32*t, k step ks): rows 32 apart share the swizzle term -> + t*4096; the k step flips
     // chunk bits 1..2 of the XOR-swizzled chunk index -> ^ (ks << 5)
@@ -566,15 +599,27 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
     };
     // One K tile from buffer `buf`: the fragments of k step ks+1 are requested before the MFMAs of step ks issue (LDS latency
     // hidden behind the matrix pipe); `spread_next` interleaves a later tile's DMA, a quarter per k step, between the MFMA groups.
-    auto compute_tile = [&](int buf, bool spread_next, int k_next, int buf_next) {
+    auto compute_tile = [&](int buf, bool spread_next, int k_next, int buf_next, int k_tile = 0) {
         const char* a_s = smem + buf * Cfg::STAGE_BYTES;
         const char* b_s = a_s + Cfg::A_BYTES;
         bf16x8 af[2][TM], bfr[2][2];
+        float4v bt[2][4];                           // BNIN: (scale, shift) of the lane's eight k of a step, fetched with the fragments
+        auto read_tab = [&](int ks, float4v (&t)[4]) {
+            const float4v* src = reinterpret_cast<const float4v*>(bn_tab + k_tile + ks * 16 + fhalf * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = src[q];
+        };
         read_frags(a_s, b_s, 0, af[0], bfr[0]);
+        if (BNIN) read_tab(0, bt[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+            if (BNIN && ks < 3) read_tab(ks + 1, bt[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE this step's MFMAs (the scheduler would sink it)
+            if (BNIN) {
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti) af[ks & 1][ti] = bn_in_apply(af[ks & 1][ti], bt[ks & 1]);
+            }
             if (spread_next) issue_quarter(ks, k_next, buf_next);
             // operands swapped: D[i][j] with i = output column n (register rows), j = output row m (lane & 31),
             // so that a lane ends up holding 4 consecutive columns of one row
@@ -625,7 +670,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
             const bool has_next = kt + 1 < nk;
             const int k_next = k_begin + (kt + 1) * GBK, buf = kt & 1;
             if (Cfg::EARLY && has_next) issue_tile(k_next, buf ^ 1);
-            compute_tile(buf, !Cfg::EARLY && has_next, k_next, buf ^ 1);
+            compute_tile(buf, !Cfg::EARLY && has_next, k_next, buf ^ 1, k_begin + kt * GBK);
             __syncthreads();
         }
     }
@@ -1230,7 +1275,8 @@ static int gemm_tile_override() {
 
 // Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
 // keeping >= 512 of K.
-// EPI_GEMM_PIPE: 0 (default) never, 1 when a workgroup's K loop has >= 6 tiles, 2 always (where a pipelined variant exists).
+// EPI_GEMM_PIPE: 0 (default) never, 1 when a workgroup's K loop has >= 6 tiles, 2 always (where a pipelined variant exists), 3 as 1 but only
+// for launches of <= 256 workgroups (see gemm_plan: round 4 measured 3 per kernel and in the step).
 // Measured on MI355X (profiles/r02_conv_layers_c_pipelined_ab.txt): the ring removes the DMA-latency stall but these GEMMs are bound by
 // the global->LDS fill itself (32 KB per 128x128x64 tile step, ~23 GB/s per CU = ~6 TB/s over the chip), so it gains nothing here
 static int g_pipe_force_fwd();
@@ -1298,7 +1344,7 @@ static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pip
 // tiles, and a deep K loop per workgroup: either enough tiles to fill the chip unsplit (K >= 512), or >= 1024 of K
 // left per split (measured on MI355X: below that the 128^2 tile at 2 workgroups / CU hides the pipeline prologue better).
 // tall (256 x 64) serves N <= 64 with enough rows to fill the chip.
-static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32) {
+static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32, bool allow_pipe = true) {
     const int ov = gemm_tile_override();
     const bool can_big = !out_f32 && N % 8 == 0 && ldc % 8 == 0;
     if (can_big && ov != 1) {
@@ -1322,10 +1368,18 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         const long long t64x128 = (long long)((M + 63) / 64) * ((N + 127) / 128) * nphase;
         if (t128 < fill_env) cfg = t64x128 < fill_env ? CFG_QUARTER : CFG_HALF;
     }
-    const int pm = out_f32 || cfg == CFG_HALF || cfg == CFG_QUARTER ? 0 : gemm_pipe_mode();
+    const int pm = (out_f32 || !allow_pipe || cfg == CFG_HALF || cfg == CFG_QUARTER) ? 0 : gemm_pipe_mode();
     if (pm) {       // pipelined ring (one workgroup per CU): pays when every workgroup still has a K loop of >= 6 tiles
         const GemmPlan pp = gemm_plan_cfg(cfg, M, N, K, nphase, true);
-        if (pm == 2 || pp.kps >= 6 * GBK) return pp;
+        // mode 3 (round 4): only launches that fit the chip in ONE round of one workgroup per CU anyway -- there the two-stage loop exposes a
+        // full DMA latency per K tile (0.9 us on operands that come from HBM, tools/gemm_trace.hip) and the ring hides two thirds of it
+        // (profiles/r04_gemm_lab_*: 1024->256 at 16 x 16 19.9 -> 14.9 us, 512->128 at 32 x 32 15.8 -> 13.4, 512->2048 at 8 x 8 12.8 -> 10.8);
+        // launches with more tiles lose the second resident workgroup per CU to the ring's LDS and run slower (512->256 at 32 x 32 18.6 -> 21.2).
+        // In the STEP the operands were written by the previous launch and come from L2 / MALL, where the ring gains nothing (the "warm" column of
+        // the same tables): 6.204 / 6.212 ms with mode 3 against 6.194 / 6.187 ms without, fused-reduction launches included
+        // (profiles/r04_ab_pipe_mode3.txt) -- so the default stays 0
+        const bool one_round = pp.tiles * nphase * pp.nsplit <= 256;
+        if (pm == 2 || (pm == 1 && pp.kps >= 6 * GBK) || (pm == 3 && one_round && pp.kps >= 6 * GBK)) return pp;
     }
     return gemm_plan_cfg(cfg, M, N, K, nphase);
 }
@@ -1334,27 +1388,32 @@ extern "C" size_t epi_gemm_workspace_bytes(int M, int N, int K, int nphase) {
     if (M <= 0 || N <= 0 || K <= 0 || nphase <= 0) return 0;
     // the larger of the two configurations' needs (the output stride / dtype are not known here)
     size_t need = 0;
-    for (int f32 = 0; f32 < 2; ++f32) {
-        const GemmPlan pl = gemm_plan(M, N, K, 8, nphase, f32 != 0);
-        if (pl.nsplit > 1) need = std::max(need, (size_t)pl.nsplit * nphase * M * N * sizeof(float));
+    for (int pipe = 0; pipe < 2; ++pipe) {             // (with / without the pipelined ring: the split factors differ)
+        for (int f32 = 0; f32 < 2; ++f32) {
+            const GemmPlan pl = gemm_plan(M, N, K, 8, nphase, f32 != 0, pipe != 0);
+            if (pl.nsplit > 1) need = std::max(need, (size_t)pl.nsplit * nphase * M * N * sizeof(float));
+        }
+        const GemmPlan ps = gemm_plan(M, N, K, 4, nphase, false, pipe != 0);
+        if (ps.nsplit > 1) need = std::max(need, (size_t)ps.nsplit * nphase * M * N * sizeof(float));
     }
-    const GemmPlan ps = gemm_plan(M, N, K, 4, nphase, false);
-    if (ps.nsplit > 1) need = std::max(need, (size_t)ps.nsplit * nphase * M * N * sizeof(float));
     return need;
 }
 
-template <bool OUT_F32, typename Cfg, int MODE, bool RED = false>
+template <bool OUT_F32, typename Cfg, int MODE, bool RED = false, bool BNIN = false>
 static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, hipStream_t st) {
     // staging ring; the epilogue reuses it for the waves' output slices and, behind them, the BatchNorm-statistics combine area
-    const size_t lds = std::max((size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES,
-                                (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
+    // (BNIN: the (scale, shift) table of the A operand's K channels behind the ring)
+    constexpr size_t ring = (size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES;
+    const size_t lds = BNIN ? ring + (size_t)a.K * sizeof(float2)
+                            : std::max(ring, (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
+    static_assert(!BNIN || ring >= (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float), "epilogue areas end below the table");
     if (lds > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE, RED>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE, RED, BNIN>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, BNIN ? (int)(ring + 2048 * sizeof(float2)) : (int)lds);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
     const dim3 grid((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)nphase);
-    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg, MODE, RED>), grid, dim3(Cfg::THREADS), lds, st, a);
+    hipLaunchKernelGGL((head_gemm_kernel<OUT_F32, Cfg, MODE, RED, BNIN>), grid, dim3(Cfg::THREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
@@ -1487,6 +1546,35 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (a.K % 8 || a.ldb % 8 || a.ldc % 4 || (!a.ga.enabled && a.lda % 8)) return EPI_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.Bt) | reinterpret_cast<uintptr_t>(a.C)) & 15u) return EPI_ERR_UNSUPPORTED;
     if (a.ga.enabled && (a.ga.Cs % GBK)) return EPI_ERR_UNSUPPORTED;     // a K tile must not straddle two taps
+    if (a.bn_in_on) {
+        // BatchNorm + ReLU on the A operand (plain rows, bf16 result): the 128 x 128 two-stage instantiation, statistics of the result from its epilogue
+        if (out_f32 || a.ga.enabled || a.sc.enabled || a.ph.enabled || nphase != 1 || a.K % GBK || a.K > 2048 || want_red.z || a.bias || a.addend || !a.coalesce ||
+            !a.bn_in.gamma || !a.bn_in.beta || !a.bn_in.scale || !a.bn_in.shift)
+            return EPI_ERR_UNSUPPORTED;
+        const GemmPlan pl = gemm_plan_cfg(CFG_SMALL, a.M, a.N, a.K, 1);
+        if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
+        if (pl.nsplit > 1) {
+            if (!workspace || (size_t)pl.nsplit * a.M * a.N * sizeof(float) > workspace_bytes) return EPI_ERR_WORKSPACE;
+            a.slabs = (float*)workspace;
+        }
+        a.k_per_split = pl.kps;
+        if (want_stats && pl.nsplit == 1) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
+        const int rc = launch_gemm_mode<false, CfgSmall, A_PLAIN, false, true>(a, pl, 1, st);
+        if (rc != EPI_OK) return rc;
+        if (pl.nsplit > 1) {
+            if (want_stats && a.N % 4 == 0) {
+                a.stats = want_stats;
+                if (stats_done) *stats_done = 1;
+                const unsigned blocks = (unsigned)(((a.M + FS_ROWS - 1) / FS_ROWS) * ((a.N + 255) / 256));
+                hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(blocks), dim3(256), 0, st, a.slabs, pl.nsplit, a);
+            } else {
+                const long long n = (long long)a.M * (a.N >> 2);
+                hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.slabs, pl.nsplit, 1, a);
+            }
+            EPI_CHECK_LAUNCH();
+        }
+        return EPI_OK;
+    }
     // short K, wide N, plain operands, bf16 result: the A-stationary kernel (the final 1x1 convolution forward)
     // (a launch that carries the fused BatchNorm-backward reduction stays on the generic kernel: the A-stationary kernel has no registers left
     //  to request a slice's z / y ahead of its MFMAs, and with them requested at their use it ran 84 .. 92 us instead of 19 .. 20 us --
@@ -1548,7 +1636,10 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             return EPI_OK;
         }
     }
-    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
+    // (a launch that carries the fused BatchNorm-backward reduction has a pipelined instantiation on the 128 x 128 tile only: a plan that comes
+    //  back with another tile AND the ring is redone without the ring)
+    GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
+    if (want_red.z && pl.pipe && pl.cfg != CFG_SMALL) pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32, false);
     if (pl.tiles > 0x7fffffffLL) return EPI_ERR_UNSUPPORTED;
     if (half_addend && pl.nsplit > 1) return EPI_ERR_UNSUPPORTED;          // (epi_conv2d_bwd_data_half_addend_ok tells the caller beforehand)
     if (pl.nsplit > 1) {
@@ -1557,13 +1648,14 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     }
     a.k_per_split = pl.kps;
     if (want_stats && pl.nsplit == 1 && a.coalesce && !a.bias) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
-    if (want_red.z && pl.nsplit == 1 && a.coalesce && !pl.pipe && (pl.cfg == CFG_BIG || pl.cfg == CFG_SMALL || pl.cfg == CFG_TALL)) {
+    if (want_red.z && pl.nsplit == 1 && a.coalesce && (!pl.pipe || pl.cfg == CFG_SMALL) && (pl.cfg == CFG_BIG || pl.cfg == CFG_SMALL || pl.cfg == CFG_TALL)) {
         a.br = want_red;
         *red_done = 1;
     }
     int rc;
     if (a.br.z) rc = pl.cfg == CFG_BIG ? launch_gemm_cfg<false, CfgBig, true>(a, pl, nphase, st)
-                   : (pl.cfg == CFG_TALL ? launch_gemm_cfg<false, CfgTall, true>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall, true>(a, pl, nphase, st));
+                   : (pl.cfg == CFG_TALL ? launch_gemm_cfg<false, CfgTall, true>(a, pl, nphase, st)
+                      : (pl.pipe ? launch_gemm_cfg<false, CfgSmallP, true>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall, true>(a, pl, nphase, st)));
     else if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
     else if (pl.cfg == CFG_HALF) rc = launch_gemm_cfg<false, CfgHalf>(a, pl, nphase, st);
@@ -1744,6 +1836,8 @@ struct GemmTnArgs {
     int gather;                   // 0: B row r, column j.  1: rows enumerate (n, ih, iw) over Hg x Wg; column j = tap*Cs + c reads
     int Hg, Wg, Hs, Ws, Cs;       //    B[n][ih*stride + kh - pad][iw*stride + kw - pad][c],  tap = kh*KW + kw
     int stride, pad, KW;
+    const float* b_bn;            // plain B only (grouped launches): B holds the RAW output z of the convolution in front and the operand is
+                                  // relu(z * b_bn[j] + b_bn[J + j]) -- the normalised activation the forward pass never wrote (GemmArgs::bn_in)
 };
 
 // Tile configurations (64 reduction rows per K tile; UNPADDED row-major tiles of COLS*2 bytes per row, filled by DMA):
@@ -1784,8 +1878,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col, i
 
 // One workgroup's share of a TN GEMM: output tile `tile_id` (tile_j fastest), reduction slice `split`.  Shared by the single-GEMM
 // kernel and the grouped kernel (many weight gradients in one launch).
-template <typename Cfg, bool GATHER>
+// eight consecutive r of ONE column (a lane's B operand) through relu(z * sc + sh): the arithmetic of bn_apply2d_kernel
+__device__ __forceinline__ bf16x8 tn_bn_apply(bf16x8 b, float sc, float sh) {
+    const uint4v u = __builtin_bit_cast(uint4v, b);
+    const unsigned int w[4] = {u.x, u.y, u.z, u.w};
+    unsigned int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+        o[k] = pack_bf16x2(fmaxf(lo * sc + sh, 0.f), fmaxf(hi * sc + sh, 0.f));
+    }
+    uint4v r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <typename Cfg, bool GATHER, bool BNB = false>
 __device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, const int split, char* smem) {
+    static_assert(!(GATHER && BNB), "BatchNorm on the B operand: plain rows only");
     constexpr int TI = Cfg::TI, BI = Cfg::BI, BJ = Cfg::BJ, AP = Cfg::A_PIECES, BP = Cfg::B_PIECES;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / Cfg::WJ, wn = wid % Cfg::WJ;
@@ -1884,6 +1993,14 @@ __device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, 
     __syncthreads();
     const int lane_c = lane & 15, grp = lane >> 4;
     const int cblk = 16 * (grp & 1), khalf = grp >> 1;
+    float bsc[2] = {0.f, 0.f}, bsh[2] = {0.f, 0.f};     // BNB: the lane's B column (one channel per tj) keeps its (scale, shift) for the whole reduction
+    if (BNB) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = j0 + wn * 64 + t * 32 + cblk + lane_c;
+            if (col < p.J) { bsc[t] = p.b_bn[col]; bsh[t] = p.b_bn[p.J + col]; }
+        }
+    }
     auto read_frags = [&](const char* a_s, const char* b_s, int ks, bf16x8 (&af)[TI], bf16x8 (&bfr)[2]) {
 #pragma unroll
         for (int t = 0; t < TI; ++t) af[t] = tr_frag<Cfg::A_ROWB>(a_s, ks * 16 + 8 * khalf, wm * (TI * 32) + t * 32 + cblk, lane_c);
@@ -1905,6 +2022,10 @@ __device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, 
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) read_frags(a_s, b_s, ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            if (BNB) {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) bfr[ks & 1][tj] = tn_bn_apply(bfr[ks & 1][tj], bsc[tj], bsh[tj]);
+            }
 #pragma unroll
             for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
@@ -1940,13 +2061,13 @@ __device__ __forceinline__ void tn_body(const GemmTnArgs& p, const int tile_id, 
     if (direct && p.out_bf16) store_tile(std::true_type{}); else store_tile(std::false_type{});
 }
 
-template <typename Cfg, bool GATHER>
+template <typename Cfg, bool GATHER, bool BNB = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) void head_gemm_tn_kernel(GemmTnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][A tile | B tile]
     // logical id: tile fastest, then split: the tiles of one split (same rows r) stay on one XCD
     const int total_wg = gridDim.x * gridDim.y;
     const int lid = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, total_wg);
-    tn_body<Cfg, GATHER>(p, lid % (int)gridDim.x, lid / (int)gridDim.x, smem);
+    tn_body<Cfg, GATHER, BNB>(p, lid % (int)gridDim.x, lid / (int)gridDim.x, smem);
 }
 
 // MANY weight gradients in one launch (a whole ResNet stage's backward-weight GEMMs, csrc/torch_glue.cpp): the deep layers at batch 32 have
@@ -1969,6 +2090,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WG_PER_CU * Cfg::THREADS / 256) 
     const int local = lid - gr.wg_begin;
     const int split = local / gr.tiles, tile_id = local - split * gr.tiles;
     if (gr.a.gather) tn_body<Cfg, true>(gr.a, tile_id, split, smem);
+    else if (gr.a.b_bn) tn_body<Cfg, false, true>(gr.a, tile_id, split, smem);
     else tn_body<Cfg, false>(gr.a, tile_id, split, smem);
 }
 
@@ -2077,15 +2199,15 @@ static TnPlan tn_plan(int R, int I, int J) {
     return best;
 }
 
-template <typename Cfg, bool GATHER>
+template <typename Cfg, bool GATHER, bool BNB = false>
 static int launch_tn_cfg(const GemmTnArgs& a, const TnPlan& pl, hipStream_t st) {
     const size_t lds = 2 * Cfg::STAGE_BYTES;
     if (lds > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_tn_kernel<Cfg, GATHER>),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_tn_kernel<Cfg, GATHER, BNB>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((head_gemm_tn_kernel<Cfg, GATHER>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), lds, st, a);
+    hipLaunchKernelGGL((head_gemm_tn_kernel<Cfg, GATHER, BNB>), dim3((unsigned)pl.tiles, (unsigned)pl.nsplit), dim3(Cfg::THREADS), lds, st, a);
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
@@ -2110,7 +2232,10 @@ static int launch_tn(GemmTnArgs a, void* out, int out_bf16, float* slab_ws, size
         a.C = out;
     }
     int rc;
-    if (pl.cfg == 2) rc = a.gather ? launch_tn_cfg<TnBig, true>(a, pl, st) : launch_tn_cfg<TnBig, false>(a, pl, st);
+    if (a.b_bn && a.gather) return EPI_ERR_UNSUPPORTED;
+    if (a.b_bn) rc = pl.cfg == 2 ? launch_tn_cfg<TnBig, false, true>(a, pl, st)
+                     : (pl.cfg == 1 ? launch_tn_cfg<TnNarrow, false, true>(a, pl, st) : launch_tn_cfg<TnSmall, false, true>(a, pl, st));
+    else if (pl.cfg == 2) rc = a.gather ? launch_tn_cfg<TnBig, true>(a, pl, st) : launch_tn_cfg<TnBig, false>(a, pl, st);
     else if (pl.cfg == 1) rc = a.gather ? launch_tn_cfg<TnNarrow, true>(a, pl, st) : launch_tn_cfg<TnNarrow, false>(a, pl, st);
     else rc = a.gather ? launch_tn_cfg<TnSmall, true>(a, pl, st) : launch_tn_cfg<TnSmall, false>(a, pl, st);
     if (rc != EPI_OK) return rc;
@@ -2212,11 +2337,14 @@ int group_item_args(const EpiWgradItem& it, GemmTnArgs* out) {
         a.A = (const unsigned short*)it.dy; a.B = (const unsigned short*)it.x; a.R = it.B * Ho * Wo; a.I = it.Cout; a.J = it.KH * it.KW * it.Cin;
         a.lda = it.Cout; a.ldb = it.Cin;
         if (!(it.KH == 1 && it.KW == 1 && it.stride == 1 && it.pad == 0)) {
+            if (it.x_scale_shift) return EPI_ERR_UNSUPPORTED;          // (an un-normalised input: 1x1 / stride-1 layers only)
             a.gather = 1; a.Hg = Ho; a.Wg = Wo; a.Hs = it.H; a.Ws = it.W; a.Cs = it.Cin; a.stride = it.stride; a.pad = it.pad; a.KW = it.KW;
         }
+        a.b_bn = it.x_scale_shift;
     } else {
         return EPI_ERR_UNSUPPORTED;
     }
+    if (it.kind != EPI_WGRAD_CONV2D && it.x_scale_shift) return EPI_ERR_UNSUPPORTED;
     a.out_bf16 = it.dw_dtype == EPI_BF16;
     if (a.I % 8 || a.J % 8 || a.lda % 8 || a.ldb % 8 || (a.gather && a.Cs % 8)) return EPI_ERR_UNSUPPORTED;
     if (a.gather && (long long)((a.R + a.Hg * a.Wg - 1) / (a.Hg * a.Wg)) * a.Hs * a.Ws * a.ldb >= (1LL << 31)) return EPI_ERR_UNSUPPORTED;
@@ -2349,6 +2477,18 @@ extern "C" int epi_wgrad_group(const EpiWgradItem* items, int n, void* slab_ws, 
         if (lrc != EPI_OK) return lrc;
     }
     return EPI_OK;
+}
+
+// ONE item by itself (its own reduction split; the per-layer path of a gradient somebody reads inside the backward pass, and the fallback of a
+// group whose slab arena is full): everything an item can describe, EpiWgradItem::x_scale_shift included.  workspace: epi_gemm_tn_workspace_bytes of
+// the item's GEMM; pending as epi_conv2d_bwd_weight_deferred (NULL: the slab sum runs right behind the GEMM).
+extern "C" int epi_wgrad_item(const EpiWgradItem* item, void* workspace, size_t workspace_bytes, EpiSlabReduce* pending, epi_stream_t stream) {
+    if (pending) *pending = EpiSlabReduce();
+    if (!item || !item->x || !item->dy || !item->dw) return EPI_ERR_INVALID_ARGUMENT;
+    GemmTnArgs a = {};
+    const int rc = group_item_args(*item, &a);
+    if (rc != EPI_OK) return rc;
+    return launch_tn(a, item->dw, item->dw_dtype == EPI_BF16, (float*)workspace, workspace_bytes, (hipStream_t)stream, pending);
 }
 
 extern "C" long long epi_slab_reduce_chunks(long long n) { return n > 0 ? (n / 2 + 255) / 256 : 0; }
@@ -2602,6 +2742,34 @@ extern "C" int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int 
                               int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
                               epi_stream_t stream) {
     return conv2d_fwd_impl(x, w, y, B, H, W, Cin, Cout, KH, KW, stride, pad, bn_sums, bn_sums_done, workspace, workspace_bytes, stream, false);
+}
+// 1x1 / stride-1 convolution whose INPUT is a raw convolution output still waiting for its BatchNorm (+ ReLU): y = conv(relu(bn(z))), the
+// normalised tensor is never written (GemmArgs::bn_in).  in_bn: the layer in front (its batch sums already in in_bn->sums_ws when in_training = 2;
+// in_training = 0: running statistics); the launch fills in_bn->mean / rstd / scale_shift, updates its running estimates and clears in_bn->bwd_sums
+// exactly as epi_bn_act_fwd(training = 2) would.  Anything it cannot do: EPI_ERR_UNSUPPORTED (the caller normalises first, as before).
+extern "C" int epi_conv1x1_fwd_bn_in(const void* z, const EpiBnLayer* in_bn, int in_training, float eps, float momentum, const void* w, void* y, int B, int H,
+                                     int W, int Cin, int Cout, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
+                                     epi_stream_t stream) {
+    if (bn_sums_done) *bn_sums_done = 0;
+    if (!z || !in_bn || !w || !y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (in_training != 0 && in_training != 2)) return EPI_ERR_INVALID_ARGUMENT;
+    if (!in_bn->gamma || !in_bn->beta || !in_bn->scale_shift || (in_training && (!in_bn->sums_ws || !in_bn->mean || !in_bn->rstd)) ||
+        (!in_training && (!in_bn->running_mean || !in_bn->running_var)))
+        return EPI_ERR_INVALID_ARGUMENT;
+    if (Cin % GBK || Cin > 2048 || Cout % 8 || deterministic()) return EPI_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = (const unsigned short*)z; a.Bt = (const unsigned short*)w; a.C = y;
+    a.M = B * H * W; a.N = Cout; a.K = Cin; a.lda = Cin; a.ldb = Cin; a.ldc = Cout;
+    a.stats = bn_sums;
+    a.stats_copies = epi_bn_sum_copies(Cout);
+    a.bn_in_on = 1;
+    BnAffine& n = a.bn_in;
+    const long long R = (long long)B * H * W;
+    n.sums = in_training ? in_bn->sums_ws : nullptr; n.ncopies = epi_bn_sum_copies(Cin); n.R = R; n.inv_r = 1.0 / (double)R;
+    n.gamma = in_bn->gamma; n.beta = in_bn->beta; n.eps = eps; n.momentum = momentum;
+    n.running_mean = in_bn->running_mean; n.running_var = in_bn->running_var; n.num_batches = in_bn->num_batches_tracked;
+    n.mean = in_bn->mean; n.rstd = in_bn->rstd; n.scale = in_bn->scale_shift; n.shift = in_bn->scale_shift + Cin;
+    n.bwd_sums = in_training ? in_bn->bwd_sums : nullptr;
+    return launch_gemm(a, false, 1, workspace, workspace_bytes, (hipStream_t)stream, bn_sums_done);
 }
 // fp32 result (y float [B][Ho][Wo][Cout]; operands bf16): the fp32-grade verification mode feeds split operands (csrc/precise.hip)
 extern "C" int epi_conv2d_fwd_f32(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,

@@ -149,6 +149,7 @@ struct SideStream {
         c10::weak_intrusive_ptr<c10::StorageImpl> dw;
         c10::Device dev;
         double flops, bytes;
+        Tensor x_stats;                                          // EpiWgradItem::x_scale_shift points into it: alive as long as x
     };
     std::vector<GroupItem> group;
 };
@@ -544,8 +545,7 @@ void side_group_flush() {
                     const int Ho = (it.H + 2 * it.pad - it.KH) / it.stride + 1, Wo = (it.W + 2 * it.pad - it.KW) / it.stride + 1;
                     const size_t need = epi_gemm_tn_workspace_bytes(it.B * Ho * Wo, it.Cout, it.Cin, it.KH * it.KW);
                     Tensor& ws = on_side ? side_workspace(need, first) : workspace(need, first);
-                    check(epi_conv2d_bwd_weight(it.x, it.dy, it.dw, it.dw_dtype, it.B, it.H, it.W, it.Cin, it.Cout, it.KH, it.KW, it.stride, it.pad,
-                                                ws.data_ptr(), (size_t)ws.numel(), st), "epi_conv2d_bwd_weight");
+                    check(epi_wgrad_item(&it, ws.data_ptr(), (size_t)ws.numel(), nullptr, st), "epi_wgrad_item");
                 }
             }
         } else {
@@ -559,7 +559,11 @@ void side_group_flush() {
         }
     }
     if (on_side)
-        for (auto& g : items) { S.keep.push_back(std::move(g.x)); S.keep.push_back(std::move(g.dy)); }
+        for (auto& g : items) {
+            S.keep.push_back(std::move(g.x));
+            S.keep.push_back(std::move(g.dy));
+            if (g.x_stats.defined()) S.keep.push_back(std::move(g.x_stats));
+        }
     end_of_pass_callback();
 }
 
@@ -826,12 +830,42 @@ struct StageSaved {       // what a stage's backward needs
     int K, S, P;
     bool relu, has_res, w_f32, need_dx;
     Tensor w;                           // the weight itself (a parameter or its training copy): consulted by the deferred-reduce rule
+    Tensor x_bn_stats;                  // defined: `x` is the RAW output of the stage in front and this stage's input was relu(bn(x)), never written
+                                        // (BnInput); [4C] mean | rstd | scale | shift of that BatchNorm, filled by this stage's convolution launch
 };
+
+// The BatchNorm + ReLU still pending on a stage's input: the stage in front ran its convolution only (defer_bn) and delivered its batch sums; this
+// stage's 1x1 convolution normalises its A operand on the fly (epi_conv1x1_fwd_bn_in) -- one apply launch and one tensor write + read less per
+// bottleneck (round 4).  MEASURED AND NOT ADOPTED (profiles/r04_ab_bn_in_fuse.txt, one box, interleaved arms): 16 apply launches and 0.13 ms of
+// BatchNorm time disappear, but the forward convolutions gain 0.10 ms (every workgroup derives the K-channel table, every wave transforms the
+// fragments it reads) and the weight gradients 0.085 ms (the TN kernel re-applies the affine to the same activation in every output tile: 4 .. 32x
+// redundant work beside its MFMAs) -- 6.363 / 6.380 ms per step with it against 6.317 / 6.345 ms without.  Off by default; EPI_BN_IN_FUSE=1 /
+// bn_in_fuse_mode(1) turns it on (tests/test_hip_conv.py keeps it correct).
+struct BnInput {
+    const StageParams* sp = nullptr;    // the stage in front
+    Tensor stats;                       // [4C], becomes that stage's saved statistics
+};
+int g_bn_in_fuse = -1;
+bool bn_in_fuse_enabled() {
+    if (g_bn_in_fuse < 0) { const char* e = getenv("EPI_BN_IN_FUSE"); g_bn_in_fuse = (e && e[0] == '1') ? 1 : 0; }
+    return g_bn_in_fuse != 0;
+}
+int bn_in_fuse_mode(int mode) {                 // test / measurement hook: returns the previous setting; a negative mode only queries
+    const int prev = bn_in_fuse_enabled() ? 1 : 0;
+    if (mode >= 0) g_bn_in_fuse = mode ? 1 : 0;
+    return prev;
+}
+int64_t g_bn_in_fused = 0;                       // convolutions that normalised their input themselves (tests count them)
+int64_t bn_in_fuse_count(bool reset) {
+    const int64_t v = g_bn_in_fused;
+    if (reset) g_bn_in_fused = 0;
+    return v;
+}
 
 // defer_bn: run the convolution (and its epilogue statistics) only and return the RAW output -- the caller normalises it together with another
 // stage's (dual_bn_forward); *sums_done_out then says whether the batch sums are already in sums_ws
 Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& residual, bool training, double momentum, double eps, bool need_dx,
-                     StageSaved* save, bool defer_bn = false, int* sums_done_out = nullptr) {
+                     StageSaved* save, bool defer_bn = false, int* sums_done_out = nullptr, const BnInput* bn_input = nullptr) {
     Tensor x = x_in;
     TORCH_CHECK(x.is_cuda() && sp.w.is_cuda(), "conv_bn_act: tensors must live on the GPU (no CPU fallback in epipolarpose_amd)");
     if (!nhwc_bf16(x)) x = x.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
@@ -855,7 +889,21 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
     }
     const double conv_flops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
     const double conv_bytes = 2.0 * ((double)x.numel() + (double)raw.numel() + (double)w.numel());
-    {
+    if (bn_input) {             // x is the raw output of the stage in front: normalised inside this launch (the caller checked the geometry)
+        const StageParams& ip = *bn_input->sp;
+        float* st = bn_input->stats.data_ptr<float>();
+        EpiBnLayer l;
+        l.gamma = ip.gamma.data_ptr<float>(); l.beta = ip.beta.data_ptr<float>();
+        l.running_mean = ip.running_mean.data_ptr<float>(); l.running_var = ip.running_var.data_ptr<float>();
+        l.num_batches_tracked = reinterpret_cast<long long*>(ip.num_batches.data_ptr<int64_t>());
+        l.mean = st; l.rstd = st + Cin; l.scale_shift = st + 2 * Cin;
+        l.sums_ws = ip.sums_ws.data_ptr<float>(); l.bwd_sums = ip.bwd_sums.data_ptr<float>();
+        ScopedTimer timer("conv_fwd", conv_flops, conv_bytes, current_stream(x));
+        check(epi_conv1x1_fwd_bn_in(x.data_ptr(), &l, training ? 2 : 0, (float)eps, (float)momentum, w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout,
+                                    training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                                    current_stream(x)), "epi_conv1x1_fwd_bn_in");
+        g_bn_in_fused += 1;
+    } else {
         ScopedTimer timer("conv_fwd", conv_flops, conv_bytes, current_stream(x));
         check(epi_conv2d_fwd(x.data_ptr(), w16.data_ptr(), raw.data_ptr(), B, H, W, Cin, Cout, K, K, S, P,
                              training ? sums_ws.data_ptr<float>() : nullptr, training ? &sums_done : nullptr, ws.data_ptr(),
@@ -895,8 +943,28 @@ Tensor stage_forward(const Tensor& x_in, const StageParams& sp, const Tensor& re
         save->K = K; save->S = S; save->P = P; save->relu = sp.relu; save->has_res = has_res; save->w_f32 = w.scalar_type() != at::kBFloat16;
         save->w = w;
         save->need_dx = need_dx;
+        save->x_bn_stats = bn_input ? bn_input->stats : Tensor();
     }
     return y;
+}
+
+// may the convolution of `next` normalise its own input (the raw output of a stage with `c_in` channels)?  (epi_conv1x1_fwd_bn_in's conditions)
+bool bn_input_eligible(const StageParams& next, int64_t c_in, bool training) {
+    return bn_in_fuse_enabled() && training && next.w.dim() == 4 && next.w.size(2) == 1 && next.w.size(3) == 1 && next.stride == 1 && next.pad == 0 &&
+           c_in % 64 == 0 && c_in <= 2048 && next.w.size(0) % 8 == 0 && epi_set_deterministic(-1) == 0;
+}
+// the separate pass after all: normalise `raw` of a stage that ran with defer_bn (its consumer turned out not to take it raw)
+Tensor finish_deferred_stage(const Tensor& raw, const StageParams& p, const Tensor& res, int sums_done, bool training, double momentum, double eps, StageSaved* sv) {
+    BnBuffers b{p.gamma, p.beta, p.running_mean, p.running_var, p.num_batches, p.sums_ws, p.bwd_sums, p.flags};
+    Tensor stats;
+    if (training && !sums_done) p.flags.data_ptr<int>()[0] = 0;
+    Tensor out_y = bn_forward(raw, res, b, training, momentum, eps, p.relu, &stats, training && sums_done != 0);
+    if (sv) {
+        sv->stats = stats;
+        sv->has_res = res.defined();
+        sv->y = (p.relu && res.defined()) ? out_y.detach() : Tensor();
+    }
+    return out_y;
 }
 
 // y = relu(bn_main(raw_main) + bn_proj(raw_proj)) in one pass (epi_bn_act_fwd_dual): the last stage of a residual unit with a projection shortcut.
@@ -1013,12 +1081,15 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
         if (!first_use) flush_pending_reduces();       // a second use of a shared weight: the engine adds it to the first on the main stream
         const bool after_pass = first_use && gradient_consumed_after_backward(sv.w);        // nobody reads this gradient before backward() returns
         const double wflops_g = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
+        // (x_bn_stats: x is the raw output of the stage in front -- the kernel re-applies that stage's BatchNorm + ReLU to its operand)
+        const float* x_ss = sv.x_bn_stats.defined() ? sv.x_bn_stats.data_ptr<float>() + 2 * Cin : nullptr;
         if (after_pass && defer_enabled() && group_mode() != 0) {      // leaves with its stage's other weight gradients (side_group_flush)
             EpiWgradItem it = {};
             it.x = x.data_ptr(); it.dy = g.dx.data_ptr(); it.dw = out.dw.data_ptr(); it.dw_dtype = sv.w_f32 ? EPI_F32 : EPI_BF16; it.kind = EPI_WGRAD_CONV2D;
             it.B = B; it.H = H; it.W = W; it.Cin = Cin; it.Cout = Cout; it.KH = K; it.KW = K; it.stride = S; it.pad = P;
+            it.x_scale_shift = x_ss;
             g_side.group.push_back(SideStream::GroupItem{it, x, g.dx, out.dw.storage().getWeakStorageImpl(), out.dw.device(), wflops_g,
-                                                         2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel())});
+                                                         2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel()), sv.x_bn_stats});
             end_of_pass_callback();
             return out;
         }
@@ -1030,16 +1101,18 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
         const bool on_side = side_mode() != 0 && after_pass && (slab_bytes == 0 || slabs != nullptr);
         const double wflops = 2.0 * B * Ho * Wo * (double)Cout * Cin * K * K;
         const double wbytes = 2.0 * ((double)x.numel() + (double)sv.raw.numel() + (double)out.dw.numel());
+        EpiWgradItem item = {};
+        item.x = x.data_ptr(); item.dy = g.dx.data_ptr(); item.dw = out.dw.data_ptr(); item.dw_dtype = sv.w_f32 ? EPI_F32 : EPI_BF16; item.kind = EPI_WGRAD_CONV2D;
+        item.B = B; item.H = H; item.W = W; item.Cin = Cin; item.Cout = Cout; item.KH = K; item.KW = K; item.stride = S; item.pad = P;
+        item.x_scale_shift = x_ss;
         if (on_side) {           // launched by side_run_jobs() when the node's main-stream work has been enqueued
-            const Tensor xin = x, dyin = g.dx, dwout = out.dw;
-            const bool w_f32 = sv.w_f32;
+            const Tensor xin = x, dyin = g.dx, dwout = out.dw, stats_keep = sv.x_bn_stats;
             g_side.jobs.push_back(SideStream::Job{x, g.dx, out.dw, [=](epi_stream_t st) {
                 EpiSlabReduce pend = {};
                 Tensor* ws = slabs ? nullptr : &side_workspace(slab_bytes, xin);
-                check(epi_conv2d_bwd_weight_deferred(xin.data_ptr(), dyin.data_ptr(), dwout.data_ptr(), w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
-                                                     K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
-                                                     slabs ? &pend : nullptr, st),
-                      "epi_conv2d_bwd_weight");
+                if (stats_keep.defined()) g_side.keep.push_back(stats_keep);
+                check(epi_wgrad_item(&item, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(), slabs ? &pend : nullptr, st),
+                      "epi_wgrad_item");
                 return pend;
             }, "conv_bwd_weight", wflops, wbytes});
         } else {
@@ -1047,10 +1120,8 @@ StageGrads stage_backward(const Tensor& dy, const StageSaved& sv, bool need_dx, 
             Tensor* ws = slabs ? nullptr : &workspace(slab_bytes, x);
             {
                 ScopedTimer timer("conv_bwd_weight", wflops, wbytes, current_stream(x));
-                check(epi_conv2d_bwd_weight_deferred(x.data_ptr(), g.dx.data_ptr(), out.dw.data_ptr(), sv.w_f32 ? EPI_F32 : EPI_BF16, B, H, W, Cin, Cout,
-                                                     K, K, S, P, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(),
-                                                     slabs ? &pend : nullptr, current_stream(x)),
-                      "epi_conv2d_bwd_weight");
+                check(epi_wgrad_item(&item, slabs ? slabs : ws->data_ptr(), slabs ? slab_bytes : (size_t)ws->numel(), slabs ? &pend : nullptr,
+                                     current_stream(x)), "epi_wgrad_item");
             }
             if (pend.nsplit > 0) pending_register(pend, out.dw);
         }
@@ -1290,8 +1361,36 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         const bool x_grad = x.requires_grad();
         if (training && x_grad) holder->in_link = link_claim(x);
         Tensor out = x;
-        for (int i = 0; i + 1 < n_main; ++i)
-            out = stage_forward(out, stage(i, true), Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i]);
+        // BatchNorm + ReLU of a stage whose consumer is a 1x1 / stride-1 convolution (the Bottleneck's bn2 -> conv3): left to that convolution's
+        // launch (BnInput) -- `pending` then travels with the raw tensor
+        std::vector<StageParams> sps;
+        sps.reserve(n_total);
+        for (int i = 0; i < n_total; ++i) sps.push_back(stage(i, i + 1 < n_main || i == n_main - 1));
+        sps[n_main - 1].relu = true;
+        if (has_downsample) sps[n_total - 1].relu = false;
+        BnInput pending;
+        for (int i = 0; i + 1 < n_main; ++i) {
+            const BnInput* in = pending.sp ? &pending : nullptr;
+            BnInput next_pending;
+            const int64_t c_out = sps[i].w.size(0);
+            if (bn_input_eligible(sps[i + 1], c_out, training)) {
+                int done = 0;
+                Tensor raw = stage_forward(out, sps[i], Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i], true, &done, in);
+                if (done) {             // the batch sums are in: the next convolution normalises its own input
+                    next_pending.sp = &sps[i];
+                    next_pending.stats = at::empty({4 * c_out}, sps[i].gamma.options().dtype(at::kFloat));
+                    holder->stages[i].stats = next_pending.stats;
+                    holder->stages[i].has_res = false;
+                    out = raw;
+                } else {
+                    out = finish_deferred_stage(raw, sps[i], Tensor(), done, training, momentum, eps, &holder->stages[i]);
+                }
+            } else {
+                out = stage_forward(out, sps[i], Tensor(), training, momentum, eps, i > 0 || x_grad, &holder->stages[i], false, nullptr, in);
+            }
+            pending = next_pending;
+        }
+        const BnInput* last_in = pending.sp ? &pending : nullptr;
         Tensor shortcut = x, y;
         if (has_downsample && bn_dual_enabled()) {
             // projection shortcut: both convolutions first, then ONE pass normalises both raw outputs, adds them and applies the ReLU -- the
@@ -1299,7 +1398,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
             int done_p = 0, done_m = 0;
             const StageParams pp = stage(n_total - 1, false), pm = stage(n_main - 1, true);
             Tensor raw_p = stage_forward(x, pp, Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1], true, &done_p);
-            Tensor raw_m = stage_forward(out, pm, Tensor(), training, momentum, eps, true, &holder->stages[n_main - 1], true, &done_m);
+            Tensor raw_m = stage_forward(out, pm, Tensor(), training, momentum, eps, true, &holder->stages[n_main - 1], true, &done_m, last_in);
             if (!training || done_p == done_m) {
                 y = dual_bn_forward(raw_m, pm, raw_p, pp, training, training && done_m, momentum, eps, training ? &holder->stages[n_main - 1] : nullptr,
                                     training ? &holder->stages[n_total - 1] : nullptr);
@@ -1319,7 +1418,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
             }
         } else {
             if (has_downsample) shortcut = stage_forward(x, stage(n_total - 1, false), Tensor(), training, momentum, eps, x_grad, &holder->stages[n_total - 1]);
-            y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1]);
+            y = stage_forward(out, stage(n_main - 1, true), shortcut, training, momentum, eps, true, &holder->stages[n_main - 1], false, nullptr, last_in);
         }
         ctx->saved_data["training"] = training;
         if (training) {
@@ -1782,6 +1881,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("wait_flush_ticket", &wait_flush_ticket, "the main stream of the device waits for the event behind a flush_pending_async ticket");
     m.def("flush_pending_reduces", &flush_pending_reduces,
           "sum the weight-gradient slabs parked by this backward pass now (the engine's final callback does it at the end of backward())");
+    m.def("bn_in_fuse_mode", &bn_in_fuse_mode, "BatchNorm + ReLU of a bottleneck interior inside the consuming 1x1 convolution's launch (1) or as its own pass (0, default); "
+          "returns the previous setting, a negative mode only queries");
+    m.def("bn_in_fuse_count", &bn_in_fuse_count, "convolutions that normalised their own input since the last reset");
     m.def("wgrad_stream_mode", &wgrad_stream_mode,
           "weight gradients on a second HIP stream: 0 off, 1 on, 2 on with the lowest stream priority; returns the previous setting");
     m.def("declare_hook_free", &declare_hook_free,

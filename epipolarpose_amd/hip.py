@@ -55,6 +55,7 @@ _SIGNATURES = {
     "epi_deconv4x4s2_bwd_data": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "epi_conv2d_workspace_bytes": (_sz, [_i] * 9),
     "epi_conv2d_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "epi_conv1x1_fwd_bn_in": (_i, [_vp, _vp, _i, ctypes.c_float, ctypes.c_float, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "epi_conv2d_pack_weight_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "epi_conv2d_pack_row_bytes": (_sz, []),
     "epi_conv2d_pack_fill_row": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "epi_wgrad_group_max": (_i, []),
     "epi_wgrad_group_plan": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]),
     "epi_wgrad_group": (_i, [_vp, _i, _vp, _sz, _vp, _vp]),
+    "epi_wgrad_item": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "epi_bn_sum_copies": (_i, [_i]),
     "epi_conv3x3_patch_mode": (_i, [_i]),
     "epi_gemm_tune": (_i, [_i, _i]),
@@ -710,7 +712,8 @@ def conv2d_bwd_weight(x, dy, kernel, stride=1, padding=0, dtype=torch.float32):
 
 
 class EpiWgradItem(ctypes.Structure):
-    _fields_ = [("x", _vp), ("dy", _vp), ("dw", _vp)] + [(k, _i) for k in ("dw_dtype", "kind", "B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
+    _fields_ = ([("x", _vp), ("dy", _vp), ("dw", _vp)] + [(k, _i) for k in ("dw_dtype", "kind", "B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad")]
+                + [("x_scale_shift", _vp)])        # (round 4: the input's pending BatchNorm, epipolar_hip.h; NULL = x is the activation itself)
 
 
 class EpiBnReduce(ctypes.Structure):

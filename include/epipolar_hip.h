@@ -343,6 +343,14 @@ int epi_gemm_store_policy(int policy);
 int epi_conv2d_fwd(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                    int stride, int pad, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes,
                    epi_stream_t stream);
+/* The 1x1 / stride-1 convolution behind a BatchNorm + ReLU WITHOUT the normalised tensor in between (`out = self.conv3(self.relu(self.bn2(out)))`,
+ * pose3d_resnet.py:76-82): z [B][H][W][Cin] is the raw output of the convolution in front, in_bn that layer's BatchNorm with the batch sums of z already in
+ * in_bn->sums_ws (in_training = 2; 0: running statistics).  The launch derives scale / shift itself, applies relu(z * scale + shift) to its A operand
+ * on the fly, fills in_bn->mean / rstd / scale_shift, updates the running estimates and clears in_bn->bwd_sums as epi_bn_act_fwd(training = 2) would;
+ * bn_sums / bn_sums_done as epi_conv2d_fwd.  Cin % 64 == 0, Cin <= 2048, Cout % 8 == 0; EPI_ERR_UNSUPPORTED otherwise and in deterministic mode (the
+ * caller then normalises first).  The weight gradient of such a layer: EpiWgradItem::x_scale_shift. */
+int epi_conv1x1_fwd_bn_in(const void* z, const EpiBnLayer* in_bn, int in_training, float eps, float momentum, const void* w, void* y, int B, int H, int W,
+                          int Cin, int Cout, float* bn_sums, int* bn_sums_done, void* workspace, size_t workspace_bytes, epi_stream_t stream);
 int epi_conv2d_pack_weight_bwd(const void* w, int Cout, int Cin, int KH, int KW, int stride, int pad, void* w_bwd,
                                epi_stream_t stream);
 /* The same for MANY layers in one launch (every backbone weight after an optimizer step).  The caller keeps a table of
@@ -403,10 +411,15 @@ typedef struct EpiWgradItem {
     void* dw;
     int dw_dtype, kind;
     int B, H, W, Cin, Cout, KH, KW, stride, pad;
+    const float* x_scale_shift;   /* NULL, or (EPI_WGRAD_CONV2D, 1x1 / stride 1 only) [2 Cin] f32: `x` is the RAW output z of the convolution in front and the
+                                     layer's input was relu(z * scale[c] + shift[c]) -- the tensor epi_conv1x1_fwd_bn_in never wrote; the kernel re-applies it */
 } EpiWgradItem;
 int epi_wgrad_group_max(void);
 int epi_wgrad_group_plan(const EpiWgradItem* items, int n, size_t* slab_bytes, int* nsplit);
 int epi_wgrad_group(const EpiWgradItem* items, int n, void* slab_ws, size_t slab_bytes, EpiSlabReduce* pending, epi_stream_t stream);
+/* One item by itself, with its own reduction split (= epi_conv2d_bwd_weight_deferred / epi_deconv4x4s2_bwd_weight for what those can describe, plus
+ * x_scale_shift).  workspace: epi_gemm_tn_workspace_bytes(rows, Cout, Cin, taps) of the item; pending NULL: the slab sum runs behind the GEMM. */
+int epi_wgrad_item(const EpiWgradItem* item, void* workspace, size_t workspace_bytes, EpiSlabReduce* pending, epi_stream_t stream);
 
 /* Weight gradients of the head (reduction over batch*pixels, fp32 results).  workspace: the split-K slabs,
  * epi_gemm_tn_workspace_bytes(R, I, J, ntap) bytes (J = columns per filter tap; ntap = 1 for epi_gemm_tn_bf16, 16 for the

@@ -407,6 +407,64 @@ def test_projection_batchnorm_in_one_pass(kind, training):
         assert float((a - b).norm()) <= 0.12 * float(b.norm()) + 1e-12, (k, float((a - b).norm()), float(b.norm()))
 
 
+@pytest.mark.parametrize("kind", ["bottleneck", "bottleneck_proj", "bottleneck_stride2", "bottleneck_wide"])
+@pytest.mark.parametrize("group", [2, 0])
+def test_bottleneck_interior_batchnorm_inside_the_consuming_convolution(kind, group):
+    """Round 4 (epi_conv1x1_fwd_bn_in + EpiWgradItem::x_scale_shift): conv3 of a Bottleneck normalises its own input -- relu(bn2(z2)) is never written,
+    the forward kernel applies it to its A fragments and the weight-gradient kernel re-applies it to its B fragments -- against the separate apply
+    pass of rounds 1-3.  The arithmetic is the apply kernel's on the same values, so the output and every gradient agree to the run-to-run level of
+    the statistics' atomics; the saved statistics / running estimates of bn2 are written by the convolution launch and must be the same numbers.
+    group 2 / 0: the weight gradient through the grouped launch / through its own launch (epi_wgrad_item)."""
+    import copy
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.models import pose3d_resnet as P
+    dev = torch.device("cuda:0")
+    inpl, planes, stride, hw, b = {"bottleneck": (256, 64, 1, 16, 8), "bottleneck_proj": (64, 64, 1, 16, 8), "bottleneck_stride2": (256, 128, 2, 16, 8),
+                                   "bottleneck_wide": (2048, 512, 1, 8, 4)}[kind]
+    torch.manual_seed(21)
+    base = P.ResidualUnit(inpl, planes, P._BOTTLENECK, stride).to(dev).to(memory_format=torch.channels_last)
+    assert base._unit is not None
+    for mod in base.modules():
+        if hasattr(mod, "running_mean"):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.normal_(1.0, 0.3)               # (a few negative scales as well: the mask test must follow the sign)
+            mod.bias.data.normal_(0.0, 0.3)
+    x = _rand((b, inpl, hw, hw), torch.Generator().manual_seed(22)).to(dev).contiguous(memory_format=torch.channels_last)
+    glue = hip.glue()
+    outs = []
+    group_before = glue.wgrad_group_mode(group)
+    try:
+        for fuse in (1, 0, 0):
+            prev = glue.bn_in_fuse_mode(fuse)
+            glue.bn_in_fuse_count(True)
+            try:
+                m = copy.deepcopy(base)
+                m.train()
+                xin = x.clone().requires_grad_(True)
+                y = m(xin)
+                dy = _rand(tuple(y.shape), torch.Generator().manual_seed(23)).to(dev).contiguous(memory_format=torch.channels_last)
+                y.backward(dy)
+                torch.cuda.synchronize()
+                grads = {k: p.grad.float().clone() for k, p in m.named_parameters()}
+                grads["x"] = xin.grad.float().clone()
+                outs.append((y.detach().float().clone(), grads, {k: v.detach().float().clone() for k, v in m.state_dict().items()}, glue.bn_in_fuse_count(True)))
+            finally:
+                glue.bn_in_fuse_mode(prev)
+    finally:
+        glue.wgrad_group_mode(group_before)
+    (ya, ga, sa, na), (yb, gb, sb, nb), (yc, gc, sc, nc) = outs
+    assert na == 1 and nb == 0 and nc == 0, (na, nb, nc)                 # conv3 took its input raw exactly once per forward
+    noise_y = float((yb - yc).abs().max())                               # two runs of the SAME (unfused) path: the level of the atomics
+    assert float((ya - yb).abs().max()) <= max(4.0 * noise_y, 2 ** -7 * float(yb.abs().max())), (float((ya - yb).abs().max()), noise_y)
+    for k in sa:
+        assert float((sa[k] - sb[k]).abs().max()) <= 1e-5 * max(1.0, float(sb[k].abs().max())), k
+    for k in ga:
+        a, bb, c = ga[k].reshape(-1).double(), gb[k].reshape(-1).double(), gc[k].reshape(-1).double()
+        noise = float((bb - c).norm())
+        assert float((a - bb).norm()) <= max(4.0 * noise, 2e-2 * float(bb.norm())) + 1e-12, (k, float((a - bb).norm()), noise, float(bb.norm()))
+
+
 def test_deferred_weight_gradient_reduction_matches_per_layer_reduction():
     """Split weight gradients summed by one launch at the end of backward() (the autograd engine's final callback) against one
     reduce per layer: the same slabs, fp32 sums in a different order; also when backward() runs twice in a row, when a gradient is
