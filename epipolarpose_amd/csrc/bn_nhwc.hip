@@ -56,9 +56,9 @@ __device__ __forceinline__ void slab_reduce_and_add(const float (&s)[V], const f
 __global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ part, int nblocks, int n, float* __restrict__ dst) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float t = 0.f;
-    for (int k = 0; k < nblocks; ++k) t += part[(long long)k * n + i];
-    dst[i] += t;
+    double t = 0.0;                         // (up to 1024 partial sums per channel: float64 keeps the ordered sum at least as accurate as the atomics)
+    for (int k = 0; k < nblocks; ++k) t += (double)part[(long long)k * n + i];
+    dst[i] += (float)t;
 }
 
 // sums[0..C) += sum x, sums[C..2C) += sum x^2     (sums zero on entry)

@@ -37,19 +37,24 @@ def cosine(a, b):
 #   * the bf16 PRODUCT path is held, for EVERY parameter and with no escape clause, to that fp32-grade mode at a trained, well-conditioned
 #     state of the same configuration (tests/trained_state.py) -- the check below.
 # (min cosine, 5th percentile, median) floors per configuration, set from the values measured on MI355X (gpurun_out/network_trained_state.json)
-# measured (call r04f, batch of the golden case): r18 0.987 / 0.991 / 0.999, r50 (128 x 128, batch 4) 0.857 / 0.879 / 0.969, cfg1 0.979 / 0.983 / 0.998,
-# cfg2 (batch 4) 0.922 / 0.932 / 0.986; ResNet-152 at its golden batch of 2 stays ill-conditioned after 10 steps (0.07 / 0.32 / 0.71 with the loss
-# equal to 6e-5), so configuration 5 is checked at batch 8.  The bench configuration itself at batch 32: tests/test_hip_precise.py.
-# (second run, call r04i: r18 0.978 / 0.986 / 0.999, r50 0.836 / 0.896 / 0.964, cfg1 0.975 / 0.981 / 0.998, cfg2 0.865 / 0.903 / 0.986, cfg5 at batch 8
-#  0.778 / 0.842 / 0.934; floors = the lower of the two runs minus a margin for the run-to-run variation of the trained state itself)
-TRAINED_FLOORS = {"r18": (0.94, 0.96, 0.99), "r50": (0.75, 0.82, 0.94), "cfg1_r18_128": (0.94, 0.95, 0.99), "cfg2_r50_256": (0.80, 0.85, 0.97),
-                  "cfg5_r152_384": (0.65, 0.75, 0.90)}
+# Measured on MI355X (tests/trained_state.py runs in deterministic mode: the same figures in every run of one build).  Ranges over the builds of round 4
+# (atomics, ordered fp32 sums, ordered float64 sums -- a change in the LAST BITS of the BatchNorm sums moves a trained state of 50 .. 152 bf16 layers this
+# far), as min / 5th percentile / median over ALL tensors | min / 5th percentile over the weight tensors proper (convolutions, deconvolutions, final layer):
+#   r18            0.956-0.989 / 0.973-0.992 / 0.994-0.999 | 0.979-0.987 / 0.980-0.992      r50 (128 x 128, batch 4)  0.776-0.898 / 0.838-0.914 / 0.935-0.986 | 0.874-0.886 / 0.877-0.889
+#   cfg1 (batch 2) 0.962-0.979 / 0.977-0.983 / 0.997-0.999 | 0.980-0.981 / 0.983-0.984      cfg2 (batch 4)            0.783-0.934 / 0.878-0.945 / 0.968-0.989 | 0.910-0.911 / 0.912-0.914
+#   cfg5 (batch 8) 0.635-0.781 / 0.727-0.872 / 0.934-0.995 | 0.711-0.803 / 0.734-0.817  -- ResNet-152 at its golden batch of 2 stays ill-conditioned after 10
+#   steps (0.07 / 0.32 / 0.71 with the losses equal to 6e-5), so configuration 5 is checked at batch 8.  The bench configuration at batch 32: tests/test_hip_precise.py.
+# The minima are stem / layer-1 tensors in every case (first convolution, first BatchNorm biases): 50 .. 150 layers of bf16 activations behind them; the head
+# (deconvolutions, final layer) is at >= 0.998 everywhere.  Floors = the lowest value seen minus 0.05: they catch a broken kernel (cosine ~0), not bf16 noise.
+TRAINED_FLOORS = {"r18": (0.90, 0.92, 0.97), "r50": (0.70, 0.78, 0.88), "cfg1_r18_128": (0.90, 0.92, 0.97), "cfg2_r50_256": (0.72, 0.82, 0.92),
+                  "cfg5_r152_384": (0.55, 0.65, 0.88)}
+TRAINED_FLOORS_WEIGHTS = {"r18": (0.92, 0.93), "r50": (0.82, 0.82), "cfg1_r18_128": (0.93, 0.93), "cfg2_r50_256": (0.85, 0.86), "cfg5_r152_384": (0.65, 0.68)}
 TRAINED_BATCH = {"cfg5_r152_384": 8}
 TRAINED_REPORT = {}
 LOSS_REL = {}
-# loss of the bf16 path against the live reference's fp32 loss, forward in deterministic mode (measured: 4e-4 r18, 6.6e-3 r50 -- a bf16 error of
+# loss of the bf16 path against the live reference's fp32 loss, forward in deterministic mode (measured: 4e-4 r18, 6.6e-3 / 8.1e-3 r50 -- a bf16 error of
 # THAT random-weight state, identical in every run --, <= 2e-6 at the full configurations, whose N(0, 0.001) head makes the loss insensitive)
-LOSS_RTOL = {"r50": 1e-2}
+LOSS_RTOL = {"r50": 1.5e-2}
 LOSS_RTOL_DEFAULT = 2e-3
 
 
@@ -139,6 +144,8 @@ def _check_network(g, name, layers, image, j, d, b, stride, head_std=None):
     assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= 5e-3 * rep["loss_precise"], rep["worst"]
     assert rep["head_min_cos"] >= 0.99, rep["head_min_cos"]
     assert rep["min_cos"] >= lo and rep["p05_cos"] >= p05 and rep["median_cos"] >= med, (rep["min_cos"], rep["p05_cos"], rep["median_cos"], rep["worst"])
+    wlo, wp05 = TRAINED_FLOORS_WEIGHTS[name]
+    assert rep["min_cos_weights"] >= wlo and rep["p05_cos_weights"] >= wp05, (rep["min_cos_weights"], rep["p05_cos_weights"], rep["worst_weights"])
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -257,6 +264,7 @@ def test_whole_network_used_twice_in_one_graph():
 
     glue = hip.glue()
     defer0, side0, group0 = glue.defer_wgrad_reduce(False), glue.wgrad_stream_mode(0), glue.wgrad_group_mode(0)
+    det0 = hip.set_deterministic(True)      # ordered BatchNorm sums: what is left between the arms is the summation order of the weight gradients
     try:
         ref = grads()
         for defer, side, group in ((True, 1, 2), (True, 1, 0), (False, 1, 2), (True, 0, 2)):
@@ -268,9 +276,10 @@ def test_whole_network_used_twice_in_one_graph():
                 assert torch.isfinite(got[k]).all(), (k, defer, side, group)
                 # run-to-run noise of a bf16 network with atomically summed BatchNorm statistics is a few % of the norm; a gradient the engine
                 # summed while one addend was still being written (or whose slab sum never ran) is O(1) wrong
-                assert float((got[k] - ref[k]).norm()) <= 0.15 * float(ref[k].norm()) + 1e-9, (k, defer, side, group)
-                assert cosine(got[k], ref[k]) >= 0.98 or float(ref[k].norm()) < 1e-9, (k, defer, side, group)
+                assert float((got[k] - ref[k]).norm()) <= 0.05 * float(ref[k].norm()) + 1e-9, (k, defer, side, group)
+                assert cosine(got[k], ref[k]) >= 0.998 or float(ref[k].norm()) < 1e-9, (k, defer, side, group)
     finally:
         glue.defer_wgrad_reduce(defer0)
         glue.wgrad_stream_mode(side0)
         glue.wgrad_group_mode(group0)
+        hip.set_deterministic(det0)

@@ -22,6 +22,20 @@ def bf16_vs_precise_at_trained_state(layers, image, j, d, b, steps=10, seed=7, t
     """`steps` Adam steps in the fp32-grade mode from a seeded initialisation (torch's default backbone initialisation, the reference's own
     N(0, 0.001) head, pose3d_resnet.py:222-239), then one forward + backward of BOTH paths on the same weights and batch.
     Returns dict(loss_precise, loss_bf16, cos{param: cosine}, min_cos, p05_cos, median_cos, head_min_cos, n_params)."""
+    from epipolarpose_amd import hip
+    # ordered BatchNorm sums in BOTH paths and deterministic library convolutions (the fp32-grade mode leaves the 7x7 stem to MIOpen): removes most of
+    # the run-to-run spread of the trained state (what is left comes from the library's stem kernels)
+    was = hip.set_deterministic(True)
+    cd, cb = torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    try:
+        return _compare(layers, image, j, d, b, steps, seed, tag)
+    finally:
+        hip.set_deterministic(was)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = cd, cb
+
+
+def _compare(layers, image, j, d, b, steps, seed, tag):
     from epipolarpose_amd.core.config import default_config
     from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
     from epipolarpose_amd.models import precise
@@ -62,12 +76,18 @@ def bf16_vs_precise_at_trained_state(layers, image, j, d, b, steps=10, seed=7, t
     loss16 = crit(logits, gt, wt)
     loss16.backward()
     torch.cuda.synchronize()
-    cos = {}
+    cos, dims = {}, {}
     for k, p in model.named_parameters():
         if p.grad is not None:
             cos[k] = cosine(p.grad.float().cpu(), sd[k].grad.cpu())
+            dims[k] = p.dim()
     vals = np.sort(np.asarray(list(cos.values())))
     head = [v for k, v in cos.items() if k.startswith(("deconv_layers", "final_layer"))]
+    # the weight tensors proper (convolutions, deconvolutions, the final layer) apart from the BatchNorm scales / biases, whose gradients are the
+    # small differences of large sums that bf16 activations hurt most (the minima over ALL tensors are always layer-1 / stem BatchNorm biases)
+    wvals = np.sort(np.asarray([v for k, v in cos.items() if dims[k] >= 2]))
     return {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item()), "cos": cos, "n_params": len(cos),
             "min_cos": float(vals[0]), "p05_cos": float(vals[len(vals) // 20]), "median_cos": float(np.median(vals)), "head_min_cos": float(min(head)),
-            "worst": sorted(cos.items(), key=lambda kv: kv[1])[:5]}
+            "n_weights": int(len(wvals)), "min_cos_weights": float(wvals[0]), "p05_cos_weights": float(wvals[len(wvals) // 20]),
+            "median_cos_weights": float(np.median(wvals)), "worst": sorted(cos.items(), key=lambda kv: kv[1])[:5],
+            "worst_weights": sorted(((k, v) for k, v in cos.items() if dims[k] >= 2), key=lambda kv: kv[1])[:3]}

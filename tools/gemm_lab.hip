@@ -4,7 +4,8 @@
 //                             same K offsets in lock step) against padded pitches and against a per-workgroup K rotation
 //   gemm_lab gemm             the real kernels through the C ABI (libepipolar_hip.so): ResNet-50 layer shapes at batch 32, padded pitches,
 //                             tile / pipeline overrides, operands rotating through > 600 MB of buffers (nothing L2- or MALL-resident) or warm
-//   gemm_lab conv             3x3 layers through epi_conv2d_fwd: patch kernel vs generic gather kernel, rotation on / off
+//   gemm_lab conv             3x3 layers through epi_conv2d_fwd: patch kernel vs generic gather kernel
+//   gemm_lab layers [batch]   the per-layer table of all 22 distinct ResNet-50 convolutions: forward / backward-data / backward-weight, us per launch
 //
 // Every figure is the mean over back-to-back launches on one stream between two HIP events (no host work between launches).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/gemm_lab_bin tools/gemm_lab.hip -Lepipolarpose_amd/_lib -lepipolar_hip -Wl,-rpath,'$ORIGIN/../epipolarpose_amd/_lib'
@@ -200,6 +201,66 @@ static void conv_battery() {
     epi_conv3x3_patch_mode(2);
 }
 
+// Every distinct ResNet-50 convolution behind the stem at batch 32: forward (with the BatchNorm sums from its epilogue, as the step runs it), backward-data
+// and backward-weight (one launch per layer; the step groups these per ResNet stage), back-to-back launches on operands that rotate through the arena.
+// The C++ successor of tools/bench_conv.py, whose Python launch path put a ~12 us floor under every entry (profiles/r03_conv_layers_final.txt).
+static void layers_table(int batch) {
+    struct L { const char* name; int n, Cin, Cout, k, s, H; };
+    const L layers[] = {{"l1.c1", 1, 64, 64, 1, 1, 64},    {"l1.c2", 3, 64, 64, 3, 1, 64},     {"l1.c3", 4, 64, 256, 1, 1, 64},   {"l1.c1", 2, 256, 64, 1, 1, 64},
+                        {"l2.c1", 1, 256, 128, 1, 1, 64},  {"l2.c2", 1, 128, 128, 3, 2, 64},   {"l2.c3", 4, 128, 512, 1, 1, 32},  {"l2.ds", 1, 256, 512, 1, 2, 64},
+                        {"l2.c1", 3, 512, 128, 1, 1, 32},  {"l2.c2", 3, 128, 128, 3, 1, 32},   {"l3.c1", 1, 512, 256, 1, 1, 32},  {"l3.c2", 1, 256, 256, 3, 2, 32},
+                        {"l3.c3", 6, 256, 1024, 1, 1, 16}, {"l3.ds", 1, 512, 1024, 1, 2, 32},  {"l3.c1", 5, 1024, 256, 1, 1, 16}, {"l3.c2", 5, 256, 256, 3, 1, 16},
+                        {"l4.c1", 1, 1024, 512, 1, 1, 16}, {"l4.c2", 1, 512, 512, 3, 2, 16},   {"l4.c3", 3, 512, 2048, 1, 1, 8},  {"l4.ds", 1, 1024, 2048, 1, 2, 16},
+                        {"l4.c1", 2, 2048, 512, 1, 1, 8},  {"l4.c2", 2, 512, 512, 3, 1, 8}};
+    printf("# ResNet-50 convolutions behind the stem, batch %d, 256x256 input; us per launch (HIP events around back-to-back launches, operands rotating through\n", batch);
+    printf("# %zu MiB: nothing L2- or MALL-resident between launches); bound = max(2.5 PF, 8 TB/s on x + y + w); TF = algorithmic TFLOP/s of the forward\n", g_arena_bytes >> 20);
+    printf("%-7s %2s %5s %5s %1s %1s %3s | %7s | %-13s | %-13s | %-13s\n", "layer", "n", "Cin", "Cout", "k", "s", "H", "GFLOP", "fwd us/bound", "dgrad us/bound", "wgrad us/bound");
+    double tot[3] = {0, 0, 0}, tot_bound = 0, tot_flops = 0;
+    for (const L& l : layers) {
+        const int pad = l.k / 2, Ho = (l.H + 2 * pad - l.k) / l.s + 1;
+        const size_t x_b = (size_t)batch * l.H * l.H * l.Cin * 2, w_b = (size_t)l.Cout * l.k * l.k * l.Cin * 2, y_b = (size_t)batch * Ho * Ho * l.Cout * 2;
+        const size_t sums_b = 4 * 2 * (size_t)l.Cout * 4;
+        const size_t set = ((x_b + 2 * w_b + 2 * y_b + x_b + sums_b + 4095) / 4096) * 4096;          // x | w | w_bwd | y | dy | dx | sums
+        const size_t ws_b = std::max(epi_conv2d_workspace_bytes(batch, l.H, l.H, l.Cin, l.Cout, l.k, l.k, l.s, pad),
+                                     epi_gemm_tn_workspace_bytes(batch * Ho * Ho, l.Cout, l.Cin, l.k * l.k));
+        char* ws = g_arena;
+        char* sets = g_arena + (ws_b + 4095) / 4096 * 4096;
+        const int nset = (int)std::max<size_t>(1, std::min<size_t>(32, (g_arena_bytes - (sets - g_arena)) / set));
+        hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (unsigned short*)g_arena, g_arena_bytes / 2, 777u);
+        int rc = 0;
+        for (int i = 0; i < nset; ++i) {
+            char* b = sets + (size_t)i * set;
+            rc |= epi_conv2d_pack_weight_bwd(b + x_b, l.Cout, l.Cin, l.k, l.k, l.s, pad, b + x_b + w_b, 0);
+            CK(hipMemsetAsync(b + 2 * x_b + 2 * w_b + 2 * y_b, 0, sums_b, 0));
+        }
+        double us[3];
+        us[0] = time_launches(30, [&](int i) {
+            char* b = sets + (size_t)(i % nset) * set;
+            int done = 0;
+            rc |= epi_conv2d_fwd(b, b + x_b, b + x_b + 2 * w_b, batch, l.H, l.H, l.Cin, l.Cout, l.k, l.k, l.s, pad, (float*)(b + 2 * x_b + 2 * w_b + 2 * y_b), &done, ws, ws_b, 0);
+        });
+        us[1] = time_launches(30, [&](int i) {
+            char* b = sets + (size_t)(i % nset) * set;
+            rc |= epi_conv2d_bwd_data(b + x_b + 2 * w_b + y_b, b + x_b + w_b, b + x_b + 2 * w_b + 2 * y_b, batch, l.H, l.H, l.Cin, l.Cout, l.k, l.k, l.s, pad, nullptr, ws, ws_b, 0);
+        });
+        us[2] = time_launches(30, [&](int i) {
+            char* b = sets + (size_t)(i % nset) * set;
+            rc |= epi_conv2d_bwd_weight(b, b + x_b + 2 * w_b + y_b, b + x_b, EPI_BF16, batch, l.H, l.H, l.Cin, l.Cout, l.k, l.k, l.s, pad, ws, ws_b, 0);
+        });
+        const double flops = 2.0 * batch * Ho * Ho * (double)l.Cout * l.Cin * l.k * l.k;
+        const double bound = std::max(flops / 2.5e15, (double)(x_b + y_b + w_b) / 8e12) * 1e6;
+        printf("%-7s %2d %5d %5d %1d %1d %3d | %7.2f | %6.1f /%5.1f | %6.1f /%5.1f | %6.1f /%5.1f   fwd %4.0f TF (%.2f of bound)%s\n", l.name, l.n, l.Cin, l.Cout, l.k, l.s, l.H,
+               flops * 1e-9, us[0], bound, us[1], bound, us[2], bound, flops / us[0] * 1e-6, bound / us[0], rc ? "  rc != 0" : "");
+        for (int k = 0; k < 3; ++k) tot[k] += l.n * us[k];
+        tot_bound += l.n * bound;
+        tot_flops += l.n * flops;
+    }
+    printf("# total ours   fwd %7.1f us  dgrad %7.1f us  wgrad %7.1f us  sum %7.1f us  -> %6.1f TFLOP/s over 3 x %.1f GFLOP\n", tot[0], tot[1], tot[2],
+           tot[0] + tot[1] + tot[2], 3 * tot_flops / (tot[0] + tot[1] + tot[2]) * 1e-6, tot_flops * 1e-9);
+    printf("# total bound  fwd %7.1f us  dgrad %7.1f us  wgrad %7.1f us  sum %7.1f us\n", tot_bound, tot_bound, tot_bound, 3 * tot_bound);
+    printf("# (MIOpen / CK on the same shapes through PyTorch, round 3, profiles/r03_conv_layers_final.txt: fwd 1001 / dgrad 1544 / wgrad 1641 us with ~12 us of Python per call in it)\n");
+}
+
 int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -215,5 +276,6 @@ int main(int argc, char** argv) {
     if (!strcmp(what, "probe") || !strcmp(what, "all")) probe();
     if (!strcmp(what, "gemm") || !strcmp(what, "all")) gemm_battery(quick);
     if (!strcmp(what, "conv") || !strcmp(what, "all")) conv_battery();
+    if (!strcmp(what, "layers")) layers_table(argc > 2 ? atoi(argv[2]) : 32);
     return 0;
 }
