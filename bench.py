@@ -358,7 +358,7 @@ def refiner_leg(args, device):
             "train_ms_per_step": round(train_ms, 4), "train_samples_per_s": round(64 / (train_ms * 1e-3), 1), "final_loss": round(float(loss.item()), 6)}
 
 
-PMC_FILE = "profiles/r03_pmc_step_families.json"
+PMC_FILE = "profiles/r04_pmc_step_families.json"
 
 
 def pmc_traffic(default_workload):
