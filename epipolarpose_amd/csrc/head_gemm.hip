@@ -1636,6 +1636,9 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             return EPI_OK;
         }
     }
+    // (round 4, measured and not kept: under-filled launches with fused column sums -- 64 .. 128 tiles of 128 x 128 in layers 3 / 4 at batch 32 -- unsplit on
+    //  64 x 128 tiles with the reduction in their epilogue: 3 .. 5 separate reduction launches go, the step gets 2 % SLOWER (6.25 -> 6.39 ms; with the 3x3
+    //  launches moved off the patch kernel as well 6.62 ms), profiles/r04_ab_underfill_half_tiles.txt)
     // (a launch that carries the fused BatchNorm-backward reduction has a pipelined instantiation on the 128 x 128 tile only: a plan that comes
     //  back with another tile AND the ring is redone without the ring)
     GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.ldc, nphase, out_f32);
