@@ -16,7 +16,11 @@
 #include "bn_affine.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
+#include <utility>
+#include <vector>
 
 namespace epi {
 
@@ -2373,30 +2377,72 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
         row.ktiles = (row.a.R + GBK - 1) / GBK;
         row.n = (long long)row.a.I * row.a.J;
     }
-    static const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
+    static const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
+    // the choice depends on the shapes only: remembered per (class, shapes) -- a training step asks for the same four groups every pass
+    static std::mutex memo_lock;
+    static std::unordered_map<unsigned long long, int> memo;
     for (int cls = 0; cls < 2; ++cls) {
         const double t_tile = cls ? 0.7 : 1.0, t_fixed = cls ? 3.0 : 4.0;
         // EPI_TN_GROUP_SLOTS=<percent>: the same knob for the grouped launches (measured: 100 / 70 / 50 / 35 -> 6.440 / 6.441 / 6.466 / 6.509 ms: off)
         static const int group_percent = [] { const char* e = getenv("EPI_TN_GROUP_SLOTS"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
+        // EPI_TN_GROUP_MODEL=0: the round-3 estimate, total workgroup time / resident workgroups -- blind to the SECOND ROUND a launch of 860
+        // workgroups needs on 768 slots (layer 1 of ResNet-50 at batch 32: the launch took 144 us for 302 MB, 2.1 TB/s, alone on the chip).
+        // 1 (default, round 4): the makespan of the launch's workgroups on `slots` slots, longest first (the order they are launched in)
+        static const bool lpt_model = [] { const char* e = getenv("EPI_TN_GROUP_MODEL"); return !(e && e[0] == '0'); }();
         const long long slots = (cls ? 768 : 512) * group_percent / 100;
-        double best_t = 1e30;
-        int best_T = 1 << 30;
-        for (int T : cand) {
-            double work = 0, longest = 0, slab = 0;
-            long long wgs = 0;
-            for (int r = 0; r < n; ++r) {
-                const GroupRowPlan& row = gp->rows[r];
-                if (row.cls != cls) continue;
-                const int ns = std::max(1, (row.ktiles + T - 1) / T), kt = (row.ktiles + ns - 1) / ns;
-                const double t_wg = kt * t_tile + t_fixed;
-                work += (double)row.tiles * ns * t_wg;
-                wgs += row.tiles * ns;
-                longest = std::max(longest, t_wg);
-                if (ns > 1) slab += (double)ns * row.n * 8.0 / 3.0e6;
+        unsigned long long key = 1469598103934665603ULL ^ (unsigned long long)(cls + 2 * group_percent + 1000 * (lpt_model ? 1 : 0));
+        int members = 0;
+        for (int r = 0; r < n; ++r) {
+            const GroupRowPlan& row = gp->rows[r];
+            if (row.cls != cls) continue;
+            ++members;
+            for (unsigned long long v : {(unsigned long long)row.tiles, (unsigned long long)row.ktiles, (unsigned long long)row.n}) { key ^= v; key *= 1099511628211ULL; }
+        }
+        if (members == 0) continue;
+        int best_T = -1;
+        {
+            std::lock_guard<std::mutex> g(memo_lock);
+            auto it = memo.find(key);
+            if (it != memo.end()) best_T = it->second;
+        }
+        if (best_T < 0) {
+            double best_t = 1e30;
+            best_T = 1 << 30;
+            std::vector<std::pair<double, long long>> jobs;
+            std::vector<double> heap;
+            for (int T : cand) {
+                double work = 0, longest = 0, slab = 0;
+                long long wgs = 0;
+                jobs.clear();
+                for (int r = 0; r < n; ++r) {
+                    const GroupRowPlan& row = gp->rows[r];
+                    if (row.cls != cls) continue;
+                    const int ns = std::max(1, (row.ktiles + T - 1) / T), kt = (row.ktiles + ns - 1) / ns;
+                    const double t_wg = kt * t_tile + t_fixed;
+                    work += (double)row.tiles * ns * t_wg;
+                    wgs += row.tiles * ns;
+                    longest = std::max(longest, t_wg);
+                    jobs.emplace_back(t_wg, row.tiles * ns);
+                    if (ns > 1) slab += (double)ns * row.n * 8.0 / 3.0e6;
+                }
+                double span = std::max(work / (double)std::min(slots, wgs), longest);
+                if (lpt_model && wgs > slots && wgs <= 16 * slots) {
+                    std::sort(jobs.begin(), jobs.end(), [](const std::pair<double, long long>& x, const std::pair<double, long long>& y) { return x.first > y.first; });
+                    heap.assign((size_t)slots, 0.0);                       // min-heap of the slots' free times
+                    auto cmp = [](double x, double y) { return x > y; };
+                    for (const auto& j : jobs)
+                        for (long long c = 0; c < j.second; ++c) {
+                            std::pop_heap(heap.begin(), heap.end(), cmp);
+                            heap.back() += j.first;
+                            std::push_heap(heap.begin(), heap.end(), cmp);
+                        }
+                    span = *std::max_element(heap.begin(), heap.end());
+                }
+                const double t = span + slab + (slab > 0 ? 3.0 : 0.0);
+                if (t < best_t) { best_t = t; best_T = T; }
             }
-            if (wgs == 0) break;
-            const double t = std::max(work / (double)std::min(slots, wgs), longest) + slab + (slab > 0 ? 3.0 : 0.0);
-            if (t < best_t) { best_t = t; best_T = T; }
+            std::lock_guard<std::mutex> g(memo_lock);
+            memo[key] = best_T;
         }
         for (int r = 0; r < n; ++r) {
             GroupRowPlan& row = gp->rows[r];

@@ -71,7 +71,13 @@ def main():
             slab += sb
             ns += nn
         gtotal += slab
-        print("%-22s %6d %9d %9d %10.1f" % (g[0][0].rsplit(".", 1)[0] + " .. " + g[-1][0].rsplit(".", 1)[0], len(g), sum(1 for v in ns if v == 1), max(ns), slab / 1e6))
+        # workgroups per launch: tiles x splits, by tile class (64 x 128 tiles for <= 64 output channels on 768 slots, 128 x 128 on 512)
+        wg = [0, 0]
+        for (_, cin, cout, k, s, h), v in zip(g, ns):
+            cls = 1 if cout <= 64 else 0
+            wg[cls] += -(-cout // (64 if cls else 128)) * -(-(k * k * cin) // 128) * v
+        print("%-22s %6d %9d %9d %10.1f   workgroups: %d of 128x128 (512 slots), %d of 64x128 (768 slots)" % (
+            g[0][0].rsplit(".", 1)[0] + " .. " + g[-1][0].rsplit(".", 1)[0], len(g), sum(1 for v in ns if v == 1), max(ns), slab / 1e6, wg[0], wg[1]))
     print("# %d groups, %.0f MB of fp32 slabs per backward pass" % (len(groups), gtotal / 1e6))
 
 
