@@ -27,6 +27,16 @@ class _SoftArgmaxLoss(torch.autograd.Function):
     def backward(ctx, grad_out):
         preds, rmax, rsum, xyz, gxyz = ctx.saved_tensors
         gscale = grad_out.to(torch.float32).contiguous()
+        # channels-last logits: the kernel also delivers the per-channel sums of the gradient it writes -- the bias gradient of the final 1x1 convolution,
+        # which that layer's backward then takes instead of re-reading the whole gradient (csrc/torch_glue.cpp take_column_sums; it checks that the
+        # tensor it receives is this very memory, unmodified, and computes the sums itself otherwise)
+        glue = hip.glue()
+        if preds.dim() == 4 and preds.is_contiguous(memory_format=torch.channels_last) and not preds.is_contiguous() and glue.column_sums_wanted():
+            sums = torch.zeros(preds.shape[1], dtype=torch.float32, device=preds.device)
+            dlogits, delivered = hip.softargmax3d_bwd(preds, ctx.num_joints, rmax, rsum, xyz, gxyz, gscale, col_sums=sums)
+            if delivered:
+                glue.offer_column_sums(dlogits, sums)
+            return dlogits, None, None, None, None, None, None
         dlogits = hip.softargmax3d_bwd(preds, ctx.num_joints, rmax, rsum, xyz, gxyz, gscale)
         return dlogits, None, None, None, None, None, None
 

@@ -222,11 +222,16 @@ __global__ void softargmax_combine_kernel(const SoftPartial* __restrict__ part, 
     xyz[3 * (long long)row + 2] = ez * inv / D - 0.5f;      // :83
 }
 
-template <typename T, int VEC, bool NHWC>
+// COLSUM (NHWC only): also accumulate, per channel c = j*D + d, the sum over batch and pixels of the gradient AS STORED (rounded to T) into
+// col_sums[C] -- the bias gradient of the 1x1 convolution that produced the logits (pose3d_resnet.py:116-122), which otherwise costs one more read of
+// the 285 MB gradient (epi_column_sums_bf16).  A thread's vector covers VEC consecutive depth bins d0 .. d0+VEC-1 of its row's joint and keeps them
+// for the whole chunk (the launcher checks SA_THREADS * VEC % D == 0); threads that share d0 are D / VEC apart.
+template <typename T, int VEC, bool NHWC, bool COLSUM = false>
 __global__ __launch_bounds__(SA_THREADS) void softargmax_bwd_kernel(const T* __restrict__ logits, RowGeom g, int nchunk,
                                                                     const float* __restrict__ row_max, const float* __restrict__ row_sum,
                                                                     const float* __restrict__ xyz, const float* __restrict__ gxyz,
-                                                                    const float* __restrict__ gscale, T* __restrict__ dlogits) {
+                                                                    const float* __restrict__ gscale, T* __restrict__ dlogits, float* __restrict__ col_sums) {
+    static_assert(!COLSUM || NHWC, "column sums: channels-last gradients only");
     const int row = blockIdx.x / nchunk;
     const int chunk = blockIdx.x - row * nchunk;
     const int tid = threadIdx.x;
@@ -245,6 +250,9 @@ __global__ __launch_bounds__(SA_THREADS) void softargmax_bwd_kernel(const T* __r
     float q0, q1, q2;     // coefficient of each abstract coordinate
     if (NHWC) { q0 = gz / (float)g.E0; q1 = gx / (float)g.E1; q2 = gy / (float)g.E2; }
     else      { q0 = gx / (float)g.E0; q1 = gy / (float)g.E1; q2 = gz / (float)g.E2; }
+    float cs[COLSUM ? VEC : 1];
+#pragma unroll
+    for (int k = 0; k < (COLSUM ? VEC : 1); ++k) cs[k] = 0.f;
 
     int e = e_begin;
 #pragma unroll 1
@@ -272,6 +280,31 @@ __global__ __launch_bounds__(SA_THREADS) void softargmax_bwd_kernel(const T* __r
                 d[k] = p * (t0[u] + q0 * (float)k);
             }
             VecIO<T, VEC>::store(dlogits + off[u], d);
+            if (COLSUM) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) cs[k] += sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(d[k])) : d[k];
+            }
+        }
+    }
+    if (COLSUM) {
+        // threads tid, tid + P, tid + 2P, ... (P = D / VEC, a power of two <= 64) hold the same depth bins: butterfly over the lanes of a wave that
+        // differ in the bits above log2(P), then one LDS row per wave, then one atomic per channel of the joint
+        __shared__ float wsum[SA_THREADS / 64][64 * VEC];
+        const int P = g.E0 / VEC, lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            for (int o = 32; o >= P; o >>= 1) cs[k] += __shfl_xor(cs[k], o, 64);
+        if (lane < P) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) wsum[wid][lane * VEC + k] = cs[k];
+        }
+        __syncthreads();
+        if (tid < g.E0) {                     // (depth bin tid of the row's joint: lane (tid / VEC) of every wave holds it at slot tid)
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SA_THREADS / 64; ++w) v += wsum[w][tid];
+            const int j = row % g.J;
+            atomicAdd(col_sums + (long long)j * g.E0 + tid, v);
         }
     }
 }
@@ -409,20 +442,38 @@ extern "C" int epi_softargmax3d_fwd(const void* logits, int dtype, int layout, i
 
 template <typename T, bool NHWC>
 static int launch_bwd(const T* logits, RowGeom g, int rows, bool vec, const float* row_max, const float* row_sum,
-                      const float* xyz, const float* gxyz, const float* gscale, T* dlogits, hipStream_t st) {
+                      const float* xyz, const float* gxyz, const float* gscale, T* dlogits, hipStream_t st, float* col_sums = nullptr, int* col_sums_done = nullptr) {
     const int nchunk = chunks_for(g.N, vec ? Elem<T>::VEC : 1);
     const unsigned grid = (unsigned)((long long)rows * nchunk);
-    if (vec)
-        hipLaunchKernelGGL((softargmax_bwd_kernel<T, Elem<T>::VEC, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, row_max, row_sum, xyz, gxyz, gscale, dlogits);
-    else
-        hipLaunchKernelGGL((softargmax_bwd_kernel<T, 1, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, row_max, row_sum, xyz, gxyz, gscale, dlogits);
+    if (col_sums_done) *col_sums_done = 0;
+    if (vec) {
+        constexpr int V = Elem<T>::VEC;
+        // the fused column sums: a thread must keep its depth bins from vector to vector, and the threads that share them must be a power of two apart
+        const int P = g.E0 / V;
+        const bool colsum_ok = NHWC && col_sums && col_sums_done && !deterministic() && g.E0 % V == 0 && (SA_THREADS * V) % g.E0 == 0 && P >= 1 && P <= 64 &&
+                               (P & (P - 1)) == 0 && g.E0 <= SA_THREADS;
+        if (colsum_ok) {
+            if constexpr (NHWC) {
+                hipLaunchKernelGGL((softargmax_bwd_kernel<T, V, true, true>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, row_max, row_sum, xyz, gxyz, gscale,
+                                   dlogits, col_sums);
+                *col_sums_done = 1;
+            }
+        } else {
+            hipLaunchKernelGGL((softargmax_bwd_kernel<T, V, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, row_max, row_sum, xyz, gxyz, gscale, dlogits,
+                               (float*)nullptr);
+        }
+    } else {
+        hipLaunchKernelGGL((softargmax_bwd_kernel<T, 1, NHWC>), dim3(grid), dim3(SA_THREADS), 0, st, logits, g, nchunk, row_max, row_sum, xyz, gxyz, gscale, dlogits,
+                           (float*)nullptr);
+    }
     EPI_CHECK_LAUNCH();
     return EPI_OK;
 }
 
-extern "C" int epi_softargmax3d_bwd(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
-                                    const float* row_max, const float* row_sum, const float* xyz, const float* grad_xyz,
-                                    const float* grad_scale, void* dlogits, epi_stream_t stream) {
+static int softargmax3d_bwd_impl(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                                 const float* row_max, const float* row_sum, const float* xyz, const float* grad_xyz,
+                                 const float* grad_scale, void* dlogits, float* col_sums, int* col_sums_done, epi_stream_t stream) {
+    if (col_sums_done) *col_sums_done = 0;
     if (!logits || !row_max || !row_sum || !xyz || !grad_xyz || !dlogits) return EPI_ERR_INVALID_ARGUMENT;
     RowGeom g;
     if (!make_geom(layout, B, J, D, H, W, &g)) return EPI_ERR_INVALID_ARGUMENT;
@@ -431,13 +482,31 @@ extern "C" int epi_softargmax3d_bwd(const void* logits, int dtype, int layout, i
     if (dtype == EPI_F32) {
         const bool vec = aligned16(logits) && aligned16(dlogits) && (g.E0 % 4 == 0) && (layout == EPI_NCHW || g.C % 4 == 0);
         return layout == EPI_NCHW ? launch_bwd<float, false>((const float*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (float*)dlogits, st)
-                                  : launch_bwd<float, true>((const float*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (float*)dlogits, st);
+                                  : launch_bwd<float, true>((const float*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (float*)dlogits, st,
+                                                            col_sums, col_sums_done);
     } else if (dtype == EPI_BF16) {
         const bool vec = aligned16(logits) && aligned16(dlogits) && (g.E0 % 8 == 0) && (layout == EPI_NCHW || g.C % 8 == 0);
         return layout == EPI_NCHW ? launch_bwd<unsigned short, false>((const unsigned short*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (unsigned short*)dlogits, st)
-                                  : launch_bwd<unsigned short, true>((const unsigned short*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (unsigned short*)dlogits, st);
+                                  : launch_bwd<unsigned short, true>((const unsigned short*)logits, g, rows, vec, row_max, row_sum, xyz, grad_xyz, grad_scale, (unsigned short*)dlogits, st,
+                                                                     col_sums, col_sums_done);
     }
     return EPI_ERR_UNSUPPORTED;
+}
+
+extern "C" int epi_softargmax3d_bwd(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                                    const float* row_max, const float* row_sum, const float* xyz, const float* grad_xyz,
+                                    const float* grad_scale, void* dlogits, epi_stream_t stream) {
+    return softargmax3d_bwd_impl(logits, dtype, layout, B, J, D, H, W, row_max, row_sum, xyz, grad_xyz, grad_scale, dlogits, nullptr, nullptr, stream);
+}
+
+// epi_softargmax3d_bwd that also delivers the per-channel sums of the gradient it writes (channels-last logits): col_sums [J*D] f32, ZERO on entry.
+// *col_sums_done = 1: col_sums holds, per channel, the sum over batch and pixels of dlogits as stored -- the bias gradient of the 1x1 convolution
+// that produced the logits; 0 (NCHW, an unsuitable depth extent, deterministic mode: the sums are fp32 atomics): col_sums untouched.
+extern "C" int epi_softargmax3d_bwd_colsums(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                                            const float* row_max, const float* row_sum, const float* xyz, const float* grad_xyz,
+                                            const float* grad_scale, void* dlogits, float* col_sums, int* col_sums_done, epi_stream_t stream) {
+    if (!col_sums || !col_sums_done) return EPI_ERR_INVALID_ARGUMENT;
+    return softargmax3d_bwd_impl(logits, dtype, layout, B, J, D, H, W, row_max, row_sum, xyz, grad_xyz, grad_scale, dlogits, col_sums, col_sums_done, stream);
 }
 
 extern "C" size_t epi_argmax_workspace_bytes(int rows, int n) {

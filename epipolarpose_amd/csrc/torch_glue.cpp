@@ -450,6 +450,55 @@ bool declared_hook_free(const Tensor& w) {
     return false;
 }
 
+// ---- column sums of a gradient, delivered by the kernel that wrote it ----
+// The criterion's backward kernel (epi_softargmax3d_bwd_colsums, core/integral_loss.py) writes the logits' gradient AND its per-channel sums -- the bias
+// gradient of the final 1x1 convolution, which otherwise re-reads the 285 MB gradient on the second stream (epi_column_sums_bf16, 92 us beside the
+// head's backward chain).  The producer OFFERS the sums for the tensor it returns; conv1x1_bias's backward TAKES them when the gradient it receives is
+// that very memory, unmodified (same live storage, offset, element count and version counter: a view made by autograd's reshape shares all of them; a
+// sum of two gradients or an in-place edit by a hook does not) -- otherwise it computes them as before.  One offer at a time, consumed once.
+// MEASURED AND OFF BY DEFAULT (EPI_BIAS_GRAD_FUSE=1 / bias_grad_fuse_mode(1) turn it on): the kernel pays 2 .. 5 us for the sums and the 92 us pass
+// with its 285 MB disappear from the second stream, yet the step gets 0.4 % SLOWER (6.172 / 6.151 / 6.158 -> 6.196 / 6.183 / 6.189 ms, same box,
+// profiles/r04_ab_bias_grad_from_criterion.txt): the column-sum pass was a light neighbour of the head's backward chain, and without it the final
+// layer's weight-gradient GEMM (247 us, reading the same 285 MB) starts 92 us earlier, beside the chain's two largest GEMMs instead of behind them.
+struct ColumnSumsOffer {
+    c10::weak_intrusive_ptr<c10::StorageImpl> storage{c10::intrusive_ptr<c10::StorageImpl>()};   // of the offered gradient: while it lives, nobody else owns that memory
+    int64_t numel = 0, offset = 0, version = -1;
+    Tensor sums;
+};
+ColumnSumsOffer g_colsum_offer;
+long long g_bias_sums_taken = 0;         // test hook: how many bias gradients came from an offer
+int g_colsum_mode = -1;
+bool column_sums_wanted() {
+    if (g_colsum_mode < 0) { const char* e = getenv("EPI_BIAS_GRAD_FUSE"); g_colsum_mode = (e && e[0] == '1') ? 1 : 0; }
+    return g_colsum_mode != 0 && epi_set_deterministic(-1) == 0;
+}
+int bias_grad_fuse_mode(int mode) {              // test / measurement hook: returns the previous setting; a negative mode only queries
+    (void)column_sums_wanted();
+    const int before = g_colsum_mode;
+    if (mode == 0 || mode == 1) g_colsum_mode = mode;
+    return before;
+}
+void offer_column_sums(const Tensor& grad, const Tensor& sums) {
+    TORCH_CHECK(grad.is_cuda() && sums.is_cuda() && sums.scalar_type() == at::kFloat && sums.is_contiguous(), "offer_column_sums: a float32 device tensor of sums");
+    ColumnSumsOffer o;
+    o.storage = grad.storage().getWeakStorageImpl();
+    o.numel = grad.numel();
+    o.offset = grad.storage_offset();
+    o.version = (int64_t)grad._version();
+    o.sums = sums;
+    g_colsum_offer = std::move(o);
+}
+Tensor take_column_sums(const Tensor& grad, int64_t channels) {
+    ColumnSumsOffer o = std::move(g_colsum_offer);      // consumed (or dropped) either way: an offer never outlives the next backward of a bias
+    g_colsum_offer = ColumnSumsOffer();
+    if (!o.sums.defined() || !grad.defined()) return Tensor();
+    const auto alive = o.storage.lock();                // the offered tensor's storage, if anybody still holds it
+    if (!alive || alive.get() != grad.storage().unsafeGetStorageImpl() || grad.numel() != o.numel || grad.storage_offset() != o.offset ||
+        (int64_t)grad._version() != o.version || o.sums.numel() != channels || o.sums.device() != grad.device())
+        return Tensor();
+    return o.sums;
+}
+
 bool gradient_consumed_after_backward(const Tensor& w) {
     if (!w.defined() || !w.is_leaf() || w.grad().defined()) return false;
     if (torch::autograd::impl::post_acc_grad_hooks(w) != nullptr && !declared_hook_free(w)) return false;
@@ -1670,8 +1719,11 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
         const auto saved = ctx->get_saved_variables();
         const Tensor x = saved[0], w16 = saved[1], w = saved[2];
         Tensor dy = grads[0];
-        if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
         const int B = (int)x.size(0), Cin = (int)x.size(1), H = (int)x.size(2), W = (int)x.size(3), Cout = (int)w16.size(0);
+        // the per-channel sums of this gradient, when the kernel that wrote it delivered them (only for the tensor as written: no conversion below)
+        Tensor offered_sums = take_column_sums(dy, Cout);                          // (consumes or drops whatever offer is pending)
+        if (offered_sums.defined() && !(nhwc_bf16(dy) && dy.dim() == 4 && dy.size(1) == Cout)) offered_sums = Tensor();
+        if (!nhwc_bf16(dy)) dy = dy.to(at::kBFloat16).contiguous(at::MemoryFormat::ChannelsLast);
         const int M = B * H * W;
         const bool w_f32 = ctx->saved_data["w_f32"].toBool();
         const double flops = 2.0 * M * (double)Cout * Cin;
@@ -1695,13 +1747,21 @@ struct Conv1x1Bias : public torch::autograd::Function<Conv1x1Bias> {
             if (red_done) link_mark_reduced(link, dx);
         }
         if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) {
-            // bias gradient = column sums of dy (one more read of the 285 MB logits gradient): second stream as well when nobody reads it early
-            Tensor sums = at::zeros({2 * (int64_t)Cout}, x.options().dtype(at::kFloat));
-            db = sums.slice(0, 0, Cout);
+            // bias gradient = column sums of dy (one more read of the 285 MB logits gradient): second stream as well when nobody reads it early --
+            // unless the criterion's backward kernel delivered them with the gradient (take_column_sums): then they are complete on the main stream
             const Tensor bias_leaf = saved[3];
             const bool first_bias = bias_leaf.defined() && first_gradient_of_pass(bias_leaf);
             if (bias_leaf.defined() && !first_bias) flush_pending_reduces();          // (second use of the layer in this graph, see the weight below)
-            if (side_mode() != 0 && first_bias && gradient_consumed_after_backward(bias_leaf)) {
+            Tensor sums;
+            if (offered_sums.defined()) {
+                db = offered_sums;
+                g_bias_sums_taken += 1;
+            } else {
+                sums = at::zeros({2 * (int64_t)Cout}, x.options().dtype(at::kFloat));
+                db = sums.slice(0, 0, Cout);
+            }
+            if (offered_sums.defined()) {
+            } else if (side_mode() != 0 && first_bias && gradient_consumed_after_backward(bias_leaf)) {
                 const Tensor dyin = dy, out = sums;
                 g_side.jobs.push_back(SideStream::Job{dy, sums, db, [=](epi_stream_t st) {
                     check(epi_column_sums_bf16(dyin.data_ptr(), (long long)M, Cout, out.data_ptr<float>(), st), "epi_column_sums_bf16");
@@ -1896,6 +1956,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("bn_bwd_fuse_mode", &bn_bwd_fuse_mode,
           "BatchNorm-backward reduction fused into the backward-data GEMM that produces the layer's gradient (EpiBnReduce): 1 on (default; "
           "EPI_BN_BWD_FUSE=0 turns it off), 0 off; returns the previous setting, a negative argument only queries");
+    m.def("column_sums_wanted", &column_sums_wanted, "whether a gradient producer should deliver per-channel sums with its gradient (off in deterministic mode / EPI_BIAS_GRAD_FUSE=0)");
+    m.def("offer_column_sums", &offer_column_sums, "per-channel sums (float32 [C]) of the gradient tensor the caller is about to return from its backward");
+    m.def("bias_grad_fuse_mode", &bias_grad_fuse_mode, "the final layer's bias gradient from the criterion's backward kernel: 0 off (default, measured slower in the step), 1 on; returns the previous setting");
+    m.def("bias_sums_taken", [](bool reset) { const long long v = g_bias_sums_taken; if (reset) g_bias_sums_taken = 0; return v; },
+          "test hook: bias gradients that came from an offered column-sum tensor since the last reset");
     m.def("wgrad_group_mode", &wgrad_group_mode,
           "grouped weight-gradient launches: 0 one launch per layer, 1 one per autograd node, 2 one per ResNet stage; returns the previous setting");
     m.def("defer_wgrad_reduce", &defer_wgrad_reduce, "enable / disable the deferred weight-gradient reduction; returns the previous setting");

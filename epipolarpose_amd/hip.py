@@ -33,6 +33,7 @@ _SIGNATURES = {
     "epi_softargmax3d_workspace_bytes": (_sz, [_i] * 5),
     "epi_softargmax3d_fwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "epi_softargmax3d_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "epi_softargmax3d_bwd_colsums": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int), _vp]),
     "epi_joint_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_argmax_workspace_bytes": (_sz, [_i, _i]),
     "epi_argmax_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
@@ -282,8 +283,9 @@ def softargmax3d_fwd(logits, num_joints):
     return xyz, rmax, rsum
 
 
-def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_scale=None):
-    """-> dlogits (same dtype / memory format as logits)."""
+def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_scale=None, col_sums=None):
+    """-> dlogits (same dtype / memory format as logits).  col_sums: a ZEROED float32 [C] tensor that receives the per-channel sums of dlogits
+    in the same pass (the bias gradient of the convolution that produced the logits); then -> (dlogits, delivered: bool)."""
     lib = load()
     _dev(logits, name="logits")
     dt, layout, logits = _logits_format(logits)
@@ -293,6 +295,15 @@ def softargmax3d_bwd(logits, num_joints, row_max, row_sum, xyz, grad_xyz, grad_s
     dlogits = torch.empty_like(logits)      # preserves the memory format
     with _on(logits.device):
         ev = timer.start("epi_softargmax3d_bwd")
+        if col_sums is not None:
+            if col_sums.dtype != torch.float32 or col_sums.numel() != c or not col_sums.is_contiguous() or col_sums.device != logits.device:
+                raise ValueError("col_sums must be a contiguous float32 [C] tensor on the logits' device")
+            done = ctypes.c_int(0)
+            _check(lib.epi_softargmax3d_bwd_colsums(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(row_max), _ptr(row_sum), _ptr(xyz),
+                                                    _ptr(grad_xyz), _ptr(grad_scale), _ptr(dlogits), _ptr(col_sums), ctypes.byref(done), _stream()),
+                   "epi_softargmax3d_bwd_colsums")
+            timer.stop(ev)
+            return dlogits, bool(done.value)
         _check(lib.epi_softargmax3d_bwd(_ptr(logits), dt, layout, b, num_joints, d, h, w, _ptr(row_max), _ptr(row_sum),
                                         _ptr(xyz), _ptr(grad_xyz), _ptr(grad_scale), _ptr(dlogits), _stream()),
                "epi_softargmax3d_bwd")

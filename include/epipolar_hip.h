@@ -74,6 +74,15 @@ int epi_softargmax3d_bwd(const void* logits, int dtype, int layout, int B, int J
                          const float* row_max, const float* row_sum, const float* xyz,
                          const float* grad_xyz, const float* grad_scale,
                          void* dlogits, epi_stream_t stream);
+/* The same, and in the same pass the per-channel sums of the gradient it writes (channels-last logits only): the bias gradient of the final 1x1
+ * convolution (pose3d_resnet.py:116-122; autograd's `grad_output.sum((0, 2, 3))`), which otherwise re-reads the whole gradient.
+ *   col_sums [J*D] f32, ZERO on entry.  *col_sums_done = 1: col_sums[c] = sum over batch and pixels of dlogits[.., c] as stored (rounded to the
+ *   logits' dtype); 0: col_sums untouched (NCHW, a depth extent the kernel's thread mapping does not cover, deterministic mode -- the sums are
+ *   fp32 atomics): use epi_column_sums_bf16. */
+int epi_softargmax3d_bwd_colsums(const void* logits, int dtype, int layout, int B, int J, int D, int H, int W,
+                                 const float* row_max, const float* row_sum, const float* xyz,
+                                 const float* grad_xyz, const float* grad_scale,
+                                 void* dlogits, float* col_sums, int* col_sums_done, epi_stream_t stream);
 
 /* Weighted joint-location loss value and its gradient w.r.t. the predicted coordinates -- replaces
  * lib/core/integral_loss.py:7-47 (weighted_mse_loss / weighted_l1_loss / weighted_smooth_l1_loss),

@@ -101,6 +101,42 @@ def test_bf16_logits(dev):
         np.testing.assert_allclose(dl.float().contiguous().cpu().numpy(), ref, atol=1e-2 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 16, 16, 16), (3, 4, 64, 8, 8), (2, 3, 32, 6, 10), (32, 17, 64, 64, 64)], ids=["d16", "d64", "d32_ragged", "bench"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_backward_delivers_the_column_sums_of_the_gradient_it_writes(dev, shape, dtype):
+    """epi_softargmax3d_bwd_colsums on channels-last logits: the per-channel sums (the bias gradient of the final 1x1 convolution,
+    pose3d_resnet.py:116-122) equal the sums of the gradient AS STORED -- fp32 accumulation of the same numbers in another order, so the bar is
+    1e-5 of the sum of magnitudes -- and the gradient itself is bit-identical to the plain entry point's."""
+    from epipolarpose_amd import hip
+    b, j, d, h, w = shape
+    gen = torch.Generator(device="cpu").manual_seed(b * 131 + d)
+    logits = (torch.randn((b, j * d, h, w), generator=gen) * 3).to(dev)
+    if dtype == "bf16":
+        logits = logits.to(torch.bfloat16)
+    logits = logits.contiguous(memory_format=torch.channels_last)
+    xyz, rmax, rsum = hip.softargmax3d_fwd(logits, j)
+    g = torch.randn((b, 3 * j), generator=gen).to(dev)
+    scale = torch.tensor([0.37], device=dev)
+    plain = hip.softargmax3d_bwd(logits, j, rmax, rsum, xyz, g, scale)
+    sums = torch.zeros(j * d, dtype=torch.float32, device=dev)
+    dl, delivered = hip.softargmax3d_bwd(logits, j, rmax, rsum, xyz, g, scale, col_sums=sums)
+    assert delivered, "channels-last logits with a power-of-two depth extent: the sums must come from the kernel"
+    assert torch.equal(dl, plain) and dl.is_contiguous(memory_format=torch.channels_last)
+    want = dl.double().sum(dim=(0, 2, 3))
+    mag = dl.double().abs().sum(dim=(0, 2, 3))
+    assert ((sums.double() - want).abs() <= 1e-5 * mag + 1e-12).all(), float(((sums.double() - want).abs() / (mag + 1e-30)).max())
+    # NCHW logits / deterministic mode: not delivered, buffer untouched
+    sums2 = torch.zeros_like(sums)
+    _, delivered2 = hip.softargmax3d_bwd(logits.contiguous(), j, rmax, rsum, xyz, g, scale, col_sums=sums2)
+    assert not delivered2 and not sums2.any()
+    hip.set_deterministic(True)
+    try:
+        _, delivered3 = hip.softargmax3d_bwd(logits, j, rmax, rsum, xyz, g, scale, col_sums=sums2)
+    finally:
+        hip.set_deterministic(False)
+    assert not delivered3 and not sums2.any()
+
+
 def test_full_size_properties(dev):
     """BASELINE size (B=32, J=17, D=H=W=64): shift invariance, peak recovery, gradient rows sum to zero."""
     from epipolarpose_amd import hip

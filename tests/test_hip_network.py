@@ -232,6 +232,59 @@ def test_fused_adam_matches_torch_adam():
     opt.load_state_dict(sd)
 
 
+def test_final_layer_bias_gradient_arrives_with_the_criterions_gradient():
+    """Round 4: the criterion's backward kernel also delivers the per-channel sums of the logits' gradient, and the final layer takes them as its
+    bias gradient (autograd's grad_output.sum((0, 2, 3)) of pose3d_resnet.py:116-122) instead of re-reading the gradient.  Held against the sums of
+    the gradient tensor that actually flowed (captured by a tensor hook), and against the separate column-sum pass with the hand-over switched off;
+    a gradient that is NOT the tensor the kernel wrote (scaled by a hook) must make the layer compute the sums itself."""
+    from epipolarpose_amd import hip
+    from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
+    from epipolarpose_amd.models.pose3d_resnet import get_pose_net
+    dev = torch.device("cuda:0")
+    j, d, image, b = 4, 16, 64, 4
+    torch.manual_seed(11)
+    model = get_pose_net(make_cfg(18, image, j, d), is_train=True).to(dev)
+    model.train()
+    crit = SmoothL1JointLocationLoss(num_joints=j)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn((b, 3, image, image), generator=gen).to(dev)
+    gt = ((torch.rand((b, 3 * j), generator=gen) - 0.5) * 0.4).to(dev)
+    wt = torch.ones(b, 3 * j, device=dev)
+    glue = hip.glue()
+
+    def run(hook=None):
+        model.zero_grad(set_to_none=True)
+        seen = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            preds = model(x)
+        preds.register_hook(lambda g: seen.append(g.detach().clone()) if hook is None else hook(g, seen))
+        crit(preds, gt, wt).backward()
+        torch.cuda.synchronize()
+        return model.final_layer.bias.grad.detach().double().clone(), seen[0].double()
+
+    mode0 = glue.bias_grad_fuse_mode(1)
+    try:
+        glue.bias_sums_taken(True)
+        got, flowed = run()
+        assert glue.bias_sums_taken(True) == 1, "the final layer did not take the sums the criterion's kernel delivered"
+        want, mag = flowed.sum(dim=(0, 2, 3)), flowed.abs().sum(dim=(0, 2, 3))
+        assert ((got - want).abs() <= 1e-5 * mag + 1e-12).all()
+        glue.bias_grad_fuse_mode(0)
+        plain, flowed0 = run()
+        assert glue.bias_sums_taken(True) == 0
+        assert ((plain - flowed0.sum(dim=(0, 2, 3))).abs() <= 1e-5 * flowed0.abs().sum(dim=(0, 2, 3)) + 1e-12).all()
+        glue.bias_grad_fuse_mode(1)
+
+        def doubled(g, seen):            # the layer receives ANOTHER tensor than the one the kernel wrote: the offer must not be used
+            seen.append((2 * g).detach().clone())
+            return 2 * g
+        got2, flowed2 = run(doubled)
+        assert glue.bias_sums_taken(True) == 0
+        assert ((got2 - flowed2.sum(dim=(0, 2, 3))).abs() <= 1e-5 * flowed2.abs().sum(dim=(0, 2, 3)) + 1e-12).all()
+    finally:
+        glue.bias_grad_fuse_mode(mode0)
+
+
 def test_whole_network_used_twice_in_one_graph():
     """The model called on TWO inputs before one backward: every layer's weight receives two gradients in one pass, and the autograd engine adds
     the second to the first on the main stream while `.grad` is still undefined.  The second stream / deferred slab sums must not leave the
