@@ -284,6 +284,7 @@ __device__ __forceinline__ void coalesced_epilogue(const EpiArgs p, f32x16 (&acc
         return *reinterpret_cast<const uint4v*>(p.addend + ar * p.ldc + n);
     };
     constexpr bool AD_EARLY = !(RED && (TM >= 4 || !RED_PREFETCH));   // (the 256-row tile / the patch kernel with the fused reduction: no registers for the addend rows)
+    constexpr int RED_GROUP = 4;        // rows' z / y tiles in flight per lane where they are fetched inside the copy loop (8 for the 256-row tile: no gain, 6.355 vs 6.339 ms)
     constexpr bool RED_EARLY = RED && RED_PREFETCH && TM <= 2;   // z / y of all rows requested before the park too: their latency hides behind it
                                                                  // (RED_PREFETCH = false: the patch kernel's register budget has no room for them)
     uint4v ad[AD_EARLY ? ROWS : 1];
@@ -353,7 +354,7 @@ __device__ __forceinline__ void coalesced_epilogue(const EpiArgs p, f32x16 (&acc
 #pragma unroll
         for (int it = 0; it < ROWS; ++it) {
             // (RED: at most four rows' z / y tiles in flight per lane -- the scheduler would otherwise hoist all TM*4 loads to the top)
-            if (RED && !RED_EARLY && it % 4 == 0 && it) __builtin_amdgcn_sched_barrier(0);
+            if (RED && !RED_EARLY && it % RED_GROUP == 0 && it) __builtin_amdgcn_sched_barrier(0);
             const int row = it * 8 + r8, sw = row & 15;
             const uint2 lo = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8) ^ sw) << 3));
             const uint2 hi = *reinterpret_cast<const uint2*>(mine + row * 128 + (((2 * c8 + 1) ^ sw) << 3));
@@ -1529,8 +1530,12 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     static const bool fuse_red = [] { const char* e = getenv("EPI_BN_BWD_FUSE"); return !(e && e[0] == '0'); }();
     GemmBnRed want_red = a.br;
     a.br = GemmBnRed{};
+    // EPI_BN_BWD_FUSE_MAX_ROWS / _MIN_ROWS: fuse only for outputs of at most / at least that many rows (all phases together) -- measurement switches
+    static const long long red_max_rows = [] { const char* e = getenv("EPI_BN_BWD_FUSE_MAX_ROWS"); return e ? atoll(e) : (1LL << 40); }();
+    static const long long red_min_rows = [] { const char* e = getenv("EPI_BN_BWD_FUSE_MIN_ROWS"); return e ? atoll(e) : 0LL; }();
     if (deterministic() || !fuse_red || !red_done || !want_red.z || !want_red.bn || !want_red.sums || a.stats || a.bias ||
-        ((reinterpret_cast<uintptr_t>(want_red.z) | reinterpret_cast<uintptr_t>(want_red.y)) & 15u))
+        ((reinterpret_cast<uintptr_t>(want_red.z) | reinterpret_cast<uintptr_t>(want_red.y)) & 15u) || (long long)a.M * nphase > red_max_rows ||
+        (long long)a.M * nphase < red_min_rows)
         want_red.z = nullptr;
     if (a.addend && (out_f32 || (reinterpret_cast<uintptr_t>(a.addend) & 15u))) return EPI_ERR_UNSUPPORTED;
     a.coalesce = (!out_f32 && a.N % 8 == 0 && a.ldc % 8 == 0) ? 1 : 0;
