@@ -5,6 +5,7 @@ TAG=${1:-r04}
 OUT=gpurun_out/end_$TAG
 mkdir -p $OUT
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6) > $OUT/pytest.log
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2) > $OUT/smoke.log
 (timeout 400 python bench.py 2>&1 | tail -1) > $OUT/bench.json
 timeout 400 bash tools/gpu_profile.sh $TAG 6 --no-ss-leg --no-loader-leg > $OUT/profile.log 2>&1
 cp gpurun_out/prof_$TAG/steady_state_kernels.csv $OUT/steady_state_kernels.csv
