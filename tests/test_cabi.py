@@ -154,3 +154,31 @@ def test_grouped_weight_gradient_plan():
     assert ns1[0] > 1 and one == (ns1[0] * 64 * 576 * 4 + 255) // 256 * 256
     lib = hip.load()
     assert lib.epi_wgrad_group_plan(None, 0, None, None) == 1          # argument validation before any work
+
+
+def test_grouped_weight_gradient_launches_fit_the_chip_in_one_round():
+    """Round 4: the split of a grouped launch is chosen by the makespan of its workgroups on the chip's resident slots (512 workgroups of the
+    128 x 128 class, 768 of the 64 x 128 class on 256 CUs).  For the two stages of ResNet-50 at batch 32 whose items are ALL split (layers 1 and 2:
+    every workgroup has the same length) a launch of slightly more workgroups than slots runs a second round that doubles its time -- the
+    round-3 model chose 640 and 860 workgroups there (measured 271 / 144 us; 200 / 110 us with 476 / 740)."""
+    from epipolarpose_amd import hip
+    b = 32
+
+    def workgroups(shapes, ns):
+        wg = [0, 0]
+        for (_, _, _, _, cin, cout, k, _, _), v in zip(shapes, ns):
+            cls = 1 if cout <= 64 else 0
+            wg[cls] += -(-cout // (64 if cls else 128)) * -(-(k * k * cin) // 128) * v
+        return wg
+    layer1 = [("conv", b, 64, 64, 256, 64, 1, 1, 0), ("conv", b, 64, 64, 64, 64, 3, 1, 1), ("conv", b, 64, 64, 64, 256, 1, 1, 0)] * 2 + \
+             [("conv", b, 64, 64, 64, 64, 1, 1, 0), ("conv", b, 64, 64, 64, 64, 3, 1, 1), ("conv", b, 64, 64, 64, 256, 1, 1, 0), ("conv", b, 64, 64, 64, 256, 1, 1, 0)]
+    _, ns = hip.wgrad_group_plan(layer1)
+    wide, narrow = workgroups(layer1, ns)
+    assert 384 <= wide <= 512 and 576 <= narrow <= 768, (wide, narrow, ns)
+    layer2 = [("conv", b, 32, 32, 512, 128, 1, 1, 0), ("conv", b, 32, 32, 128, 128, 3, 1, 1), ("conv", b, 32, 32, 128, 512, 1, 1, 0)] * 3 + \
+             [("conv", b, 64, 64, 256, 128, 1, 1, 0), ("conv", b, 64, 64, 128, 128, 3, 2, 1), ("conv", b, 32, 32, 128, 512, 1, 1, 0), ("conv", b, 64, 64, 256, 512, 1, 2, 0)]
+    _, ns2 = hip.wgrad_group_plan(layer2)
+    wide2, narrow2 = workgroups(layer2, ns2)
+    assert narrow2 == 0 and 384 <= wide2 <= 512, (wide2, ns2)
+    # the same question asked twice gives the same plan (the choice is remembered per shape set)
+    assert hip.wgrad_group_plan(layer2)[1] == ns2
