@@ -1645,6 +1645,11 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
             return EPI_OK;
         }
     }
+    // (round 4, measured and not kept: split launches finished by the workgroup that completes a tile -- arrival counter per tile, partials through
+    //  agent-scope (L2-bypassing) accesses, the last arriver sums them in split order and runs the whole epilogue with the fused column sums: 12 finish
+    //  and 6 reduction launches per step gone, the step 6.17 -> 6.75 ms (7.15 ms with __threadfence() around ordinary accesses: a whole-L2 write-back
+    //  and invalidate per workgroup).  A finish launch spreads over the whole chip and reads the partials from L2; the last arrivers are 64 .. 256
+    //  workgroups reading them past the L2, serially behind their own K loop.  profiles/r04_ab_split_finished_in_kernel.txt)
     // (round 4, measured and not kept: under-filled launches with fused column sums -- 64 .. 128 tiles of 128 x 128 in layers 3 / 4 at batch 32 -- unsplit on
     //  64 x 128 tiles with the reduction in their epilogue: 3 .. 5 separate reduction launches go, the step gets 2 % SLOWER (6.25 -> 6.39 ms; with the 3x3
     //  launches moved off the patch kernel as well 6.62 ms), profiles/r04_ab_underfill_half_tiles.txt)
