@@ -1384,7 +1384,10 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         // the same tables): 6.204 / 6.212 ms with mode 3 against 6.194 / 6.187 ms without, fused-reduction launches included
         // (profiles/r04_ab_pipe_mode3.txt) -- so the default stays 0
         const bool one_round = pp.tiles * nphase * pp.nsplit <= 256;
-        if (pm == 2 || (pm == 1 && pp.kps >= 6 * GBK) || (pm == 3 && one_round && pp.kps >= 6 * GBK)) return pp;
+        // mode 4: only the long under-filled launches (<= 128 workgroups with >= 32 K tiles each: the deconvolution backward-data at 16 x 16 / 8 x 8):
+        // GEMM family 4.96 -> 4.94 ms on one stream, the two-stream step 6.26 -> 6.30 ms (the ring's 128 KB per CU leave no LDS for the weight gradients beside it)
+        const bool long_underfilled = pp.tiles * nphase * pp.nsplit <= 128 && pp.kps >= 32 * GBK;
+        if (pm == 2 || (pm == 1 && pp.kps >= 6 * GBK) || (pm == 3 && one_round && pp.kps >= 6 * GBK) || (pm == 4 && long_underfilled)) return pp;
     }
     return gemm_plan_cfg(cfg, M, N, K, nphase);
 }
