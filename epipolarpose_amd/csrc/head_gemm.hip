@@ -2197,9 +2197,16 @@ static TnPlan tn_plan(int R, int I, int J) {
     // 6.534 -> 6.462 ms/step over three boxes (100: 6.529 / 6.539 / 6.474, 70: 6.440 / 6.484 / 6.415; 60: 6.424, 50: 6.463, 40: 6.527).  Round 2
     // measured the opposite on its per-layer backbone launches (7.67 / 7.73 vs 7.65 ms for 50 / 70): those are grouped now (group_plan).
     static const int slot_percent = [] { const char* e = getenv("EPI_TN_SLOTS"); const int v = e ? atoi(e) : 70; return v >= 10 && v <= 100 ? v : 70; }();
+    // Long reductions over large operands (the final layer: 131 072 rows x (1088 + 256) columns; the last deconvolution: 32 768 x (256 + 16 x 256)): the
+    // launch is bound by the LDS fill traffic, which the 256 x 256 tile halves (every operand row is staged once per 256 instead of 128 output columns /
+    // rows) -- measured alone with HBM-fresh operands (tools/bench_tn_tiles.py): 195 -> 165 us and 138 -> 125 us; shorter reductions lose 25 .. 35 % on
+    // that tile (2048 / 8192 rows), and the cost model below, calibrated on those, never picks it.  EPI_TN_BIG_LONG=0: the model alone.
+    static const bool big_long_on = [] { const char* e = getenv("EPI_TN_BIG_LONG"); return !(e && e[0] == '0'); }();
+    const bool big_long = big_long_on && ov == 0 && R >= 32768 && fills(I) && fills(J) && (long long)I * J >= 256 * 1024;
     TnPlan best = {0, 0, 1, 0};
     double best_t = 1e30;
     for (const Cfg& c : cfgs) {
+        if (big_long && c.id != 2) continue;
         if (c.id == 1 && I > 64) continue;
         if (c.id == 0 && I <= 64 && ov == 0) continue;
         if (c.id == 2 && !((fills(I) && fills(J)) || ov == 2)) continue;
