@@ -1357,7 +1357,12 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         const int tiles_n = (N + 255) / 256;
         const bool fills = M >= 256 && tiles_n * 256 <= N + N / 4;
         const bool deep = pb.nsplit == 1 ? (K >= 512 && pb.tiles * nphase >= 200) : pb.kps >= 1024;
-        if (ov == 2 || (fills && deep)) return pb;
+        // (round 4) ... unless the 256 x 256 tile has to split K while 128 x 128 tiles fill the chip UNSPLIT: the unsplit launch needs no finish launch and
+        // can carry the fused column sums.  The first deconvolution's backward-data (2048 x 2048 x 4096): 49 us + 18 us finish + 11 us BatchNorm-backward
+        // reduction on four splits of 64 tiles, 54 us alone on 256 unsplit tiles (tools/bench_nt_tiles.py).  EPI_GEMM_BIG_SPLIT=1: the round-3 choice.
+        static const bool big_split_ok = [] { const char* e = getenv("EPI_GEMM_BIG_SPLIT"); return e && e[0] == '1'; }();
+        const bool small_fills_unsplit = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase >= 200;
+        if (ov == 2 || (fills && deep && (pb.nsplit == 1 || big_split_ok || !small_fills_unsplit))) return pb;
     }
     // (fp32 results run on the 128 x 128 instantiation only: planning them for the tall tile launched that kernel on the tall tile's grid --
     //  wrong results for N <= 64 at M >= 65536, i.e. the fp32-grade mode's 64-channel layers from batch 16 on; found in round 4 by the
