@@ -131,6 +131,9 @@ def test_weight_gradient_plan_is_consistent_with_its_workspace():
         if i <= 64:
             assert p["cfg"] == 1                     # the narrow tile serves the 64-channel layers
     assert hip.gemm_tn_plan(2048, 512, 512, 9) == {"cfg": 0, "tiles": 144, "nsplit": 2, "rows_per_split": 1024, "slab_bytes": 2 * 512 * 4608 * 4}
+    # round 4: long reductions over large operands (the final layer, the last deconvolution) take the 256 x 256 tile; shorter ones do not
+    assert hip.gemm_tn_plan(131072, 1088, 256, 1)["cfg"] == 2 and hip.gemm_tn_plan(32768, 256, 256, 16)["cfg"] == 2
+    assert hip.gemm_tn_plan(8192, 256, 256, 16)["cfg"] == 0 and hip.gemm_tn_plan(2048, 2048, 256, 16)["cfg"] == 0
 
 
 def test_grouped_weight_gradient_plan():
