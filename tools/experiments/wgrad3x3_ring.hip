@@ -1,7 +1,8 @@
 // EXPERIMENT, NOT COMPILED INTO THE LIBRARY (round 4): the weight gradient of a 3x3 / stride-1 / pad-1 convolution with the
 // reduction over zero-padded positions and the input rows in an LDS ring.  Bit-for-bit parity with the TN kernel's results on tests/test_hip_conv.py /
-// tests/test_hip_head.py (-k weight), but 51 .. 60 us per ResNet-50 layer at batch 32 against the TN kernel's 37 .. 40 us: the transposing LDS reads
-// (ds_read_b64_tr_b16, 20 per 9 MFMAs) bound it, not the DMA.  Kept as a starting point: the device part below dropped into csrc/head_gemm.hip behind
+// tests/test_hip_head.py (-k weight), but 51 .. 60 us per ResNet-50 layer at batch 32 against the TN kernel's 37 .. 40 us (~3 us per 64-position tile).  Not the DMA
+// (three tiles in flight changed nothing); the operand reads (20 ds_read_b64_tr_b16 per 9 MFMAs, 3.1 ns each per CU: tools/lds_tr_probe.hip) explain ~1 us per tile;
+// the rest -- 147 KB of fp32 result per workgroup, 19 MB of slabs per layer, only 128 workgroups -- was not separated.  Kept as a starting point: the device part below dropped into csrc/head_gemm.hip behind
 // tn_body (it uses glds16, tn_swz, tr_frag's layout, xcd_remap, GemmTnArgs), the host part in front of tn_plan; launch_tn called launch_w3 when
 // w3_eligible(a), epi_gemm_tn_workspace_bytes covered w3_nsplit's slabs.
 
