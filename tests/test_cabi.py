@@ -185,3 +185,15 @@ def test_grouped_weight_gradient_launches_fit_the_chip_in_one_round():
     assert narrow2 == 0 and 384 <= wide2 <= 512, (wide2, ns2)
     # the same question asked twice gives the same plan (the choice is remembered per shape set)
     assert hip.wgrad_group_plan(layer2)[1] == ns2
+
+
+def test_gemm_plan_prefers_unsplit_128_tiles_over_a_k_split_256_plan():
+    """Round 4 (host only, through the workspace the library asks for): a GEMM whose 256 x 256 plan would have to split K while 128 x 128 tiles fill
+    the chip unsplit needs NO split-K slabs any more -- the first deconvolution's backward-data of the head, 2048 x 2048 x 4096 -- while the
+    shapes that have too few 128 x 128 tiles to fill the chip (layer 4's 2048 x 512 x 2048; the first deconvolution's forward, four phases of
+    2048 x 256 x 8192) still split."""
+    from epipolarpose_amd import hip
+    lib = hip.load()
+    assert lib.epi_gemm_workspace_bytes(2048, 2048, 4096, 1) == 0
+    assert lib.epi_gemm_workspace_bytes(2048, 512, 2048, 1) == 4 * 2048 * 512 * 4
+    assert lib.epi_gemm_workspace_bytes(2048, 256, 8192, 4) > 0
