@@ -1366,7 +1366,11 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
             };
             const bool first_use = first_gradient_of_pass(sv.w);
             if (!first_use) flush_pending_reduces();                  // (the model used twice in one graph: the first gradient must be final before the engine adds this one)
-            if (side_mode() != 0 && first_use && gradient_consumed_after_backward(sv.w)) {
+            // The stem is the LAST node of the backward chain: on the second stream its weight gradient queues behind layer 1's grouped launches, which
+            // are still running when the chain ends, and the step's tail waits for both one after the other.  On the main stream it runs BESIDE them.
+            // EPI_STEM_WGRAD_SIDE=1: the second stream as before (A/B)
+            static const bool stem_side = [] { const char* e = getenv("EPI_STEM_WGRAD_SIDE"); return e && e[0] == '1'; }();
+            if (stem_side && side_mode() != 0 && first_use && gradient_consumed_after_backward(sv.w)) {
                 g_side.jobs.push_back(SideStream::Job{sv.x, g.dx, dw, [=](epi_stream_t st) {
                     launch(st, side_workspace(ws_bytes, s2d));
                     g_side.keep.push_back(dwp);
