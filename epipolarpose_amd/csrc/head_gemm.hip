@@ -34,8 +34,9 @@ constexpr int GBK = 64;                            // K (reduction) depth of one
 //   tall:  256 x  64, 4 waves (4 x 1), 80 KiB LDS (2 workgroups / CU)  -- N <= 64 (the 64-channel layers): no half-empty MFMA tiles
 //   big:   256 x 256, 8 waves (2 x 4), 128 KiB LDS (1 workgroup / CU)  -- twice the MFMA work per staged byte and per DMA
 //          instruction, 1.5x less LDS read traffic per MFMA
-template <int TM_, int WM_, int WN_, int MIN_WAVES_, int NSTAGE_> struct GemmCfg {
+template <int TM_, int WM_, int WN_, int MIN_WAVES_, int NSTAGE_, bool STAGGER_ = false> struct GemmCfg {
     static constexpr int TM = TM_, WM = WM_, WN = WN_, NW = WM_ * WN_, THREADS = 64 * NW, MIN_WAVES = MIN_WAVES_, NSTAGE = NSTAGE_;
+    static constexpr bool STAGGER = STAGGER_;                      // the two-wave-group K loop (see head_gemm_kernel)
     static constexpr int BM = WM_ * TM_ * 32, BN = WN_ * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;       // 1 KiB DMA pieces (8 rows x 128 B) per wave and K tile
@@ -45,7 +46,8 @@ template <int TM_, int WM_, int WN_, int MIN_WAVES_, int NSTAGE_> struct GemmCfg
 };
 typedef GemmCfg<2, 2, 2, 2, 2> CfgSmall;
 typedef GemmCfg<2, 4, 1, 2, 2> CfgTall;
-typedef GemmCfg<4, 2, 4, 1, 2> CfgBig;
+typedef GemmCfg<4, 2, 4, 1, 2> CfgBigLock;                        // the lock-step two-stage loop of rounds 1-4 (epi_gemm_tune tile 5: A/B only)
+typedef GemmCfg<4, 2, 4, 1, 2, true> CfgBig;                      // round 5: two wave groups half a K-tile phase apart
 // Under-filled launches (the deep layers at batch 32: 8192 or 2048 rows, 64 .. 512 tiles of 128 x 128): a workgroup that owns a CU alone
 // fills LDS at ~30 B/clk (tools/probe_fill.hip: 4 waves issuing 1 KiB loads), two per CU at ~51 B/clk, and a CU without a workgroup at
 // nothing -- so the same problem cut into twice or four times as many, smaller tiles finishes sooner although it stages more bytes.
@@ -528,7 +530,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
         const void* src;
         if (MODE != A_PLAIN) {       // K tiles never straddle a tap (Cs % 64 == 0) and K has no tail in the gather modes
             const unsigned eoff = (unsigned)(a_pix[ps] + g_shift) * (unsigned)(p.ga.pitch ? p.ga.pitch : p.ga.Cs) + (unsigned)g_c0;
-            src = ((a_mask[ps] >> g_tap) & 1) ? reinterpret_cast<const void*>(a_ptr[ps] + eoff) : reinterpret_cast<const void*>(zero_src);
+            // (the staggered loop issues one or two tiles past the end of its K range: zero chunks, never read)
+            const bool in_k = !Cfg::STAGGER || k0 < k_end;
+            src = (in_k && ((a_mask[ps] >> (g_tap & 31)) & 1)) ? reinterpret_cast<const void*>(a_ptr[ps] + eoff) : reinterpret_cast<const void*>(zero_src);
         } else {
             const bool ok = a_mask[ps] && (k0 + a_chunk[ps] < k_end);          // K tail (K % 8 == 0): zero-filled chunks
             src = ok ? reinterpret_cast<const void*>(a_ptr[ps] + k0) : reinterpret_cast<const void*>(zero_src);
@@ -637,7 +641,109 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
     };
     GEMM_STAMP(2);
     GEMM_STAMP_V(11, (unsigned long long)nk);
-    if constexpr (Cfg::NSTAGE > 2) {
+    if constexpr (Cfg::STAGGER) {
+        // ---- staggered loop (round 5; 8 waves, 256 x 256 tile) ----
+        // The lock-step loop below lets all eight waves read fragments, issue DMA and wait at the same moments, so the matrix pipe of every
+        // SIMD idles whenever its two waves do anything else (ISA + phase trace: < 50 % MFMA duty).  Here the workgroup is two GROUPS of four
+        // waves -- group g = wave row wm owns output rows g*128 .. +127 -- that run the same sequence of SLOTS one barrier apart:
+        //     READ(t,0)  fragments of B (all 64 k) and of the group's first 64 A rows -> 16 ds_read_b128; DMA of the A tile t+1     | barrier
+        //     MFMA(t,0)  16 MFMAs (rows 0..63 of the wave's 128 x 64, 4 k steps); counted vmcnt                                   | barrier
+        //     READ(t,1)  fragments of the second 64 A rows -> 8 ds_read_b128; DMA of the B tile t+2                                  | barrier
+        //     MFMA(t,1)  16 MFMAs with the B fragments still in registers; counted vmcnt                                           | barrier
+        // Group 1 passes one extra barrier first, so whenever group 0 is in a READ slot group 1 is in an MFMA slot and vice versa: the two
+        // waves that share a SIMD alternate between feeding its matrix pipe (512 cycles per slot) and everything else (reads, DMA issue, waits).
+        // Hazards, in slots (group 0's READ(t,0) is slot 4t, group 1's is 4t+1; a barrier ends every slot; waves 4g .. 4g+3 stage A rows of group g
+        // and all waves a share of B):
+        //   WAR  A(t+1) lands in buffer (t+1)&1 whose A rows were last read in READ(t-1,1) (slots 4t-2 / 4t-1, lgkmcnt(0) before the barrier);
+        //        B(t+2) lands in buffer t&1 whose B rows were last read in READ(t,0) (slots 4t / 4t+1) and is issued in slots 4t+2 / 4t+3.
+        //   RAW  DMA completes in issue order per wave, batches of 4 pieces: ... A(t+1), B(t+2), A(t+2), B(t+3) ...; `vmcnt(4)` at the end of
+        //        every MFMA slot leaves only the newest batch in flight, so before the barrier that opens READ(t,0) every wave has retired its
+        //        pieces of A(t) and B(t), and the barrier publishes them.  A tile has 3.5 slots (~1800 cycles) to land, a B tile 5.
+        //   Tiles past the end of the K range are issued as zero chunks (same counts, no branches) into buffers nobody reads again.
+        static_assert(AP == 4 && BP == 4 && TM == 4 && Cfg::NW == 8 && Cfg::NSTAGE == 2 && !BNIN, "staggered loop: 256 x 256 tile, 8 waves");
+        const int grp = __builtin_amdgcn_readfirstlane(wid) >> 2;          // == wm
+        int kb_run = k_begin;                                               // position of the next B tile to be issued (A's is k_run)
+        auto issue_a_tile = [&](int buf) {
+#pragma unroll
+            for (int ps = 0; ps < AP; ++ps) issue_a(ps, 0, buf);
+            advance_gather();
+        };
+        auto issue_b_tile = [&](int buf) {
+            char* b_s = smem + buf * Cfg::STAGE_BYTES + Cfg::A_BYTES + __builtin_amdgcn_readfirstlane(wid) * (BP * 1024);
+#pragma unroll
+            for (int ps = 0; ps < BP; ++ps) {
+                const bool ok = b_ok[ps] && kb_run + b_chunk[ps] < k_end;
+                glds16(ok ? reinterpret_cast<const void*>(b_ptr[ps] + kb_run) : reinterpret_cast<const void*>(zero_src), b_s + ps * 1024);
+            }
+            kb_run += GBK;
+        };
+        issue_b_tile(0);
+        issue_a_tile(0);
+        issue_b_tile(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        GEMM_STAMP(3);
+        if (grp) __builtin_amdgcn_s_barrier();
+        bf16x8 af[4][2], bfr[4][2];
+        auto mfma_half = [&](int h) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj)
+                        acc[2 * h + ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][tj], af[ks][ti], acc[2 * h + ti][tj], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const char* a_s = smem + buf * Cfg::STAGE_BYTES;
+            const char* b_s = a_s + Cfg::A_BYTES;
+            // READ(t,0)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    bfr[ks][tj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + tj * 4096)));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + ti * 4096)));
+            __builtin_amdgcn_sched_barrier(0);
+            issue_a_tile(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // READ(t,1)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + (2 + ti) * 4096)));
+            __builtin_amdgcn_sched_barrier(0);
+            issue_b_tile(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // the epilogue reuses the staging LDS
+    } else if constexpr (Cfg::NSTAGE > 2) {
         // ---- pipelined loop: tiles kt+1 .. kt+S-2 stay in flight across the barrier of tile kt ----
         // RAW: a wave's `s_waitcnt vmcnt(N)` retires ITS pieces of tile kt (DMA completes in issue order), the barrier that
         // follows makes every wave's pieces visible to every reader.  WAR: tile kt+S-1 goes into the buffer of tile kt-1, whose
@@ -1275,7 +1381,7 @@ static int gemm_tile_override() {
         return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
     }();
     const int f = g_tile_force_fwd();
-    return f == 1 || f == 2 ? f : v;
+    return f == 1 || f == 2 ? f : (f == 5 ? 2 : v);
 }
 
 // Split-K factor for one tile configuration: split until every CU has a workgroup (4-wave tiles: two), each split
@@ -1681,7 +1787,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (a.br.z) rc = pl.cfg == CFG_BIG ? launch_gemm_cfg<false, CfgBig, true>(a, pl, nphase, st)
                    : (pl.cfg == CFG_TALL ? launch_gemm_cfg<false, CfgTall, true>(a, pl, nphase, st)
                       : (pl.pipe ? launch_gemm_cfg<false, CfgSmallP, true>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgSmall, true>(a, pl, nphase, st)));
-    else if (pl.cfg == CFG_BIG) rc = launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
+    else if (pl.cfg == CFG_BIG) rc = g_tile_force == 5 ? launch_gemm_cfg<false, CfgBigLock>(a, pl, nphase, st) : launch_gemm_cfg<false, CfgBig>(a, pl, nphase, st);
     else if (out_f32) rc = launch_gemm_cfg<true, CfgSmall>(a, pl, nphase, st);
     else if (pl.cfg == CFG_HALF) rc = launch_gemm_cfg<false, CfgHalf>(a, pl, nphase, st);
     else if (pl.cfg == CFG_QUARTER) rc = launch_gemm_cfg<false, CfgQuarter>(a, pl, nphase, st);

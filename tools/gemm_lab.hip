@@ -261,6 +261,98 @@ static void layers_table(int batch) {
     printf("# (MIOpen / CK on the same shapes through PyTorch, round 3, profiles/r03_conv_layers_final.txt: fwd 1001 / dgrad 1544 / wgrad 1641 us with ~12 us of Python per call in it)\n");
 }
 
+// ---- round 5: the staggered 256 x 256 loop (tile 2) against the lock-step loop of rounds 1-4 (tile 5) and the 128 x 128 tile (tile 1) ----
+// reference: one thread per output element, fp32 accumulation in k order
+__global__ void ref_gemm_kernel(const unsigned short* __restrict__ A, int lda, const unsigned short* __restrict__ Bt, int ldb, float* __restrict__ C, int ldc,
+                                int M, int N, int K, int m_lo, int n_lo, int m_cnt, int n_cnt) {
+    const int n = n_lo + blockIdx.x * blockDim.x + threadIdx.x, m = m_lo + blockIdx.y;
+    if (n >= n_lo + n_cnt || n >= N || m >= M) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += __uint_as_float((unsigned)A[(size_t)m * lda + k] << 16) * __uint_as_float((unsigned)Bt[(size_t)n * ldb + k] << 16);
+    C[(size_t)(m - m_lo) * ldc + (n - n_lo)] = acc;
+}
+// err[0] = max |c - ref| (as uint bits of a non-negative float), err[1] = max |ref|, err[2] = count of |c - ref| > 0.01 * |ref| + 0.02
+__global__ void cmp_kernel(const unsigned short* __restrict__ C, int ldc, const float* __restrict__ R, int ldr, int m_lo, int n_lo, int m_cnt, int n_cnt, unsigned int* err) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= n_cnt || m >= m_cnt) return;
+    const float c = __uint_as_float((unsigned)C[(size_t)(m_lo + m) * ldc + n_lo + n] << 16), r = R[(size_t)m * ldr + n];
+    const float d = fabsf(c - r);
+    atomicMax(err, __float_as_uint(d));
+    atomicMax(err + 1, __float_as_uint(fabsf(r)));
+    if (d > 0.01f * fabsf(r) + 0.02f) atomicAdd(err + 2, 1u);
+}
+__global__ void checksum_kernel(const unsigned int* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += (unsigned long long)p[i] * (i % 1021 + 1);
+    atomicAdd(out, s);
+}
+
+static float bits_f(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
+static void stag_battery() {
+    const Shape shapes[] = {{"8192^3          ", 8192, 8192, 8192}, {"4096^3          ", 4096, 4096, 4096}, {"2048^3          ", 2048, 2048, 2048},
+                            {"fin.dX 1088->256", 131072, 256, 1088}, {"dc1.dX 2048x2048x4096", 2048, 2048, 4096}, {"dc3 32768x256x1024", 32768, 256, 1024},
+                            {"8192x256x2304   ", 8192, 256, 2304},  {"8192x1024x256   ", 8192, 1024, 256},   {"ragged 1000x520x456", 1000, 520, 456},
+                            {"2048x512x2048   ", 2048, 512, 2048},  {"131072x256x64   ", 131072, 256, 64}};
+    printf("# stag: epi_gemm_bf16, tile 2 = 256x256 staggered loop (round 5), tile 5 = 256x256 lock-step loop (rounds 1-4), tile 1 = 128x128, tile 0 = planner's choice\n");
+    printf("# check: a 512 x 512 corner block + the LAST 256 x 256 block against an fp32 reference (bad = elements off by > 1 %% + 0.02); race screen: 6 reruns, checksum of C\n");
+    unsigned int* err; CK(hipMalloc(&err, 16));
+    unsigned long long* sum; CK(hipMalloc(&sum, 8));
+    float* ref; CK(hipMalloc(&ref, 512 * 512 * 4));
+    for (const Shape& s : shapes) {
+        const int lda = s.K, ldb = s.K, ldc = s.N;
+        const size_t a_bytes = (size_t)s.M * lda * 2, b_bytes = (size_t)s.N * ldb * 2, c_bytes = (size_t)s.M * ldc * 2;
+        size_t ws_bytes = 0;
+        for (int t : {0, 1, 2, 5}) { epi_gemm_tune(t, -1); ws_bytes = std::max(ws_bytes, epi_gemm_workspace_bytes(s.M, s.N, s.K, 1)); }
+        const size_t set = ((a_bytes + b_bytes + c_bytes + 4095) / 4096) * 4096;
+        char* ws = g_arena;
+        char* sets = g_arena + (ws_bytes + 4095) / 4096 * 4096;
+        if ((size_t)(sets - g_arena) + set > g_arena_bytes) { printf("%s (arena too small)\n", s.name); continue; }
+        const int nfresh = (int)std::max<size_t>(1, std::min<size_t>(8, (g_arena_bytes - (sets - g_arena)) / set));
+        hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, (unsigned short*)g_arena, g_arena_bytes / 2, 4242u);
+        for (int tile : {2, 5, 1, 0}) {
+            epi_gemm_tune(tile, -1);
+            int rc = 0;
+            char* base = sets;
+            unsigned short* A = (unsigned short*)base; unsigned short* B = (unsigned short*)(base + a_bytes); unsigned short* C = (unsigned short*)(base + a_bytes + b_bytes);
+            // correctness on set 0
+            CK(hipMemsetAsync(C, 0xff, c_bytes, 0));
+            rc |= epi_gemm_bf16(A, lda, B, ldb, C, ldc, EPI_BF16, s.M, s.N, s.K, nullptr, ws, ws_bytes, 0);
+            unsigned int herr[2][4] = {};
+            for (int blk = 0; blk < 2; ++blk) {
+                const int m_cnt = std::min(s.M, blk ? 256 : 512), n_cnt = std::min(s.N, blk ? 256 : 512);
+                const int m_lo = blk ? s.M - m_cnt : 0, n_lo = blk ? s.N - n_cnt : 0;
+                CK(hipMemsetAsync(err, 0, 16, 0));
+                hipLaunchKernelGGL(ref_gemm_kernel, dim3((n_cnt + 63) / 64, m_cnt), dim3(64), 0, 0, A, lda, B, ldb, ref, 512, s.M, s.N, s.K, m_lo, n_lo, m_cnt, n_cnt);
+                hipLaunchKernelGGL(cmp_kernel, dim3((n_cnt + 63) / 64, m_cnt), dim3(64), 0, 0, C, ldc, ref, 512, m_lo, n_lo, m_cnt, n_cnt, err);
+                CK(hipMemcpy(herr[blk], err, 16, hipMemcpyDeviceToHost));
+            }
+            // race screen: identical reruns must give identical bits
+            unsigned long long first = 0; int mismatches = 0;
+            for (int rep = 0; rep < 6; ++rep) {
+                if (rep) rc |= epi_gemm_bf16(A, lda, B, ldb, C, ldc, EPI_BF16, s.M, s.N, s.K, nullptr, ws, ws_bytes, 0);
+                CK(hipMemsetAsync(sum, 0, 8, 0));
+                hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned int*)C, c_bytes / 4, sum);
+                unsigned long long h; CK(hipMemcpy(&h, sum, 8, hipMemcpyDeviceToHost));
+                if (!rep) first = h; else if (h != first) ++mismatches;
+            }
+            double us[2];
+            for (int fresh = 1; fresh >= 0; --fresh) {
+                const int nset = fresh ? nfresh : 1;
+                us[fresh] = time_launches(s.M >= 8192 && s.N >= 8192 ? 10 : 30, [&](int i) {
+                    char* b = sets + (size_t)(i % nset) * set;
+                    rc |= epi_gemm_bf16(b, lda, b + a_bytes, ldb, b + a_bytes + b_bytes, ldc, EPI_BF16, s.M, s.N, s.K, nullptr, ws, ws_bytes, 0);
+                });
+            }
+            const double flop = 2.0 * s.M * s.N * s.K;
+            printf("%-22s tile %d  fresh %8.2f us (%7.1f TF)  warm %8.2f us (%7.1f TF)  err %.4f / %.4f of max|ref| %.2f  bad %u+%u  rerun mismatches %d  rc %d\n", s.name, tile, us[1],
+                   flop / us[1] * 1e-6, us[0], flop / us[0] * 1e-6, bits_f(herr[0][0]), bits_f(herr[1][0]), bits_f(herr[0][1]), herr[0][2], herr[1][2],
+                   mismatches, rc);
+            fflush(stdout);
+        }
+        epi_gemm_tune(0, -1);
+    }
+}
+
 int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -277,5 +369,6 @@ int main(int argc, char** argv) {
     if (!strcmp(what, "gemm") || !strcmp(what, "all")) gemm_battery(quick);
     if (!strcmp(what, "conv") || !strcmp(what, "all")) conv_battery();
     if (!strcmp(what, "layers")) layers_table(argc > 2 ? atoi(argv[2]) : 32);
+    if (!strcmp(what, "stag")) stag_battery();
     return 0;
 }
