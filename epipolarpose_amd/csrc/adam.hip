@@ -19,7 +19,7 @@ constexpr int ADAM_CHUNK = 16384;       // elements per workgroup
 
 // sum of squares of every gradient (the total norm torch.nn.utils.clip_grad_norm_ computes; refiner/main.py:53): one atomic per chunk
 __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks,
-                                                                  float* __restrict__ sumsq) {
+                                                                  float* __restrict__ sumsq, float* __restrict__ part) {
     __shared__ float red[17];
     const int2 ck = chunks[blockIdx.x];
     const AdamTensor t = table[ck.x];
@@ -31,7 +31,19 @@ __global__ __launch_bounds__(ADAM_THREADS) void grad_sumsq_kernel(const AdamTens
         s = fmaf(g, g, s);
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) atomicAdd(sumsq, s);
+    if (threadIdx.x == 0) {
+        if (part) part[blockIdx.x] = s;         // deterministic mode: one partial per chunk, added in index order by sumsq_total_kernel
+        else atomicAdd(sumsq, s);
+    }
+}
+
+// deterministic mode (csrc/capi.hip): *sumsq += part[0] + part[1] + ... in a FIXED order (thread t adds part[t], part[t + 256], ...; then the fixed tree of block_sum)
+__global__ __launch_bounds__(ADAM_THREADS) void sumsq_total_kernel(const float* __restrict__ part, int n, float* __restrict__ sumsq) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += ADAM_THREADS) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) sumsq[0] += s;
 }
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks,
@@ -121,9 +133,14 @@ extern "C" int epi_adam_step_clipped(const void* table, const void* chunks, int 
                                      long long step, float max_norm, float* norm_sq, epi_stream_t stream) {
     if (!table || !chunks || !norm_sq || nchunks <= 0 || step < 1 || !(max_norm > 0.f)) return EPI_ERR_INVALID_ARGUMENT;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    float* part = epi::deterministic() ? epi::det_scratch((size_t)nchunks) : nullptr;      // (the BatchNorm half: the optimizer runs behind the backward chain on its stream)
     hipLaunchKernelGGL(epi::grad_sumsq_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
-                       (const epi::AdamTensor*)table, (const int2*)chunks, norm_sq);
+                       (const epi::AdamTensor*)table, (const int2*)chunks, norm_sq, part);
     EPI_CHECK_LAUNCH();
+    if (part) {
+        hipLaunchKernelGGL(epi::sumsq_total_kernel, dim3(1), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream, (const float*)part, nchunks, norm_sq);
+        EPI_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(epi::adam_multi_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
                        (const epi::AdamTensor*)table, (const int2*)chunks, beta1, beta2, eps, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)),
                        (const float*)norm_sq, max_norm);

@@ -1,5 +1,6 @@
 // Library identification and error strings for libepipolar_hip.
 #include "common.h"
+#include <mutex>
 
 extern "C" const char* epi_version(void) { return "epipolar_hip 0.1.0 (gfx950)"; }
 
@@ -25,16 +26,34 @@ extern "C" const char* epi_status_string(int status) {
 // gradient, which the training path runs on its weight-gradient stream).  Bit-identical reruns: tests/test_hip_deterministic.py.
 namespace epi {
 static int g_det = 0;
-static float* g_det_buf = nullptr;
 static const size_t DET_FLOATS = (size_t)4 << 20;       // 16 MB per half: 1024 row blocks x 2 x 2048 channels
+// ONE scratch per DEVICE, allocated the first time a launch on that device asks for it: a process that drives device 1 (GPUS: '1', or a rank whose
+// launcher sets the device after epi_set_deterministic) must not write its partial sums into device 0's memory (round-4 advisor finding).
+static const int DET_MAX_DEVICES = 64;
+static float* g_det_buf[DET_MAX_DEVICES] = {};
+static std::mutex g_det_mutex;
 bool deterministic() { return g_det != 0; }
-float* det_scratch(size_t floats, bool column_sums) { return (g_det && floats <= DET_FLOATS) ? g_det_buf + (column_sums ? DET_FLOATS : 0) : nullptr; }
+float* det_scratch(size_t floats, bool column_sums) {
+    if (!g_det || floats > DET_FLOATS) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DET_MAX_DEVICES) return nullptr;
+    float* buf = g_det_buf[dev];
+    if (!buf) {
+        std::lock_guard<std::mutex> lock(g_det_mutex);
+        buf = g_det_buf[dev];
+        if (!buf) {
+            if (hipMalloc(&buf, 2 * DET_FLOATS * sizeof(float)) != hipSuccess) return nullptr;
+            g_det_buf[dev] = buf;
+        }
+    }
+    return buf + (column_sums ? DET_FLOATS : 0);
+}
 }  // namespace epi
 
 extern "C" int epi_set_deterministic(int on) {
     const int before = epi::g_det;
     if (on < 0) return before;              // query
-    if (on && !epi::g_det_buf && hipMalloc(&epi::g_det_buf, 2 * epi::DET_FLOATS * sizeof(float)) != hipSuccess) return -1;
     epi::g_det = on ? 1 : 0;
+    if (on && !epi::det_scratch(1, false)) { epi::g_det = before; return -1; }      // (the current device's scratch now; other devices' at their first use)
     return before;
 }

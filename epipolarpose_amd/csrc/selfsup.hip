@@ -605,6 +605,32 @@ EPI_HD __forceinline__ int tri_iterative_ne(const double (&u)[NV][2], const doub
     return all_front ? 1 : code;
 }
 
+// Linear least squares (triangulation.py:34-97) for float32 STORAGE (round 5): the normal equations A^T A x = A^T b accumulated and solved in float64 from
+// the float32 inputs.  cond(A)^2 ~ 1e8 against float64's 1e-16 leaves ~1e-8 relative -- below the float32 rounding of the result -- at a third of the
+// instructions of the float32 Householder QR (whose ~730 dependent instructions per item, not HBM, bounded the bulk launch at 0.44 of peak).  The
+// float64-storage path keeps the QR (1e-6 mm against cv2.solve(DECOMP_SVD) needs cond, not cond^2).
+template <int NV, typename TI>
+EPI_HD __forceinline__ int tri_ls_ne(const TI (&uu)[NV][2], const TI (&PP)[NV][12], int nv, double (&x)[3]) {
+    double n[6] = {0, 0, 0, 0, 0, 0}, r[3] = {0, 0, 0};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < nv) {
+            const double p8 = (double)PP[v][8], p9 = (double)PP[v][9], p10 = (double)PP[v][10], p11 = (double)PP[v][11];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double uq = (double)uu[v][q];
+                const double a0 = uq * p8 - (double)PP[v][4 * q], a1 = uq * p9 - (double)PP[v][4 * q + 1], a2 = uq * p10 - (double)PP[v][4 * q + 2];
+                const double b = (double)PP[v][4 * q + 3] - uq * p11;                                         // triangulation.py:138-148
+                n[0] = fma(a0, a0, n[0]); n[1] = fma(a0, a1, n[1]); n[2] = fma(a0, a2, n[2]);
+                n[3] = fma(a1, a1, n[3]); n[4] = fma(a1, a2, n[4]); n[5] = fma(a2, a2, n[5]);
+                r[0] = fma(a0, b, r[0]); r[1] = fma(a1, b, r[1]); r[2] = fma(a2, b, r[2]);
+            }
+        }
+    }
+    solve_sym3(n, r, x);
+    return 1;                                                                                                  // triangulation.py:97: status all True
+}
+
 // Mixed precision (round 3): the same iteration with float64 where it is needed and float32 everywhere else.
 //   * round 1 (all weights 1) is the plain least-squares solve: normal equations and solve in float64 -> x0, depths d0;
 //   * every later round only MOVES the solution by a few millimetres (the cumulative re-weighting shifts it between the views'
@@ -731,8 +757,8 @@ EPI_HD __forceinline__ int tri_iterative_mixed(const TI (&uu)[NV][2], const TI (
 // M is the eigenvector of the smallest eigenvalue of the 4 x 4 Gram matrix M^T M -- found by inverse iteration on its (shifted)
 // LDL^T factorisation instead of a Jacobi SVD of M.  The eigenvalue gap is enormous (lambda_4 / lambda_3 = noise^2), three
 // solves converge to float64 round-off; squaring the condition number (1e4 -> 1e8) costs 1e-8 relative, inside the fp32 envelope.
-template <int NV>
-EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (&P)[NV][12], int nv, double (&x)[3]) {
+template <int NV, typename TI = double>
+EPI_HD __forceinline__ int tri_dlt_gram(const TI (&u)[NV][2], const TI (&P)[NV][12], int nv, double (&x)[3]) {
     double g[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -746,7 +772,7 @@ EPI_HD __forceinline__ int tri_dlt_gram(const double (&u)[NV][2], const double (
             for (int r = 0; r < 2; ++r) {
                 double m[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) m[c] = u[v][r] * P[v][8 + c] - P[v][4 * r + c];                 // cv2.triangulatePoints rows
+                for (int c = 0; c < 4; ++c) m[c] = (double)u[v][r] * (double)P[v][8 + c] - (double)P[v][4 * r + c];   // cv2.triangulatePoints rows
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -817,13 +843,13 @@ __device__ __forceinline__ int triangulate_one_dlt(const double (&u)[NV][2], con
     return tri_dlt<NV>(u, P, nv, x);
 }
 
-// Arithmetic type per method for storage type S.  The single-solve LS runs in the storage precision.  The
-// iterative solver always runs in float64: the reference's stopping rule compares depths (~5000 mm) with an
+// Arithmetic type per method for storage type S: float64 everywhere (the inputs stay in the storage type and are converted at use).  The
+// iterative solver must: the reference's stopping rule compares depths (~5000 mm) with an
 // absolute 3e-5 mm tolerance (triangulation.py:161), below fp32 resolution, and its result depends on running
 // exactly as many re-weighting rounds as the reference does.  The homogeneous DLT needs float64 (sigma_max /
 // sigma_3 ~ 1e4).
 template <typename S, int METHOD> struct TriCompute { typedef double type; };
-template <> struct TriCompute<float, TRI_LS> { typedef float type; };
+// (round 5: the float32-storage LS accumulates its normal equations in float64 too -- tri_ls_ne)
 
 template <typename S, int NV, int METHOD>
 __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TRI_DLT) ? 4 : 1) void triangulate_kernel(const S* __restrict__ kps, int kstride, const S* __restrict__ Pm,
@@ -834,7 +860,7 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
     if (t >= (long long)G * J) return;
     const int g = (int)(t / J), j = (int)(t - (long long)g * J);
     // inputs stay in the storage type for the mixed-precision iterative solver (it converts at every use: 56 registers instead of 112)
-    typedef typename std::conditional<METHOD == TRI_ITER && std::is_same<S, float>::value, float, T>::type TIN;
+    typedef typename std::conditional<std::is_same<S, float>::value && METHOD != TRI_POLY, float, T>::type TIN;
     TIN u[NV][2], P[NV][12];
     T x[3];
 #pragma unroll
@@ -842,8 +868,8 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
         if (v < V) {
             const long long s = (long long)v * G + g;                  // img_utils.py:197-202
             const S* kp = kps + (s * J + j) * kstride;
-            u[v][0] = (TIN)kp[0]; u[v][1] = (TIN)kp[1];
             const S* pp = Pm + s * 12;
+            u[v][0] = (TIN)kp[0]; u[v][1] = (TIN)kp[1];
 #pragma unroll
             for (int k = 0; k < 12; ++k) P[v][k] = (TIN)pp[k];
         } else {
@@ -859,13 +885,105 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
         correct_match(F, u[0], u[1]);
         st = tri_dlt<NV>(u, P, V, x);
     } else if constexpr (METHOD == TRI_DLT) {
-        if constexpr (std::is_same<S, float>::value) st = tri_dlt_gram<NV>(u, P, V, x);       // bulk fp32 storage: Gram + inverse iteration
+        if constexpr (std::is_same<S, float>::value) st = tri_dlt_gram<NV, TIN>(u, P, V, x);  // bulk fp32 storage: Gram + inverse iteration
         else st = tri_dlt<NV>(u, P, V, x);
     } else if constexpr (METHOD == TRI_ITER && std::is_same<S, float>::value) {
         st = tri_iterative_mixed<NV, TIN>(u, P, V, tol, max_iter, x);                           // bulk fp32 storage: float64 first round, float32 corrections
+    } else if constexpr (METHOD == TRI_LS && std::is_same<S, float>::value) {
+        st = tri_ls_ne<NV, TIN>(u, P, V, x);                                                    // fp32 storage: float64 normal equations
     } else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
     X[3 * t] = (S)x[0]; X[3 * t + 1] = (S)x[1]; X[3 * t + 2] = (S)x[2];
     if (status) status[t] = st;
+}
+
+// Bulk form of triangulate_kernel (round 5).  The per-item kernel above reads its inputs the way the reference indexes them -- 12 scalar loads of P per view
+// (the J items of a group all fetch the same 48 bytes), 2 per key point, 3 scalar stores per result: ~60 vector-memory instructions per wave for 3.5 KB, which
+// the address path, not HBM, bounds (LS 3.25 TB/s = 0.41 of peak, profiles/r03_microbench_tri.txt).  Here a 256-thread workgroup owns 256 consecutive items
+// (group, joint) = the groups g_lo .. g_hi and
+//   * stages the projection matrices of those groups, per view ONE contiguous block [g_lo .. g_hi][12], through LDS with 16-byte loads (every thread then reads
+//     its group's rows as broadcast 16-byte LDS reads);
+//   * reads a key point as ONE (x, y) vector load per view (kstride == 2: consecutive items are consecutive in memory, 512 bytes per wave instruction);
+//   * parks the results in LDS and writes them out as 16-byte stores.
+// ~7 vector-memory instructions per wave.  Same arithmetic, same results as the per-item kernel (tests/test_hip_selfsup.py runs both).
+template <typename S, int NV, int METHOD>
+__global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD != TRI_POLY) ? 3 : 1)
+void triangulate_staged_kernel(const S* __restrict__ kps, int kstride, const S* __restrict__ Pm, int G, int V, int J, int ng_max, double tol, int max_iter,
+                               S* __restrict__ X, int* __restrict__ status) {
+    typedef typename TriCompute<S, METHOD>::type T;
+    typedef typename std::conditional<std::is_same<S, float>::value && METHOD != TRI_POLY, float, T>::type TIN;
+    extern __shared__ __attribute__((aligned(16))) char tri_lds[];
+    S* Pl = reinterpret_cast<S*>(tri_lds);                                  // [V][ng_max][12]
+    S* Xl = Pl + (size_t)V * ng_max * 12;                                   // [256][3]
+    const int tid = threadIdx.x;
+    const long long total = (long long)G * J, t0 = (long long)blockIdx.x * 256, t = t0 + tid;
+    const int n_items = (int)(total - t0 < 256 ? total - t0 : 256);
+    const int g_lo = (int)(t0 / J), g_hi = (int)((t0 + n_items - 1) / J), ng = g_hi - g_lo + 1;
+    constexpr int VEC = 16 / (int)sizeof(S);                                // elements per 16-byte access (12 is a multiple of it)
+    const bool live = tid < n_items;
+    const int g = live ? (int)(t / J) : g_lo, j = live ? (int)(t - (long long)g * J) : 0;
+    // the key points first: their latency overlaps the staging of the projection matrices
+    TIN u[NV][2], P[NV][12];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < V) {
+            const S* kp = kps + (((long long)v * G + g) * J + j) * kstride;
+            if (kstride == 2) {
+                typedef S vec2 __attribute__((ext_vector_type(2)));
+                const vec2 q = *reinterpret_cast<const vec2*>(kp);
+                u[v][0] = (TIN)q.x; u[v][1] = (TIN)q.y;
+            } else { u[v][0] = (TIN)kp[0]; u[v][1] = (TIN)kp[1]; }
+        } else u[v][0] = u[v][1] = 0;
+    }
+    {
+        const int per_view = ng * 12 / VEC;                                 // 16-byte vectors per view block
+        for (int i = tid; i < V * per_view; i += 256) {
+            const int v = i / per_view, e = i - v * per_view;
+            const uint4v w = *reinterpret_cast<const uint4v*>(Pm + ((long long)v * G + g_lo) * 12 + (long long)e * VEC);
+            *reinterpret_cast<uint4v*>(Pl + ((size_t)v * ng_max * 12) + (size_t)e * VEC) = w;
+        }
+    }
+    __syncthreads();
+    T x[3] = {0, 0, 0};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if (v < V) {
+            const S* pp = Pl + ((size_t)v * ng_max + (g - g_lo)) * 12;
+#pragma unroll
+            for (int k = 0; k < 12; k += VEC) {
+                const uint4v w = *reinterpret_cast<const uint4v*>(pp + k);
+                S tmp[VEC];
+                __builtin_memcpy(tmp, &w, 16);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) P[v][k + e] = (TIN)tmp[e];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P[v][k] = 0;
+        }
+    }
+    int st;
+    if constexpr (METHOD == TRI_POLY) {
+        double F[3][3];
+        fundamental_from_P(P[0], P[1], F);
+        correct_match(F, u[0], u[1]);
+        st = tri_dlt<NV>(u, P, V, x);
+    } else if constexpr (METHOD == TRI_DLT) {
+        if constexpr (std::is_same<S, float>::value) st = tri_dlt_gram<NV, TIN>(u, P, V, x);   // bulk fp32 storage: Gram + inverse iteration
+        else st = tri_dlt<NV>(u, P, V, x);
+    } else if constexpr (METHOD == TRI_ITER && std::is_same<S, float>::value) {
+        st = tri_iterative_mixed<NV, TIN>(u, P, V, tol, max_iter, x);                           // bulk fp32 storage: float64 first round, float32 corrections
+    } else if constexpr (METHOD == TRI_LS && std::is_same<S, float>::value) {
+        st = tri_ls_ne<NV, TIN>(u, P, V, x);
+    } else st = triangulate_one<T, NV, METHOD>(u, P, V, (T)tol, max_iter, x);
+    Xl[3 * tid] = (S)x[0]; Xl[3 * tid + 1] = (S)x[1]; Xl[3 * tid + 2] = (S)x[2];
+    if (status && live) status[t] = st;
+    __syncthreads();
+    {
+        const int n_el = n_items * 3, n_vec = n_el / VEC;
+        S* out = X + t0 * 3;                                                // (t0 * 3 * sizeof(S) is a multiple of 3072: 16-byte aligned)
+        for (int i = tid; i < n_vec; i += 256) *reinterpret_cast<uint4v*>(out + (size_t)i * VEC) = *reinterpret_cast<const uint4v*>(Xl + (size_t)i * VEC);
+        for (int i = n_vec * VEC + tid; i < n_el; i += 256) out[i] = Xl[i];
+    }
 }
 
 // cv2.correctMatches over G fundamental matrices x J pairs each (float64).
@@ -1037,11 +1155,31 @@ static inline MetaDev to_dev(const epi_view_meta* m) {
     return d;
 }
 
+static int g_tri_staged = 1;
+
 template <typename T, int METHOD>
 static int launch_tri(const void* kps, int kstride, const void* P, int G, int V, int J, double tol, int max_iter, void* X,
                       int32_t* status, hipStream_t st) {
     const long long total = (long long)G * J;
     const unsigned grid = (unsigned)((total + 255) / 256);
+    // the staged (bulk) kernel: its LDS block must fit, operands must allow 16-byte accesses; g_tri_staged = 0 forces the per-item kernel (tests run both)
+    const int ng_max = 255 / J + 2;
+    const size_t lds = ((size_t)V * ng_max * 12 + 768) * sizeof(T);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(kps) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(X)) & 15u) == 0;
+    // measured on MI355X, 2^20 groups x 4 views x 17 joints, float32 storage (profiles/r05_microbench_tri.txt): LS 0.271 ms staged / 0.316 per item, DLT 0.351 /
+    // 0.382, iterative 0.897 / 0.770 -- the iterative solver's ten rounds want the per-item kernel's occupancy, the single-solve methods the staged loads
+    const bool want_staged = g_tri_staged == 2 || (g_tri_staged == 1 && (METHOD == TRI_LS || METHOD == TRI_DLT));
+    if (want_staged && aligned && lds <= 65536 && total >= 256) {
+#define EPI_TRI_LAUNCH(NVV)                                                                                               \
+    hipLaunchKernelGGL((triangulate_staged_kernel<T, NVV, METHOD>), dim3(grid), dim3(256), lds, st, (const T*)kps, kstride, (const T*)P, \
+                       G, V, J, ng_max, tol, max_iter, (T*)X, (int*)status)
+        if (V == 2) EPI_TRI_LAUNCH(2);
+        else if (V <= 4) EPI_TRI_LAUNCH(4);
+        else EPI_TRI_LAUNCH(8);
+#undef EPI_TRI_LAUNCH
+        EPI_CHECK_LAUNCH();
+        return EPI_OK;
+    }
 #define EPI_TRI_LAUNCH(NVV)                                                                                               \
     hipLaunchKernelGGL((triangulate_kernel<T, NVV, METHOD>), dim3(grid), dim3(256), 0, st, (const T*)kps, kstride, (const T*)P, \
                        G, V, J, tol, max_iter, (T*)X, (int*)status)
@@ -1067,6 +1205,14 @@ static int tri_entry(const void* kps, int kstride, const void* P, int dtype, int
 }  // namespace epi
 
 using namespace epi;
+
+// 1 (default): bulk launches (>= 256 items, 16-byte aligned operands) of the single-solve methods (ls, dlt) take triangulate_staged_kernel; 2: of every method;
+// 0: always the per-item kernel.  Returns the previous value.
+extern "C" int epi_triangulate_staged(int on) {
+    const int before = g_tri_staged;
+    if (on >= 0) g_tri_staged = on > 2 ? 1 : on;
+    return before;
+}
 
 extern "C" int epi_triangulate_iterls(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                                       double tolerance, int max_iter, void* X, int32_t* status, epi_stream_t stream) {

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "epi_triangulate_ls": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_dlt": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "epi_triangulate_poly": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "epi_triangulate_staged": (_i, [_i]),
     "epi_fundamental_8point": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "epi_fundamental_lmeds_medians": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "epi_fundamental_errors": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),

@@ -140,6 +140,11 @@ int epi_triangulate_ls(const void* kps, int kps_stride, const void* P, int dtype
                        void* X, int32_t* status, epi_stream_t stream);
 int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                         void* X, int32_t* status, epi_stream_t stream);
+/* Bulk launches (>= 256 (group, joint) items, 16-byte aligned kps / P / X) of the single-solve triangulators (ls, dlt) run a staged kernel:
+ * the projection matrices of a workgroup's groups through LDS with 16-byte loads, one (u, v) vector load per view, 16-byte result stores --
+ * the same arithmetic as the per-item kernel.  epi_triangulate_staged: 0 always the per-item kernel, 1 the default above, 2 the staged
+ * kernel for every method (the parity tests run both on the same inputs), negative only queries; returns the previous setting. */
+int epi_triangulate_staged(int on);
 
 /* triangulation.py:184-220 (polynomial_triangulation), V must be 2: F = [t]_x R from the two projection
  * matrices (:196-204), the matches moved onto the closest exactly-epipolar pair (cv2.correctMatches, :210;

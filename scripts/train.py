@@ -83,9 +83,6 @@ def main(argv=None):
 
     torch.backends.cudnn.benchmark = config.CUDNN.BENCHMARK              # MIOpen find mode
     torch.backends.cudnn.deterministic = config.CUDNN.DETERMINISTIC
-    if config.CUDNN.DETERMINISTIC and torch.cuda.is_available():
-        from epipolarpose_amd import hip as _hip
-        _hip.set_deterministic(True)          # ordered BatchNorm sums instead of atomics: bit-identical reruns (epipolar_hip.h)
     torch.backends.cudnn.enabled = config.CUDNN.ENABLED
     # GPUS (config / --gpus): the reference hands the id list to nn.DataParallel (train.py:93-94).  Here one PROCESS drives one GPU:
     # a single process honours a single id; several ids need `python -m torch.distributed.run --nproc-per-node N scripts/train.py ...`
@@ -97,6 +94,10 @@ def main(argv=None):
                            config.TRAIN.BATCH_SIZE, len(gpu_ids))
         local = gpu_ids[0]
     torch.cuda.set_device(local)
+    if config.CUDNN.DETERMINISTIC and torch.cuda.is_available():
+        # (after set_device: the library keeps one partial-sum scratch per device, allocated on the device that is current at first use)
+        from epipolarpose_amd import hip as _hip
+        _hip.set_deterministic(True)          # ordered BatchNorm sums instead of atomics: bit-identical reruns (epipolar_hip.h)
 
     model = models.pose3d_resnet.get_pose_net(config, is_train=True).cuda()
     if rank == 0 and os.path.abspath(os.path.dirname(args.cfg)) != os.path.abspath(final_output_dir):

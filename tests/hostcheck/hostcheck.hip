@@ -75,6 +75,7 @@ extern "C" void hostcheck_triangulate2(int method, const double* u1, const doubl
         else if (method == 2) st = epi::tri_dlt<2>(u, P, 2, x);
         else if (method == 3) st = epi::tri_iterative_mixed<2, double>(u, P, 2, tol, max_iter, x);      // the bulk (fp32-storage) variants, fed float64 inputs here
         else if (method == 4) st = epi::tri_dlt_gram<2>(u, P, 2, x);
+        else if (method == 6) st = epi::tri_ls_ne<2, double>(u, P, 2, x);                                  // round 5: the float32-storage LS (float64 normal equations)
         else st = epi::tri_iterative_ne<2>(u, P, 2, tol, max_iter, x);
         X[3 * i] = x[0]; X[3 * i + 1] = x[1]; X[3 * i + 2] = x[2];
         status[i] = st;

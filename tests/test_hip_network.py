@@ -139,9 +139,12 @@ def _check_network(g, name, layers, image, j, d, b, stride, head_std=None):
     for k, gk in grads.items():
         assert gk is not None and torch.isfinite(gk).all(), k
     # gradients of the bf16 product path: every parameter, against the fp32-grade mode, at a trained state of THIS configuration
-    from trained_state import bf16_vs_precise_at_trained_state
+    from trained_state import assert_not_worse_than_stock, bf16_vs_precise_at_trained_state
     rep = bf16_vs_precise_at_trained_state(layers, image, j, d, TRAINED_BATCH.get(name, b), tag="trained/" + name)
-    TRAINED_REPORT[name] = {k: v for k, v in rep.items() if k != "cos"}
+    TRAINED_REPORT[name] = {k: v for k, v in rep.items() if k not in ("cos", "cos_stock")}
+    # (round 5) the teeth: per tensor class against the STOCK bf16 network on the same weights and batch -- cosine not more than 0.02 below stock's, norm
+    # within 15 %.  The absolute floors below stay as a backstop only.
+    assert_not_worse_than_stock(rep)
     lo, p05, med = TRAINED_FLOORS[name]
     assert rep["n_params"] == len(grads), (rep["n_params"], len(grads))
     assert abs(rep["loss_bf16"] - rep["loss_precise"]) <= 5e-3 * rep["loss_precise"], rep["worst"]

@@ -354,3 +354,47 @@ def test_fundamental_lmeds_vs_oracle(dev, n, outliers):
     fm, (k1, k2) = cam.get_fundamental_matrix(u1, u2)
     np.testing.assert_allclose(fm, ref_f, rtol=1e-9, atol=1e-12 * np.abs(ref_f).max())
     assert k1.dtype == np.int32 and len(k1) == len(k2) == int(ref_mask.sum()) and np.array_equal(k1, i1[ref_mask == 1])
+
+
+# ------------------------------------------------------------------ round 5: the staged bulk kernel against the per-item kernel
+@pytest.mark.parametrize("n_view,g_n,j", [(2, 40, 17), (4, 64, 17), (4, 31, 16), (3, 300, 1), (6, 23, 13), (4, 1000, 3)])
+def test_staged_bulk_kernel_matches_per_item_kernel(dev, n_view, g_n, j):
+    """triangulation.py:8-27,34-97,104-181 through csrc/selfsup.hip:triangulate_staged_kernel (>= 256 items: LDS-staged projection matrices, vector
+    key-point loads, 16-byte result stores) and through triangulate_kernel on the SAME inputs: the arithmetic is shared, so results agree to the last
+    bits and status codes exactly -- ragged last workgroup, groups straddling workgroups (J = 17 / 13 / 3), one item per group (J = 1), float64 and float32 storage,
+    and an unaligned key-point view that must fall back to the per-item kernel by itself."""
+    from epipolarpose_amd import hip
+    lib = hip.load()
+    sc = scene(g_n, j, 500 + n_view + j, n_view=n_view, noise_px=2.0)
+    kps = torch.from_numpy(sc.kps_img).to(dev)
+    pm = torch.from_numpy(sc.meta["projection_matrix"]).to(dev)
+    assert g_n * j >= 256
+    methods = ["iterative", "ls", "dlt"] + (["poly"] if n_view == 2 else [])
+    try:
+        for dt in (torch.float64, torch.float32):
+            k, p = kps[..., :2].to(dt).contiguous(), pm.to(dt).contiguous()        # two entries per key point: the vector-load path
+            for method in methods:
+                lib.epi_triangulate_staged(0)
+                xi, si = hip.triangulate(k, p, n_view, method)
+                for mode in (2, 1):                     # the staged kernel for every method / the default selection
+                    lib.epi_triangulate_staged(mode)
+                    xs, ss = hip.triangulate(k, p, n_view, method)
+                    # (the same source arithmetic; the compiler contracts multiply-adds differently per instantiation -> last-bit differences)
+                    tol = 1e-9 if dt == torch.float64 else 2e-4
+                    assert (xs - xi).abs().max().item() <= tol, (method, dt, mode, (xs - xi).abs().max().item())
+                    assert torch.equal(ss, si), (method, dt, mode)
+                lib.epi_triangulate_staged(1)
+            # three entries per key point (u, v, score): the scalar key-point path of the staged kernel
+            k3 = torch.cat([k, torch.ones_like(k[..., :1])], dim=-1).contiguous()
+            xs3, _ = hip.triangulate(k3, p, n_view, "ls")
+            x2, _ = hip.triangulate(k, p, n_view, "ls")
+            assert torch.equal(xs3, x2)
+        # oracle on a few groups of the float64 run (the staged kernel is the default path)
+        x, st = hip.triangulate(kps, pm, n_view, "iterative")
+        for grp in (0, g_n // 2, g_n - 1):
+            idx = [v * g_n + grp for v in range(n_view)]
+            ref, rst = o_tri.iterative_ls_triangulation(sc.kps_img[idx], sc.meta["projection_matrix"][idx])
+            np.testing.assert_allclose(x[grp].cpu().numpy(), ref, atol=1e-6)
+            np.testing.assert_array_equal(st[grp].cpu().numpy(), rst)
+    finally:
+        lib.epi_triangulate_staged(1)

@@ -71,6 +71,9 @@ def test_bulk_variants_match_reference_golden(golden, hostlib, noise):
             np.testing.assert_array_equal(st, g[tag + "/iter_status"])
             x, st = _tri(hostlib, 4, u[va, grp], u[vb, grp], ps[va], ps[vb])
             np.testing.assert_allclose(x, g[tag + "/eigen_x"], atol=1e-4)
+            x, st = _tri(hostlib, 6, u[va, grp], u[vb, grp], ps[va], ps[vb])        # round 5: LS through float64 normal equations (the fp32-storage path)
+            np.testing.assert_allclose(x, g[tag + "/ls_x"], atol=1e-4)
+            assert (st == 1).all()
     print("mixed-precision iterative solver: worst |x - reference| = %.2e mm (noise %d px)" % (worst, noise))
 
 

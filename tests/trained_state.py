@@ -18,6 +18,30 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
+def tensor_class(key):
+    """stem / layer1 .. layer4 / head: the classes the bf16 product path is held to the stock-bf16 yardstick on."""
+    if key.startswith(("conv1", "bn1")):
+        return "stem"
+    if key.startswith("layer"):
+        return key.split(".")[0]
+    return "head"
+
+
+def assert_not_worse_than_stock(rep, margin=0.02, norm_margin=0.15):
+    """Per tensor class, on the class's CONCATENATED gradient (one vector per class: per-tensor cosines of the small BatchNorm tensors are two independent
+    bf16 noise draws, the concatenation is not): cosine(ours, fp32-grade) >= cosine(stock bf16, fp32-grade) - margin, and the gradient norm within
+    norm_margin of the fp32-grade norm or of the stock-bf16 norm's own deviation.  A dropped term or a wrong scale in one layer class shows up here however
+    well-correlated it stays, because the library kernels do not make that mistake."""
+    bad = []
+    for name, c in sorted(rep["by_class"].items()):
+        if c["cos_ours"] < c["cos_stock"] - margin:
+            bad.append((name, "cosine", c["cos_ours"], c["cos_stock"]))
+        dev_ours, dev_stock = abs(c["norm_ratio_ours"] - 1.0), abs(c["norm_ratio_stock"] - 1.0)
+        if dev_ours > norm_margin and dev_ours > dev_stock + 0.5 * norm_margin:
+            bad.append((name, "norm", c["norm_ratio_ours"], c["norm_ratio_stock"]))
+    assert not bad, bad
+
+
 def bf16_vs_precise_at_trained_state(layers, image, j, d, b, steps=10, seed=7, tag="trained"):
     """`steps` Adam steps in the fp32-grade mode from a seeded initialisation (torch's default backbone initialisation, the reference's own
     N(0, 0.001) head, pose3d_resnet.py:222-239), then one forward + backward of BOTH paths on the same weights and batch.
@@ -76,17 +100,41 @@ def _compare(layers, image, j, d, b, steps, seed, tag):
     loss16 = crit(logits, gt, wt)
     loss16.backward()
     torch.cuda.synchronize()
-    cos, dims = {}, {}
+    # the STOCK yardstick (round 5): the oracle network -- PyTorch-ROCm library kernels -- under the same bf16 autocast, from the same trained weights on the
+    # same batch.  What bf16 activations cost against the fp32-grade gradients is measured, per tensor class, on a path that shares no kernel with ours.
+    from oracle import network as o_net
+    sd_stock = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.detach().clone()) for k, v in state.items()}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        logits_stock = o_net.forward(sd_stock, x, layers, training=True, new_stats={})
+    loss_stock = crit(logits_stock.to(torch.bfloat16).contiguous(memory_format=torch.channels_last), gt, wt)
+    loss_stock.backward()
+    torch.cuda.synchronize()
+    cos, dims, cos_stock = {}, {}, {}
+    classes = {}
     for k, p in model.named_parameters():
         if p.grad is not None:
-            cos[k] = cosine(p.grad.float().cpu(), sd[k].grad.cpu())
+            ours, ref, stock = p.grad.float().cpu(), sd[k].grad.cpu(), sd_stock[k].grad.float().cpu()
+            cos[k] = cosine(ours, ref)
+            cos_stock[k] = cosine(stock, ref)
             dims[k] = p.dim()
+            c = classes.setdefault(tensor_class(k), {"ours": [], "ref": [], "stock": [], "n": 0})
+            c["ours"].append(ours.reshape(-1).double()); c["ref"].append(ref.reshape(-1).double()); c["stock"].append(stock.reshape(-1).double())
+            c["n"] += 1
+    by_class = {}
+    for name, c in classes.items():
+        o, r, t = torch.cat(c["ours"]), torch.cat(c["ref"]), torch.cat(c["stock"])
+        keys = [k for k in cos if tensor_class(k) == name]
+        by_class[name] = {"n": c["n"], "cos_ours": cosine(o, r), "cos_stock": cosine(t, r), "norm_ratio_ours": float(o.norm() / (r.norm() + 1e-300)),
+                          "norm_ratio_stock": float(t.norm() / (r.norm() + 1e-300)),
+                          "median_cos_ours": float(np.median([cos[k] for k in keys])), "median_cos_stock": float(np.median([cos_stock[k] for k in keys])),
+                          "min_cos_ours": float(min(cos[k] for k in keys)), "min_cos_stock": float(min(cos_stock[k] for k in keys))}
     vals = np.sort(np.asarray(list(cos.values())))
     head = [v for k, v in cos.items() if k.startswith(("deconv_layers", "final_layer"))]
     # the weight tensors proper (convolutions, deconvolutions, the final layer) apart from the BatchNorm scales / biases, whose gradients are the
     # small differences of large sums that bf16 activations hurt most (the minima over ALL tensors are always layer-1 / stem BatchNorm biases)
     wvals = np.sort(np.asarray([v for k, v in cos.items() if dims[k] >= 2]))
-    return {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item()), "cos": cos, "n_params": len(cos),
+    return {"loss_precise": float(loss32.item()), "loss_bf16": float(loss16.item()), "loss_stock_bf16": float(loss_stock.item()), "cos": cos, "cos_stock": cos_stock,
+            "by_class": by_class, "n_params": len(cos),
             "min_cos": float(vals[0]), "p05_cos": float(vals[len(vals) // 20]), "median_cos": float(np.median(vals)), "head_min_cos": float(min(head)),
             "n_weights": int(len(wvals)), "min_cos_weights": float(wvals[0]), "p05_cos_weights": float(wvals[len(wvals) // 20]),
             "median_cos_weights": float(np.median(wvals)), "worst": sorted(cos.items(), key=lambda kv: kv[1])[:5],

@@ -106,10 +106,14 @@ def bench_tri():
     from epipolarpose_amd.synthetic import make_cameras
     pm = torch.cat([torch.from_numpy(c["projection_matrix"]).float().expand(g_n, 3, 4) for c in make_cameras(v_n)]).contiguous().to(DEV)
     nbytes = (v_n * j * 2 + v_n * 12 + j * 3) * 4.0 * g_n
-    for method in ("ls", "iterative", "dlt"):
-        t = timeit(lambda: hip.triangulate(kps, pm, v_n, method), iters=5, warm=1)
-        print("triangulate %-9s f32 storage 2^20 groups x 4 views: %.3f ms  %7.1f GB/s (%.3f of HBM peak)" % (
-            method, t, nbytes / t / 1e6, nbytes / t / 1e6 / HBM), flush=True)
+    lib = hip.load()
+    for staged in (2, 0):       # round 5: the staged bulk kernel / the per-item kernel with vector loads / the per-item kernel of rounds 1-4
+        lib.epi_triangulate_staged(staged)
+        for method in ("ls", "iterative", "dlt"):
+            t = timeit(lambda: hip.triangulate(kps, pm, v_n, method), iters=8, warm=2)
+            print("triangulate %-9s f32 storage 2^20 groups x 4 views, %s kernel: %.3f ms  %7.1f GB/s (%.3f of HBM peak)" % (
+                method, ("per-item", "default ", "staged  ")[staged], t, nbytes / t / 1e6, nbytes / t / 1e6 / HBM), flush=True)
+    lib.epi_triangulate_staged(1)
     # polynomial (optimal) two-view solver: compute bound (root isolation, ~20k f64 flops per point), realistic 2 px noise
     from epipolarpose_amd.synthetic import project
     g2 = 1 << 16
