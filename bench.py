@@ -43,6 +43,10 @@ def parse_args():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' + --same-device lets "
                     "the N>1 code path be exercised on a single-GPU box")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (functional testing only)")
+    ap.add_argument("--allreduce", choices=["default", "ring", "direct"], default="default",
+                    help="gradient collective at N > 1 (SURVEY section 5: xGMI is point-to-point): default = one all-reduce per bucket, algorithm and "
+                         "channels chosen by RCCL; ring = the same with NCCL_ALGO=Ring pinned before the communicator exists; direct = reduce-scatter + "
+                         "all-gather as grouped point-to-point transfers, one per peer / xGMI link (epipolarpose_amd/distributed.py)")
     ap.add_argument("--force-grad-sync", action="store_true", help="diagnostic: run the N>1 gradient-bucket path at N=1 (copies "
                     "into the flat buckets, no collective) to price its overhead on one GPU")
     ap.add_argument("--refiner-leg", action="store_true", help="also time the refiner MLP beside the step (configs[4] names it: post-lift refinement of "
@@ -178,6 +182,18 @@ def cpu_baseline(args, scenes):
                                         scenes.n_view, want_world=True)
         err = np.linalg.norm(xw.cpu().numpy() - xw_ref[:scenes.n_group], axis=2)
         out["mpjpe_vs_ref_mm"] = float(err.mean())
+    if ref is None:
+        # The reference itself cannot travel to the GPU box; its timing on the BUILD container's cores (bench.py --cpu-baseline-only there, committed
+        # under profiles/) rides in the same record, so that the port's figure on this host and the reference's own figure are never apart.
+        path = os.path.join(ROOT, "profiles", "r05_cpu_baseline_reference_build_container.json")
+        if not os.path.isfile(path):
+            path = os.path.join(ROOT, "profiles", "r04_cpu_baseline_reference_build_container.json")
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            out["reference_build_container"] = dict(rec["cpu_baseline"], host_cpus=rec.get("host", {}).get("cpus"), file=os.path.relpath(path, ROOT))
+        except (OSError, ValueError, KeyError):
+            pass
     return out
 
 
@@ -395,7 +411,9 @@ def self_launch(args):
 
 def rank_inventory(world, device):
     """Who took part, for the JSON line's `config`: backend, RCCL version, every rank's device."""
-    inv = {"backend": None, "world_size": world, "rccl_version": None, "devices": [torch.cuda.get_device_name(device)]}
+    inv = {"backend": None, "world_size": world, "rccl_version": None, "devices": [torch.cuda.get_device_name(device)],
+           # what decides the all-reduce's shape on xGMI: the env RCCL reads (None = its own choice) -- `--allreduce` is recorded by the caller
+           "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS")}
     if world > 1:
         inv["backend"] = torch.distributed.get_backend()
         names = [None] * world
@@ -425,6 +443,8 @@ def main():
 
     if args.same_device:
         os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+    if args.allreduce == "ring":
+        os.environ["NCCL_ALGO"] = "Ring"               # (read by RCCL when the communicator is created, i.e. at the first collective)
     rank, world, local = epd.init_from_env(backend=args.backend, set_device=not args.same_device)
     if args.same_device:
         local = 0
@@ -447,7 +467,7 @@ def main():
         enable_step_in_backward(optimizer, model)       # EPI_STEP_IN_BACKWARD=1 only (measured: < 1 %)
     if world > 1 or args.force_grad_sync:
         epd.broadcast_module(model, optimizer=optimizer)
-        grad_sync = epd.BucketedGradSync(model, optimizer=optimizer)
+        grad_sync = epd.BucketedGradSync(model, optimizer=optimizer, collective="direct" if args.allreduce == "direct" else "allreduce")
     n_view = args.views if args.workload == "ss" else None
     # 4-view SS uses the V-view generalisation of the reference's iterative LS solver (V=2 is the reference itself)
 
@@ -527,6 +547,10 @@ def main():
         elapsed = float(t.item())
     final_loss = float(loss.item())
     inventory = rank_inventory(world, device)
+    inventory["allreduce"] = args.allreduce
+    if grad_sync is not None:
+        inventory["gradient_buckets"] = len(grad_sync.buckets)
+        inventory["gradient_bytes_per_step"] = grad_sync.total_bytes()
     # the other single-GPU workload of BASELINE.json (configs[2]: pseudo labels from multi-view triangulation inside the step)
     # rides along as an extra field of the same JSON line: same model / optimizer state, `steps` more steps, same timing rules
     ss_line = None

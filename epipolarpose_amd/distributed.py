@@ -67,6 +67,34 @@ def broadcast_module(module, src=0, optimizer=None):
         optimizer.refresh_training_copies()
 
 
+class _DirectHandle:
+    """One bucket of the "direct" collective in flight (BucketedGradSync._start_collective): wait() finishes the scatter phase and reduces this rank's
+    slice (fp32 sum in rank order -- the same result on every backend), start_gather() / wait_gather() send it to every peer and collect theirs."""
+
+    def __init__(self, flat, slices, recv, works, me, n):
+        self.flat, self.slices, self.recv, self.works, self.me, self.n = flat, slices, recv, works, me, n
+        self.gather = []
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.recv[self.me].copy_(self.slices[self.me])
+        self.slices[self.me].copy_(self.recv.float().sum(0))
+
+    def start_gather(self):
+        ops = []
+        for peer in range(self.n):
+            if peer != self.me:
+                ops.append(dist.P2POp(dist.isend, self.slices[self.me], peer))
+                ops.append(dist.P2POp(dist.irecv, self.slices[peer], peer))
+        self.gather = dist.batch_isend_irecv(ops)
+
+    def wait_gather(self):
+        for w in self.gather:
+            w.wait()
+        self.gather = []
+
+
 class BucketedGradSync:
     """Average gradients across ranks with a few large all-reduces overlapped with backward.
 
@@ -79,7 +107,15 @@ class BucketedGradSync:
     ResNet-50) plus the bucket memsets.  One backward per step (no gradient accumulation across backward calls).
     """
 
-    def __init__(self, module, bucket_bytes=32 << 20, grad_dtype=None, optimizer=None):
+    def __init__(self, module, bucket_bytes=32 << 20, grad_dtype=None, optimizer=None, collective="allreduce"):
+        # collective (SURVEY section 5: xGMI is point-to-point, a ring is bound by ONE link):
+        #   "allreduce"  one dist.all_reduce per bucket -- the library (RCCL) picks algorithm and channels (NCCL_ALGO / NCCL_PROTO pin them);
+        #   "direct"     reduce-scatter + all-gather written as grouped point-to-point transfers: rank r sends slice j of the bucket straight to rank j
+        #                (N - 1 concurrent sends, one per xGMI link), sums the N slices it owns in fp32, and sends the reduced slice straight to every peer.
+        #                Each link carries S / N per phase instead of the ring's 2 (N - 1) S / N over one link.
+        if collective not in ("allreduce", "direct"):
+            raise ValueError("collective must be 'allreduce' or 'direct', got %r" % (collective,))
+        self.collective = collective
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         copies = optimizer.training_copies() if hasattr(optimizer, "training_copies") else {}
@@ -139,6 +175,8 @@ class BucketedGradSync:
 
     def _make_bucket(self, plist, grad_dtype):
         total = sum(p.numel() for p in plist)
+        if self.collective == "direct" and self.world > 1:
+            total = (total + self.world - 1) // self.world * self.world       # equal slices (the padding stays zero)
         flat = torch.zeros(total, dtype=grad_dtype or plist[0].dtype, device=plist[0].device)
         off, views = 0, []
         for p in plist:
@@ -181,9 +219,7 @@ class BucketedGradSync:
             from . import hip
             hip.glue().pack_bucket(plist, views)         # the loop below, in C++ (0.3 ms of Python per step otherwise)
             self._launched.add(bi)
-            if self.world > 1:
-                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-                self._handles.append(dist.all_reduce(flat, op=op, async_op=True))
+            self._start_collective(flat)
             return
         dst, src = [], []
         for p, v in zip(plist, views):
@@ -228,9 +264,25 @@ class BucketedGradSync:
         for p, v in zip(plist, views):
             p.grad = v
         self._launched.add(bi)
-        if self.world > 1:
+        self._start_collective(flat)
+
+    def _start_collective(self, flat):
+        if self.world <= 1:
+            return
+        if self.collective == "allreduce":
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._handles.append(dist.all_reduce(flat, op=op, async_op=True))
+            return
+        # direct, phase 1 (scatter): slice j of my bucket -> rank j; the slices of MY index arrive from everybody
+        n, me = self.world, dist.get_rank()
+        slices = flat.view(n, -1)
+        recv = torch.empty_like(slices)
+        ops = []
+        for peer in range(n):
+            if peer != me:
+                ops.append(dist.P2POp(dist.isend, slices[peer], peer))
+                ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
+        self._handles.append(_DirectHandle(flat, slices, recv, dist.batch_isend_irecv(ops), me, n))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -282,6 +334,12 @@ class BucketedGradSync:
                 self._launch(bi)
         for h in self._handles:
             h.wait()
+        for h in self._handles:               # direct form: the all-gather phases of all buckets, started together, then awaited
+            if isinstance(h, _DirectHandle):
+                h.start_gather()
+        for h in self._handles:
+            if isinstance(h, _DirectHandle):
+                h.wait_gather()
         self._handles = []
         if self.world > 1 and not self._avg:
             inv = 1.0 / self.world

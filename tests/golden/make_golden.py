@@ -32,7 +32,8 @@ torch.set_num_threads(8)
 
 
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
+    # EPI_GOLDEN_OUT: write somewhere else (tests/test_golden_regeneration.py regenerates the fast sets into a temporary directory and compares)
+    path = os.path.join(os.environ.get("EPI_GOLDEN_OUT", HERE), name)
     np.savez_compressed(path, **arrays)
     print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024.0))
 
