@@ -32,7 +32,7 @@ _LIB_ALIASES = {
     "refiner.data": "epipolarpose_amd.refiner.data",
     "lib.utils.augmentation": "epipolarpose_amd.utils.augmentation",
     "lib.dataset": "epipolarpose_amd.dataset",
-    "lib.dataset.h36m": "epipolarpose_amd.dataset.synthetic",
+    "lib.dataset.h36m": "epipolarpose_amd.dataset.h36m",
 }
 
 

@@ -452,7 +452,7 @@ static inline void reduce_blocking(long long R, int C, int* rows_per_wg, dim3* g
 // run 8 workgroups per CU), >= 128 rows (four per lane) each
 static inline void apply_blocking(long long R, int C, int* rows_per_wg, dim3* grid, int slab_width) {
     const int nslab = (C + slab_width - 1) / slab_width;
-    static const long long target = [] { const char* e = getenv("EPI_BN_2D_WGS"); const long long v = e ? atoll(e) : 2048; return v >= 64 ? v : 2048; }();
+    const long long target = 2048;
     long long nrb = target / nslab;
     const long long max_rb = (R + 127) / 128;
     if (nrb > max_rb) nrb = max_rb;
@@ -466,7 +466,7 @@ static inline void apply_blocking(long long R, int C, int* rows_per_wg, dim3* gr
 // EPI_BN_2D: bit 0 forward apply, bit 1 backward apply on the 2-D kernels (default 3 = both; 0 = the grid-stride kernels)
 static int g_bn_2d = -1;
 static inline int bn_2d_mode() {
-    if (g_bn_2d < 0) { const char* e = getenv("EPI_BN_2D"); g_bn_2d = e ? atoi(e) & 3 : 3; }
+    if (g_bn_2d < 0) g_bn_2d = 3;
     return g_bn_2d;
 }
 

@@ -1375,11 +1375,7 @@ struct GemmPlan { int cfg; int nsplit, kps; long long tiles; int pipe; };
 // EPI_GEMM_TILE=small|big forces a tile configuration (benchmarking); default: by shape
 static int g_tile_force_fwd();
 static int gemm_tile_override() {
-    static const int v = [] {
-        const char* e = getenv("EPI_GEMM_TILE");
-        if (!e) return 0;
-        return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
-    }();
+    const int v = 0;
     const int f = g_tile_force_fwd();
     return f == 1 || f == 2 ? f : (f == 5 ? 2 : v);
 }
@@ -1392,7 +1388,7 @@ static int gemm_tile_override() {
 // the global->LDS fill itself (32 KB per 128x128x64 tile step, ~23 GB/s per CU = ~6 TB/s over the chip), so it gains nothing here
 static int g_pipe_force_fwd();
 static int gemm_pipe_mode() {
-    static const int v = [] { const char* e = getenv("EPI_GEMM_PIPE"); return e ? atoi(e) : 0; }();
+    const int v = 0;
     const int f = g_pipe_force_fwd();
     return f >= 0 ? f : v;
 }
@@ -1400,7 +1396,7 @@ static int gemm_pipe_mode() {
 // tile / pipeline overrides at run time (tuning hook; -1 only queries): tile 0 by shape, 1 small, 2 big, 3 half, 4 quarter; pipe as EPI_GEMM_PIPE
 static int g_store_policy = -1;
 static int gemm_store_policy() {
-    if (g_store_policy < 0) { const char* e = getenv("EPI_GEMM_STORES"); g_store_policy = (e && e[0] == 'n') ? 1 : 0; }       // EPI_GEMM_STORES=nt
+    if (g_store_policy < 0) g_store_policy = 0;
     return g_store_policy;
 }
 extern "C" int epi_gemm_store_policy(int v) {
@@ -1431,7 +1427,7 @@ static GemmPlan gemm_plan_cfg(int cfg, int M, int N, int K, int nphase, bool pip
     // 16 K tiles beats two splits + the finish kernel (ResNet-50 layer4.conv1: 16 us vs 27 us)
     // (EPI_GEMM_ENOUGH: measurement switch.  120 vs 200 on MI355X, profiles/r02_conv_layers_e_*: the 128-tile layers -- ResNet-50
     // layer3 1x1 at batch 32 -- run unsplit in 14.6 us instead of 21.9 us with four splits + finish; 60 loses again)
-    static const long long enough_env = [] { const char* e = getenv("EPI_GEMM_ENOUGH"); return e ? atoll(e) : 120LL; }();
+    const long long enough_env = 120;
     const long long enough = enough_env, target = one_per_cu ? 256 : 512;
     int nsplit = 1;
     if (wgs < enough) {
@@ -1466,7 +1462,7 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
         // (round 4) ... unless the 256 x 256 tile has to split K while 128 x 128 tiles fill the chip UNSPLIT: the unsplit launch needs no finish launch and
         // can carry the fused column sums.  The first deconvolution's backward-data (2048 x 2048 x 4096): 49 us + 18 us finish + 11 us BatchNorm-backward
         // reduction on four splits of 64 tiles, 54 us alone on 256 unsplit tiles (tools/bench_nt_tiles.py).  EPI_GEMM_BIG_SPLIT=1: the round-3 choice.
-        static const bool big_split_ok = [] { const char* e = getenv("EPI_GEMM_BIG_SPLIT"); return e && e[0] == '1'; }();
+        const bool big_split_ok = false;
         const bool small_fills_unsplit = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase >= 200;
         if (ov == 2 || (fills && deep && (pb.nsplit == 1 || big_split_ok || !small_fills_unsplit))) return pb;
     }
@@ -1477,7 +1473,7 @@ static GemmPlan gemm_plan(int M, int N, int K, int ldc, int nphase, bool out_f32
     // smaller tiles while the launch leaves CUs without two workgroups (EPI_GEMM_FILL: the workgroup count below which the next
     // smaller tile is taken; 0 = never, the default -- measured per layer and in the step (profiles/r02_conv_layers_g_*): a few layers
     // gain 1 .. 5 us, the stride-2 3x3 layers lose 30 us, the step 7.64 (off) / 7.70 (384) / 7.81 ms (640))
-    static const long long fill_env = [] { const char* e = getenv("EPI_GEMM_FILL"); return e ? atoll(e) : 0LL; }();
+    const long long fill_env = 0;
     if (cfg == CFG_SMALL && !out_f32 && (g_tile_force == 3 || g_tile_force == 4)) cfg = g_tile_force == 3 ? CFG_HALF : CFG_QUARTER;
     else if (cfg == CFG_SMALL && ov == 0 && !out_f32 && fill_env > 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * nphase;
@@ -1572,7 +1568,7 @@ struct PatchPlan { bool ok; int cfg, nb, patch_px, nsplit, cps; long long tiles;
 // EPI_CONV3X3_PATCH: 0 never (the generic gather kernel), 1 only where the tiles fill the chip without a channel split, 2 (default) always
 static int g_patch_mode = -1;
 static int patch_mode() {
-    if (g_patch_mode < 0) { const char* e = getenv("EPI_CONV3X3_PATCH"); g_patch_mode = e ? atoi(e) : 2; }
+    if (g_patch_mode < 0) g_patch_mode = 2;
     return g_patch_mode;
 }
 // tuning / test hook: set the mode (0 .. 2; anything else only queries); returns the mode in force before the call
@@ -1641,12 +1637,12 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     if (red_done) *red_done = 0;
     a.store_policy = gemm_store_policy();
     // EPI_BN_BWD_FUSE=0: never (A/B measurements)
-    static const bool fuse_red = [] { const char* e = getenv("EPI_BN_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    const bool fuse_red = true;
     GemmBnRed want_red = a.br;
     a.br = GemmBnRed{};
     // EPI_BN_BWD_FUSE_MAX_ROWS / _MIN_ROWS: fuse only for outputs of at most / at least that many rows (all phases together) -- measurement switches
-    static const long long red_max_rows = [] { const char* e = getenv("EPI_BN_BWD_FUSE_MAX_ROWS"); return e ? atoll(e) : (1LL << 40); }();
-    static const long long red_min_rows = [] { const char* e = getenv("EPI_BN_BWD_FUSE_MIN_ROWS"); return e ? atoll(e) : 0LL; }();
+    const long long red_max_rows = 1LL << 40;
+    const long long red_min_rows = 0;
     if (deterministic() || !fuse_red || !red_done || !want_red.z || !want_red.bn || !want_red.sums || a.stats || a.bias ||
         ((reinterpret_cast<uintptr_t>(want_red.z) | reinterpret_cast<uintptr_t>(want_red.y)) & 15u) || (long long)a.M * nphase > red_max_rows ||
         (long long)a.M * nphase < red_min_rows)
@@ -1662,7 +1658,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     // atomics, 8 lanes x 8 strided columns per instruction -- 16 (instruction, line) pairs per wave and line, which L2 serialises at
     // ~9 ns each (layer-1 convolutions 26 us -> 230 .. 430 us, profiles/r02_fs_steady_state_x_*).  Now: one contiguous atomic
     // instruction per workgroup after an LDS combine (as the standalone statistics kernel does).
-    static const bool fuse_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS"); return !(e && e[0] == '0'); }();
+    const bool fuse_stats = true;
     float* const want_stats = (fuse_stats && !deterministic()) ? a.stats : nullptr;      // (deterministic mode: no column sums by atomics, csrc/capi.hip)
     a.stats = nullptr;
     if (!a.A || !a.Bt || !a.C || a.M <= 0 || a.N <= 0 || a.K <= 0) return EPI_ERR_INVALID_ARGUMENT;
@@ -1705,7 +1701,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
     // A launch that wants BatchNorm statistics leaves the A-stationary kernel for the generic one, whose epilogue delivers them: 6.530 vs 6.562
     // ms/step against the A-stationary kernel + a separate statistics pass over its output (forward convolutions +46 us, BatchNorm -64 us and 8
     // launches; EPI_STATS_OFF_ASTAT=0 restores the round-2 arrangement; statistics from the A-stationary epilogue itself cost more than either)
-    static const bool stats_off_astat = [] { const char* e = getenv("EPI_STATS_OFF_ASTAT"); return !(e && e[0] == '0'); }();
+    const bool stats_off_astat = true;
     if (!want_red.z && !(want_stats && stats_off_astat && !a.bias) && !half_addend &&
         !out_f32 && !a.ga.enabled && !a.sc.enabled && nphase == 1 && (a.K == 64 || a.K == 128 || a.K == 256) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && a.N >= 4 * AS_BN && a.N <= 8192 && a.M >= 64 * AS_BM && gemm_tile_override() == 0) {
@@ -1713,7 +1709,7 @@ static int launch_gemm(GemmArgs a, bool out_f32, int nphase, void* workspace, si
         // BatchNorm statistics from THIS kernel's epilogue are off by default (EPI_FUSE_BN_STATS_ASTAT=1 turns them on): in the step trace the
         // A-stationary launches with statistics take 39 / 37 us (K = 64 / 128) against 21 / 20 us without -- more than the separate statistics
         // pass over their output costs (14 / 8 us); measured in the step, same box: 7.06 ms without, 7.13 ms with
-        static const bool astat_stats = [] { const char* e = getenv("EPI_FUSE_BN_STATS_ASTAT"); return e && e[0] == '1'; }();
+        const bool astat_stats = false;
         if (want_stats && !a.bias && astat_stats) { a.stats = want_stats; if (stats_done) *stats_done = 1; }
 #define EPI_ASTAT(KS)                                                                                                      \
         do {                                                                                                               \
@@ -2307,12 +2303,12 @@ static TnPlan tn_plan(int R, int I, int J) {
     // launches (deconvolution head, final convolution, stem), which run beside the backward chain on the second stream.  Default 70 since round 3:
     // 6.534 -> 6.462 ms/step over three boxes (100: 6.529 / 6.539 / 6.474, 70: 6.440 / 6.484 / 6.415; 60: 6.424, 50: 6.463, 40: 6.527).  Round 2
     // measured the opposite on its per-layer backbone launches (7.67 / 7.73 vs 7.65 ms for 50 / 70): those are grouped now (group_plan).
-    static const int slot_percent = [] { const char* e = getenv("EPI_TN_SLOTS"); const int v = e ? atoi(e) : 70; return v >= 10 && v <= 100 ? v : 70; }();
+    const int slot_percent = 70;
     // Long reductions over large operands (the final layer: 131 072 rows x (1088 + 256) columns; the last deconvolution: 32 768 x (256 + 16 x 256)): the
     // launch is bound by the LDS fill traffic, which the 256 x 256 tile halves (every operand row is staged once per 256 instead of 128 output columns /
     // rows) -- measured alone with HBM-fresh operands (tools/bench_tn_tiles.py): 195 -> 165 us and 138 -> 125 us; shorter reductions lose 25 .. 35 % on
     // that tile (2048 / 8192 rows), and the cost model below, calibrated on those, never picks it.  EPI_TN_BIG_LONG=0: the model alone.
-    static const bool big_long_on = [] { const char* e = getenv("EPI_TN_BIG_LONG"); return !(e && e[0] == '0'); }();
+    const bool big_long_on = true;
     const bool big_long = big_long_on && ov == 0 && R >= 32768 && fills(I) && fills(J) && (long long)I * J >= 256 * 1024;
     TnPlan best = {0, 0, 1, 0};
     double best_t = 1e30;
@@ -2515,11 +2511,11 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
     for (int cls = 0; cls < 2; ++cls) {
         const double t_tile = cls ? 0.7 : 1.0, t_fixed = cls ? 3.0 : 4.0;
         // EPI_TN_GROUP_SLOTS=<percent>: the same knob for the grouped launches (measured: 100 / 70 / 50 / 35 -> 6.440 / 6.441 / 6.466 / 6.509 ms: off)
-        static const int group_percent = [] { const char* e = getenv("EPI_TN_GROUP_SLOTS"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
+        const int group_percent = 100;
         // EPI_TN_GROUP_MODEL=0: the round-3 estimate, total workgroup time / resident workgroups -- blind to the SECOND ROUND a launch of 860
         // workgroups needs on 768 slots (layer 1 of ResNet-50 at batch 32: the launch took 144 us for 302 MB, 2.1 TB/s, alone on the chip).
         // 1 (default, round 4): the makespan of the launch's workgroups on `slots` slots, longest first (the order they are launched in)
-        static const bool lpt_model = [] { const char* e = getenv("EPI_TN_GROUP_MODEL"); return !(e && e[0] == '0'); }();
+        const bool lpt_model = true;
         const long long slots = (cls ? 768 : 512) * group_percent / 100;
         unsigned long long key = 1469598103934665603ULL ^ (unsigned long long)(cls + 2 * group_percent + 1000 * (lpt_model ? 1 : 0));
         int members = 0;

@@ -158,7 +158,7 @@ SideStream g_side;
 // unit); 2 (default) one per ResNet stage -- flushed behind the unit that carries the stage's downsample projection
 int g_group_mode = -1;
 int group_mode() {
-    if (g_group_mode < 0) { const char* e = getenv("EPI_WGRAD_GROUP"); g_group_mode = e ? atoi(e) : 2; }
+    if (g_group_mode < 0) g_group_mode = 2;
     return g_group_mode;
 }
 int wgrad_group_mode(int mode) {               // test / measurement hook: returns the previous setting; a negative mode only queries
@@ -180,7 +180,7 @@ Tensor& side_workspace(size_t bytes, const Tensor& like) {
 }
 
 int side_mode() {
-    if (g_side.mode < 0) { const char* e = getenv("EPI_WGRAD_STREAM"); g_side.mode = e ? atoi(e) : 1; }
+    if (g_side.mode < 0) g_side.mode = 1;
     return g_side.mode;
 }
 int wgrad_stream_mode(int mode) {             // test / measurement hook: returns the previous setting; a negative mode only queries
@@ -222,7 +222,7 @@ hipStream_t side_fork(int dev, hipStream_t main_stream) {
             // the fence an event adds by default.  EPI_EVENT_FENCE=0 drops it (hipEventDisableSystemFence: both streams are on one device
             // and every kernel ends / starts with its own agent-scope release / acquire; measured 7.26 -> 7.13 ms/step with 20 fork events
             // per step in round 2 -- with one fork per ResNet stage the difference is gone, and HIP documents the flag for timing-only events)
-            static const bool fence = [] { const char* e = getenv("EPI_EVENT_FENCE"); return !(e && e[0] == '0'); }();
+            const bool fence = true;
             const unsigned flags = hipEventDisableTiming | (fence ? 0u : (unsigned)hipEventDisableSystemFence);
             S.fork.resize(256);
             for (auto& e : S.fork) TORCH_CHECK(hipEventCreateWithFlags(&e, flags) == hipSuccess, "weight-gradient stream: event");
@@ -259,7 +259,7 @@ struct PendingReduces {
 PendingReduces g_pend;
 int g_defer = -1;
 bool defer_enabled() {
-    if (g_defer < 0) { const char* e = getenv("EPI_DEFER_WGRAD_REDUCE"); g_defer = (e && e[0] == '0') ? 0 : 1; }
+    if (g_defer < 0) g_defer = 1;
     return g_defer != 0;
 }
 // test / measurement hook: returns the previous setting
@@ -338,7 +338,7 @@ void flush_pending_reduces() {
         hipStream_t stream = c10::hip::getCurrentHIPStream(P.dev.index()).stream();
         // (EPI_REDUCE_STREAM=1; measured on MI355X: 7.48 vs 7.46 ms/step on the main stream -- the sum then competes with the stem's
         // backward instead of following it -- so it stays on the main stream by default)
-        static const bool reduce_on_side = [] { const char* e = getenv("EPI_REDUCE_STREAM"); return e && e[0] == '1'; }();
+        const bool reduce_on_side = false;
         if (reduce_on_side && g_side.dirty && g_side.device == P.dev.index()) stream = side_fork(P.dev.index(), stream);
         else side_join();            // the slabs may still be in flight on the weight-gradient stream
         launch_pending_rows(stream, 1);
@@ -469,7 +469,7 @@ ColumnSumsOffer g_colsum_offer;
 long long g_bias_sums_taken = 0;         // test hook: how many bias gradients came from an offer
 int g_colsum_mode = -1;
 bool column_sums_wanted() {
-    if (g_colsum_mode < 0) { const char* e = getenv("EPI_BIAS_GRAD_FUSE"); g_colsum_mode = (e && e[0] == '1') ? 1 : 0; }
+    if (g_colsum_mode < 0) g_colsum_mode = 0;
     return g_colsum_mode != 0 && epi_set_deterministic(-1) == 0;
 }
 int bias_grad_fuse_mode(int mode) {              // test / measurement hook: returns the previous setting; a negative mode only queries
@@ -701,7 +701,7 @@ struct BnLink : torch::CustomClassHolder {
 std::unordered_map<void*, c10::weak_intrusive_ptr<BnLink>> g_links;
 int g_bn_fuse = -1;
 bool bn_fuse_enabled() {
-    if (g_bn_fuse < 0) { const char* e = getenv("EPI_BN_BWD_FUSE"); g_bn_fuse = (e && e[0] == '0') ? 0 : 1; }
+    if (g_bn_fuse < 0) g_bn_fuse = 1;
     return g_bn_fuse != 0;
 }
 int64_t g_bn_fused = 0, g_bn_refused = 0;         // BatchNorm backward passes that found their reduction done / done but unusable
@@ -896,7 +896,7 @@ struct BnInput {
 };
 int g_bn_in_fuse = -1;
 bool bn_in_fuse_enabled() {
-    if (g_bn_in_fuse < 0) { const char* e = getenv("EPI_BN_IN_FUSE"); g_bn_in_fuse = (e && e[0] == '1') ? 1 : 0; }
+    if (g_bn_in_fuse < 0) g_bn_in_fuse = 0;
     return g_bn_in_fuse != 0;
 }
 int bn_in_fuse_mode(int mode) {                 // test / measurement hook: returns the previous setting; a negative mode only queries
@@ -1020,7 +1020,7 @@ Tensor finish_deferred_stage(const Tensor& raw, const StageParams& p, const Tens
 // Both stages ran with defer_bn; their saved state gets the statistics (and the main stage the mask source) here.
 int g_bn_dual = -1;
 bool bn_dual_enabled() {
-    if (g_bn_dual < 0) { const char* e = getenv("EPI_BN_DUAL"); g_bn_dual = (e && e[0] == '0') ? 0 : 1; }
+    if (g_bn_dual < 0) g_bn_dual = 1;
     return g_bn_dual != 0;
 }
 int bn_dual_mode(int mode) {                    // test / measurement hook: returns the previous setting; a negative mode only queries
@@ -1369,7 +1369,7 @@ struct StemConvBnAct : public torch::autograd::Function<StemConvBnAct> {
             // The stem is the LAST node of the backward chain: on the second stream its weight gradient queues behind layer 1's grouped launches, which
             // are still running when the chain ends, and the step's tail waits for both one after the other.  On the main stream it runs BESIDE them.
             // EPI_STEM_WGRAD_SIDE=1: the second stream as before (A/B)
-            static const bool stem_side = [] { const char* e = getenv("EPI_STEM_WGRAD_SIDE"); return e && e[0] == '1'; }();
+            const bool stem_side = false;
             if (stem_side && side_mode() != 0 && first_use && gradient_consumed_after_backward(sv.w)) {
                 g_side.jobs.push_back(SideStream::Job{sv.x, g.dx, dw, [=](epi_stream_t st) {
                     launch(st, side_workspace(ws_bytes, s2d));
@@ -1503,7 +1503,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
             // a 1x1 stride-2 projection in front of a 1x1 stride-1 first stage (every stride-2 Bottleneck): the projection's input gradient is zero at
             // three pixels of four -- it stays at half resolution and the first stage's backward-data epilogue adds it at the even pixels
             // (EPI_HALF_SHORTCUT=0: expanded with zeros by the four-phase launch, as in round 2)
-            static const bool half_ok = [] { const char* e = getenv("EPI_HALF_SHORTCUT"); return !(e && e[0] == '0'); }();
+            const bool half_ok = true;
             const StageSaved& ds = holder->stages[n_total - 1];
             const StageSaved& s0 = holder->stages[0];
             const bool half = half_ok && need_x && ds.K == 1 && ds.S == 2 && ds.P == 0 && s0.K == 1 && s0.S == 1 && s0.P == 0 && ds.x.defined() &&
@@ -1530,7 +1530,7 @@ struct ResidualUnitFn : public torch::autograd::Function<ResidualUnitFn> {
         // (EPI_WGRAD_GROUP_ROWS = N: also flush a unit by itself when it reduces over >= N rows.  Measured with N = 65 536 -- layer 1 at the bench
         //  shape, whose stage group otherwise leaves at the very end of the backward chain: 6.606 vs 6.600 ms/step, 7 launches instead of 5; the
         //  earlier launches take from the main stream what the shorter tail gives back.  Off.)
-        static const long long unit_rows = [] { const char* e = getenv("EPI_WGRAD_GROUP_ROWS"); return e ? atoll(e) : 0LL; }();
+        const long long unit_rows = 0;
         const StageSaved& s0 = holder->stages.empty() ? StageSaved() : holder->stages[0];
         const long long rows = s0.x.defined() ? (long long)s0.x.size(0) * s0.x.size(2) * s0.x.size(3) : 0;
         if (group_mode() == 1 || holder->has_downsample || g_side.group.size() + 4 > (size_t)epi_wgrad_group_max() ||

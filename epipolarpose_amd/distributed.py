@@ -12,11 +12,10 @@ import os
 import torch
 import torch.distributed as dist
 
-# How a completed bucket's gradients are packed into its flat buffer: "foreach" (default: torch._foreach_copy_ into the
-# parameter-strided views) or "cat" (torch.cat of memory-order flat aliases, written straight into the flat buffer: one
-# batched-copy kernel per <=128 tensors).  Same bytes either way (tests/test_distributed_cpu.py); the choice is a speed
-# experiment for the N>1 path.
-BUCKET_PACK = os.environ.get("EPI_BUCKET_PACK", "foreach")
+# How a completed bucket's gradients are packed into its flat buffer: "foreach" (torch._foreach_copy_ into the parameter-strided views; on the
+# GPU the same loop in C++, csrc/torch_glue.cpp pack_bucket) or "cat" (torch.cat of memory-order flat aliases, written straight into the flat
+# buffer).  Same bytes either way (tests/test_host_logic.py sets this attribute to compare them); "foreach" is the training path.
+BUCKET_PACK = "foreach"
 
 
 def _memory_order_flat(t):
@@ -154,7 +153,7 @@ class BucketedGradSync:
         self._hooks = []
         self._launched = set()
         self._deferred = []        # complete buckets whose launch waits for the next hook (GPU: see _launch_from_hook)
-        self._pipeline = os.environ.get("EPI_BUCKET_PIPELINE", "1") != "0"
+        self._pipeline = True      # GPU: a complete bucket is launched one hook later, behind an event (see _launch_from_hook)
         self._last = {}
         self._learning = True
         self._declare_hook_free([])

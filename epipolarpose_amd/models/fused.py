@@ -6,17 +6,11 @@
 * ``Conv1x1``            -- the final 1x1 convolution as an MFMA GEMM (``epi_gemm_bf16``).
 All activations are NHWC (``channels_last``) bf16; parameters stay fp32 (master weights).  No CPU path.
 """
-import os
-
 import torch
 import torch.nn as nn
 
 from .. import hip
 from ..optim import sync_training_copy
-
-
-# EPI_HEAD=python: deconvolution head and final convolution through the Python autograd.Functions of round 1 instead of the C++ nodes
-HEAD_BACKEND = os.environ.get("EPI_HEAD", "glue")
 
 
 def _nhwc_bf16(x):
@@ -144,31 +138,6 @@ class FusedResidualUnit:
         return hip.glue().residual_unit(x, tensors, self.geometry, self.has_downsample, bn0.training, bn0.momentum, bn0.eps)
 
 
-class PointwiseConv(nn.Module):
-    """Bias-free 1x1 stride-1 convolution of an NHWC tensor as a plain library GEMM (hipBLASLt through ``F.linear`` on the
-    zero-copy [B*H*W, Cin] view); weight [Cout, Cin, 1, 1] keeps the ``nn.Conv2d`` name and shape (bottleneck conv1 / conv3,
-    pose3d_resnet.py:56,61).  At batch 32 hipBLASLt runs these shapes at 0.7-1.0 PFLOP/s where MIOpen's implicit-GEMM
-    convolution kernels reach ~0.3; forward and both backward GEMMs are stock autograd (no custom Function, no host cost)."""
-
-    supports_training_copy = True
-
-    def __init__(self, in_channels, out_channels):
-        super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 1, 1))
-        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)          # nn.Conv2d default initialisation
-        self.register_parameter("bias", None)
-
-    def forward(self, x):
-        w = self.weight if getattr(self, "weight_lp", None) is None else sync_training_copy(self)
-        if x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
-            x = _nhwc_bf16(x)
-        if w.dtype != torch.bfloat16:
-            w = w.to(torch.bfloat16)
-        y = torch.nn.functional.linear(x.permute(0, 2, 3, 1), w.reshape(self.out_channels, self.in_channels))
-        return y.permute(0, 3, 1, 2)                                # logical NCHW, NHWC memory
-
-
 class _DeconvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, w_phase):
@@ -224,40 +193,6 @@ def deconv_bn_act(deconv, bn, x):
     return hip.glue().deconv_bn_act(x, w, wp, g, b, rm, rv, nbt, sums_ws, bwd_sums, bn._flags, bn.training, bn.momentum, bn.eps, bn.relu)
 
 
-class _Conv1x1Function(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        b, cin, h, w = x.shape
-        cout = weight.shape[0]
-        w2 = weight.detach().reshape(cout, cin)
-        if w2.dtype != torch.bfloat16:
-            w2 = w2.to(torch.bfloat16)
-        x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, cin)          # NHWC view, no copy
-        out = hip.gemm_bf16(x2, w2, bias=None if bias is None else bias.detach().float())
-        ctx.save_for_backward(x, w2)
-        ctx.has_bias = bias is not None
-        ctx.lp = weight.dtype == torch.bfloat16
-        return out.reshape(b, h, w, cout).permute(0, 3, 1, 2)       # logical NCHW, NHWC memory
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w2 = ctx.saved_tensors
-        b, cin, h, w = x.shape
-        cout = w2.shape[0]
-        dy2 = _nhwc_bf16(dy).permute(0, 2, 3, 1).reshape(b * h * w, cout)
-        x2 = x.permute(0, 2, 3, 1).reshape(b * h * w, cin)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = hip.gemm_bf16(dy2, w2.t().contiguous()).reshape(b, h, w, cin).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            dw = hip.gemm_tn_bf16(dy2, x2).reshape(cout, cin, 1, 1)
-            if ctx.lp:
-                dw = dw.to(torch.bfloat16)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = hip.column_sum_bf16(dy2)
-        return dx, dw, db
-
-
 class Conv1x1(nn.Module):
     """1x1 stride-1 convolution as an MFMA GEMM; weight [Cout, Cin, 1, 1] (+ bias [Cout]) named as in ``nn.Conv2d``
     (final layer: pose3d_resnet.py:116-122; bottleneck conv1/conv3: :56,61).  When an optimizer installs a bf16 training
@@ -279,6 +214,4 @@ class Conv1x1(nn.Module):
 
     def forward(self, x):
         w = self.weight if getattr(self, "weight_lp", None) is None else sync_training_copy(self)
-        if HEAD_BACKEND == "python":                                  # round-1 path: Python autograd.Function over ctypes (A/B switch)
-            return _Conv1x1Function.apply(_nhwc_bf16(x), w, self.bias)
         return hip.glue().conv1x1_bias(x, w, self.bias)

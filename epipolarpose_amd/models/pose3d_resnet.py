@@ -5,11 +5,15 @@ API surface kept: ``get_pose_net(cfg, is_train)``, ``PoseResNet.forw
 compatibility surface proper -- the ``state_dict()`` key names and shapes of the reference (pose3d_resnet.py:93-126):
 ``conv1 bn1 layer{1..4}.{i}.{conv,bn}{1..3} layer*.0.downsample.{0,1} deconv_layers.{0,1,3,4,6,7} final_layer``.
 
-MI355X-first choices: the network is built channels-last (NHWC) bf16 end to end; backbone convolutions go to
-MIOpen/hipBLASLt under bf16 autocast; EVERY BatchNorm (+ReLU, + residual add) is one fused HIP apply pass
-(``FusedBatchNormAct``) because at batch 32 those HBM-bound passes dominate the step; the deconvolution head and the
-final 1x1 convolution are hand-written MFMA implicit GEMMs (``Deconv4x4s2``, ``Conv1x1``); residual units are
-generated from a per-depth plan table instead of two hand-written block classes.  GPU only (no CPU path).
+MI355X-first choices: the network is built channels-last (NHWC) bf16 end to end and runs on hand-written HIP kernels only
+(csrc/): every convolution -- the 7x7 stem through its space-to-depth form, the residual units' 1x1 / 3x3, the deconvolution head,
+the final 1x1 -- is an MFMA implicit GEMM (``epi_conv2d_*``, ``epi_stem7x7s2_*``, ``epi_deconv4x4s2_*``, ``epi_gemm_bf16``); EVERY
+BatchNorm (+ReLU, + residual add) is one fused apply pass; a whole residual unit, a deconvolution stage, the stem (+ its max-pool) and
+the final layer are ONE C++ autograd node each (csrc/torch_glue.cpp); residual units are generated from a per-depth plan table instead
+of two hand-written block classes.  The ``nn.Conv2d`` / ``FusedBatchNormAct`` modules only hold the parameters under the reference's
+``state_dict`` names.  GPU only: there is no CPU path and no library (MIOpen / hipBLASLt) back-end; layer shapes the kernels do not
+tile (channel counts that are not multiples of 64, deconvolution kernels other than 4, a final 3x3) fall to the stock ``nn`` modules,
+which no shipped experiment uses.
 """
 import logging
 import os
@@ -20,23 +24,9 @@ import torch.nn as nn
 
 from .. import hip
 from ..optim import sync_training_copy
-from .fused import HEAD_BACKEND, Conv1x1, Deconv4x4s2, deconv_bn_act, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, PointwiseConv, conv_is_fusable
+from .fused import Conv1x1, Deconv4x4s2, deconv_bn_act, FusedBatchNormAct, FusedConvBn, FusedResidualUnit, conv_is_fusable
 
 BN_MOMENTUM = 0.1
-# Backend of the bottleneck 1x1 stride-1 convolutions (EPI_1X1).  Measured round 1 at B=32 (ms/step, whole training step):
-#   "miopen" (default, nn.Conv2d)                                  9.8
-#   "blaslt" (plain hipBLASLt GEMM on the NHWC view, F.linear)    13.4
-#   "mfma"   (the hand-written head GEMM + TN weight gradient)    14.4   (per-call host cost + weight transposes)
-POINTWISE_BACKEND = os.environ.get("EPI_1X1", "miopen")
-# Backend of the residual units' convolutions (EPI_CONV): "hip" (default) = the hand-written implicit-GEMM kernels, every
-# conv -> BatchNorm (+ residual) (+ ReLU) stage one C++ autograd node (models/fused.py:FusedConvBn); "miopen" = nn.Conv2d through
-# MIOpen followed by the fused BatchNorm module (the round-1 path, kept for A/B measurements).
-CONV_BACKEND = os.environ.get("EPI_CONV", "hip")
-MAXPOOL_BACKEND = os.environ.get("EPI_MAXPOOL", "hip")       # "torch": the library max-pool (A/B switch)
-# Backend of the 7x7 stem convolution (EPI_STEM): "hip" (default, round 3) = the implicit-GEMM kernels on the space-to-depth image,
-# conv -> BatchNorm -> ReLU one C++ autograd node; "miopen" = nn.Conv2d through MIOpen + the fused BatchNorm module (rounds 1-2)
-STEM_BACKEND = os.environ.get("EPI_STEM", "hip")
-STEM_POOL = os.environ.get("EPI_STEM_POOL", "1") != "0"      # the stem's max-pool inside the stem node (BatchNorm + ReLU applied on the way in)
 logger = logging.getLogger(__name__)
 
 # depth -> (unit plan, units per stage).  A plan lists (kernel, width multiplier, carries the stride) per conv.
@@ -52,19 +42,17 @@ resnet_spec = {18: (_BASIC, [2, 2, 2, 2]),
 class ResidualUnit(nn.Module):
     """conv-bn(-relu) chain + identity/projection shortcut; parameters are named conv{i}/bn{i}/downsample.{0,1}."""
 
-    def __init__(self, inplanes, planes, plan, stride=1):
+    def __init__(self, inplanes, planes, plan, stride=1, unit_node=True):
+        """unit_node: the whole unit as ONE autograd node (the training path); False = one node per conv/bn stage with autograd's own accumulation at
+        the junction -- the same kernels, kept as the cross-check of tests/test_hip_conv.py."""
         super().__init__()
         self.n_conv = len(plan)
+        self._unit_node = unit_node
         cin = inplanes
         for i, (k, mult, strided) in enumerate(plan, start=1):
             cout = planes * mult
             s_i = stride if strided else 1
-            if k == 1 and s_i == 1 and POINTWISE_BACKEND == "blaslt":
-                conv = PointwiseConv(cin, cout)                  # plain GEMM [B*H*W, Cin] x [Cin, Cout] (hipBLASLt)
-            elif k == 1 and s_i == 1 and cin % 8 == 0 and cout % 8 == 0 and POINTWISE_BACKEND == "mfma":
-                conv = Conv1x1(cin, cout, bias=False)            # the same GEMM on the hand-written MFMA kernel
-            else:
-                conv = nn.Conv2d(cin, cout, kernel_size=k, stride=s_i, padding=k // 2, bias=False)
+            conv = nn.Conv2d(cin, cout, kernel_size=k, stride=s_i, padding=k // 2, bias=False)       # (parameter holder: FusedConvBn runs it)
             setattr(self, "conv%d" % i, conv)
             setattr(self, "bn%d" % i, FusedBatchNormAct(cout, momentum=BN_MOMENTUM, relu=True))
             cin = cout
@@ -82,11 +70,10 @@ class ResidualUnit(nn.Module):
         pairs = [(getattr(self, "conv%d" % i), getattr(self, "bn%d" % i)) for i in range(1, self.n_conv + 1)]
         if self.downsample is not None:
             pairs.append((self.downsample[0], self.downsample[1]))
-        if CONV_BACKEND != "hip" or not all(conv_is_fusable(c) for c, _ in pairs):
+        if not all(conv_is_fusable(c) for c, _ in pairs):
             return ()
         fused = tuple(FusedConvBn(c, b) for c, b in pairs)
-        # EPI_UNIT_NODE=0: one autograd node per conv/bn stage (A/B switch); default: one node per residual unit
-        self._unit = FusedResidualUnit(fused, self.downsample is not None) if os.environ.get("EPI_UNIT_NODE", "1") != "0" else None
+        self._unit = FusedResidualUnit(fused, self.downsample is not None) if self._unit_node else None
         return fused
 
     def forward(self, x):
@@ -156,7 +143,7 @@ class PoseResNet(nn.Module):
         self.deconv_layers = nn.Sequential(*head)
         # (deconvolution, BatchNorm) pairs that run as one C++ autograd node each; empty: module by module
         pairs = [(head[i], head[i + 1]) for i in range(0, len(head), 3)]
-        self._head_pairs = tuple(pairs) if HEAD_BACKEND != "python" and all(isinstance(d, Deconv4x4s2) for d, _ in pairs) else ()
+        self._head_pairs = tuple(pairs) if all(isinstance(d, Deconv4x4s2) for d, _ in pairs) else ()
 
         fk = extra.FINAL_CONV_KERNEL
         out_ch = self.num_joints * self.depth_res if self.volume else self.num_joints
@@ -173,15 +160,13 @@ class PoseResNet(nn.Module):
     def step_in_backward_split(self):
         """(boundary, late modules) for ``optim.FusedAdam.enable_step_in_backward``: when the backward pass crosses the output of
         ``layer1`` every gradient behind it (layers 2-4, the head: 99 % of the parameters) is final."""
-        n = int(os.environ.get("EPI_EARLY_BOUNDARY", "1"))          # measurement switch: the boundary after layer n
-        layers = [self.layer1, self.layer2, self.layer3, self.layer4]
-        return layers[n - 1], [self.conv1, self.bn1] + layers[:n]
+        return self.layer1, [self.conv1, self.bn1, self.layer1]
 
     def stem(self, x, pool=False):
         """conv1 -> bn1 -> relu (pose3d_resnet.py:186-188); ``pool``: also the max-pool, inside the same node (the normalised tensor is then never
         written: csrc/torch_glue.cpp StemConvBnAct).  Returns (tensor, pooled)."""
         conv, bn = self.conv1, self.bn1
-        if (STEM_BACKEND == "hip" and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+        if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
                 and conv.out_channels % 8 == 0):
             w = sync_training_copy(conv) if getattr(conv, "weight_lp", None) is not None else conv.weight
             g, b, rm, rv, nbt, sums_ws, bwd_sums = bn._tensors()
@@ -190,8 +175,8 @@ class PoseResNet(nn.Module):
         return bn(conv(x)), False
 
     def features(self, x):
-        own_pool = x.is_cuda and self.conv1.out_channels % 8 == 0 and MAXPOOL_BACKEND == "hip"      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
-        x, pooled = self.stem(x, pool=own_pool and STEM_POOL)
+        own_pool = x.is_cuda and self.conv1.out_channels % 8 == 0      # MaxPool2d(3, 2, 1) on epi_maxpool3x3s2_* (csrc/pool.hip)
+        x, pooled = self.stem(x, pool=own_pool)
         if not pooled:
             x = hip.glue().maxpool3x3s2(x) if own_pool else self.maxpool(x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))

@@ -316,11 +316,9 @@ def test_residual_unit_node_matches_per_stage_nodes(kind, monkeypatch, request):
     #  BatchNorms does not: "same roundings" holds for the two-pass form, the one-pass form has its own test below)
     prev_dual = hip.glue().bn_dual_mode(0)
     request.addfinalizer(lambda: hip.glue().bn_dual_mode(prev_dual))
-    monkeypatch.setenv("EPI_UNIT_NODE", "1")
     unit = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
     assert unit._unit is not None
-    monkeypatch.setenv("EPI_UNIT_NODE", "0")
-    staged = P.ResidualUnit(inpl, planes, plan, stride).to(dev).to(memory_format=torch.channels_last)
+    staged = P.ResidualUnit(inpl, planes, plan, stride, unit_node=False).to(dev).to(memory_format=torch.channels_last)
     assert staged._unit is None and staged._fused
     staged.load_state_dict(copy.deepcopy(unit.state_dict()))
     gen = torch.Generator().manual_seed(4)
