@@ -321,8 +321,15 @@ def build_roofline(args, ksum, glue_times, model, images):
     if pmc and "traffic" in out and out.get("launches_per_step"):
         g = pmc["families"].get("implicit_gemm")
         if g:
-            out["traffic"] = round(g["hbm_bytes_per_step"] / out["launches_per_step"])
+            # per launch of the family as the PMC passes counted them (their launch set includes the split finishes and slab sums: 141.6 per step;
+            # the timed `launches_per_step` counts entry-point calls) -- both figures of the quotient from ONE source
+            out["traffic"] = round(g.get("hbm_bytes_per_launch", g["hbm_bytes_per_step"] / out["launches_per_step"]))
             out["traffic_per_step"] = round(g["hbm_bytes_per_step"])
+            out["traffic_launches_per_step"] = g.get("launches_per_step")
+            if g.get("mfma_busy") is not None:
+                # share of the family's own kernel cycles a SIMD's matrix pipe was busy: (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs),
+                # summed over the family's launches of the profiled steps (profiles/r05_pmc_sq_step.csv holds it per kernel class)
+                out["mfma_busy"] = g["mfma_busy"]
         bnp = pmc["families"].get("batchnorm")
         if bnp and "batchnorm" in out:
             out["batchnorm"]["traffic_per_step"] = round(bnp["hbm_bytes_per_step"])
@@ -374,12 +381,12 @@ def refiner_leg(args, device):
             "train_ms_per_step": round(train_ms, 4), "train_samples_per_s": round(64 / (train_ms * 1e-3), 1), "final_loss": round(float(loss.item()), 6)}
 
 
-PMC_FILE = "profiles/r04_pmc_step_families.json"
+PMC_FILE = "profiles/r05_pmc_step_families.json"
 
 
 def pmc_traffic(default_workload):
-    """The committed summary of the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py at the default workload
-    (tools/gpu_pmc_step.sh): counters cannot be read from inside the process, so `roofline.traffic` quotes that file -- and only for the
+    """The committed summary of the three rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ + GRBM) over bench.py at the default workload
+    (tools/gpu_pmc_step_r05.sh): counters cannot be read from inside the process, so `roofline.traffic` quotes that file -- and only for the
     workload it was taken on."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
     if not default_workload or not os.path.isfile(path):

@@ -1,8 +1,13 @@
-"""Dataset of the refinement MLP -- the reference's ``refiner/data.py`` reads pickled (noisy 3-D pose, ground truth) pairs of
-Human3.6M; no such data exists on the build / GPU boxes, so ``SyntheticLift`` supplies seeded pairs with the same item contract
-(``(inp f32 [45], out f32 [45])``, hip joint removed, inputs always and training targets standardised, data.py:40-70) and the same
-``evaluate`` protocol (MPJPE and Procrustes-aligned MPJPE over the 15 joints, data.py:78-158).  The reference's pickle-reading ``Human36M`` class is
-data plumbing outside the hot-path scope and is not mirrored."""
+"""Dataset of the refinement MLP (reference ``refiner/data.py``).
+
+* ``Human36M(is_train)`` -- the class the reference's ``refiner/main.py:13`` imports: reads the reference's pickles ``refiner/data/{train,valid}.pkl``
+  (``{'inp': ..., 'out': ...}`` pose pairs, hip joint removed, inputs always and training targets standardised, ``norm.pkl`` written by the training split:
+  data.py:40-70) where they exist, and falls back to seeded synthetic pairs with the same item contract where they do not (no such data on the build /
+  GPU boxes).  ``evaluate`` = MPJPE and Procrustes-aligned MPJPE over the 15 joints (data.py:78-158).
+* ``SyntheticLift`` -- the seeded stand-in itself."""
+import os
+import pickle
+
 import numpy as np
 from torch.utils.data import Dataset
 
@@ -40,3 +45,36 @@ class SyntheticLift(Dataset):
             dist.append(np.linalg.norm(g - p, axis=1).mean())
             dist_align.append(np.linalg.norm(g - (b * p.dot(t) + c), axis=1).mean())
         return float(np.mean(dist)), float(np.mean(dist_align))
+
+
+class Human36M(SyntheticLift):
+    """refiner/data.py:31-76 (see the module docstring).  ``root``: where ``refiner/data/*.pkl`` live (the reference uses the working directory)."""
+
+    def __init__(self, is_train, root="."):
+        fname = os.path.join(root, "refiner", "data", "train.pkl" if is_train else "valid.pkl")
+        if not os.path.isfile(fname):
+            super().__init__(is_train)
+            return
+        self.is_train = is_train
+        with open(fname, "rb") as f:
+            anno = pickle.load(f)
+        data = np.asarray(anno["inp"], dtype=np.float32).reshape(len(anno["inp"]), -1)
+        labels = np.asarray(anno["out"], dtype=np.float32).reshape(len(anno["out"]), -1)
+        data, labels = np.delete(data, np.s_[18:21], axis=1), np.delete(labels, np.s_[18:21], axis=1)          # remove the hip joint (:50-52)
+        norm_file = os.path.join(root, "refiner", "data", "norm.pkl")
+        if os.path.exists(norm_file):
+            with open(norm_file, "rb") as f:
+                norm = pickle.load(f)
+        elif is_train:
+            norm = (data.mean(axis=0), data.std(axis=0), labels.mean(axis=0), labels.std(axis=0))
+            with open(norm_file, "wb") as f:
+                pickle.dump(norm, f)
+        else:
+            raise IOError("refiner/data/norm.pkl is missing: construct the training split first (refiner/data.py:54-62)")
+        self.data_mean, self.data_std, self.labels_mean, self.labels_std = norm
+        data = (data - self.data_mean) / self.data_std
+        if is_train:
+            labels = (labels - self.labels_mean) / self.labels_std
+            rnd = np.random.permutation(labels.shape[0])                                                     # :69-71
+            data, labels = data[rnd], labels[rnd]
+        self.data, self.labels = data, labels
