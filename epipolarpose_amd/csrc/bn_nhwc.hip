@@ -270,6 +270,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply2d_kernel(const T* __restr
     __shared__ float ss[2 * SLAB];                // scale | shift of this slab
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
     const bool lead = blockIdx.y == 0;
+    // (round 5) the first four rows of every lane are REQUESTED before the per-channel prologue: the prologue is a dependent chain of its own (batch sums
+    // from L2 -> a few float64 operations -> LDS -> barrier, ~1 us) and the ~110 small BatchNorm launches of a step are latency, not bandwidth
+    const int ch0 = slab * SLAB + g * V;
+    const bool act = ch0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    long long r = r0 + rl;
+    const bool pre = act && r + 3LL * BN_RLANES < r1;
+    float pv[4][V], pq[4][V];
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Elem<T>::load(x + (r + (long long)u * BN_RLANES) * C + ch0, pv[u]);
+            if (RES) Elem<T>::load(res + (r + (long long)u * BN_RLANES) * C + ch0, pq[u]);
+        }
+    }
     if (threadIdx.x < SLAB) {
         const int c = slab * SLAB + threadIdx.x;
         float sc = 0.f, sh = 0.f;
@@ -305,13 +321,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply2d_kernel(const T* __restr
     }
     if (lead && slab == 0 && threadIdx.x == 0 && a.num_batches && a.sums) a.num_batches[0] += 1;
     __syncthreads();
-    const int ch0 = slab * SLAB + g * V;
-    if (ch0 >= C) return;
+    if (!act) return;
     float sc[V], sh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { sc[k] = ss[g * V + k]; sh[k] = ss[SLAB + g * V + k]; }
-    const long long r0 = (long long)blockIdx.y * rows_per_wg;
-    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     auto one = [&](float (&v)[V], const float (&r)[V]) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -320,7 +333,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply2d_kernel(const T* __restr
             v[k] = RELU ? fmaxf(t, 0.f) : t;
         }
     };
-    long long r = r0 + rl;
+    if (pre) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            one(pv[u], pq[u]);
+            Elem<T>::store(y + (r + (long long)u * BN_RLANES) * C + ch0, pv[u]);
+        }
+        r += 4LL * BN_RLANES;
+    }
     for (; r + 3LL * BN_RLANES < r1; r += 4LL * BN_RLANES) {             // four rows (4 .. 8 independent 16-byte loads) in flight per lane
         float v[4][V], q[4][V];
 #pragma unroll
@@ -353,6 +373,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2d_kernel(const T* __r
     constexpr int V = Elem<T>::VEC, SLAB = 8 * V;
     __shared__ float cs[5 * SLAB];                // P | Q | S | scale | shift of this slab:  dx = P dz + Q x + S
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
+    // (round 5) the first two rows of every lane are requested before the per-channel prologue (see bn_apply2d_kernel)
+    const int ch0 = slab * SLAB + g * V;
+    const bool act = ch0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    long long r = r0 + rl;
+    const bool pre = act && r + BN_RLANES < r1;
+    float pxa[V], pga[V], pya[V], pxb[V], pgb[V], pyb[V];
+    if (pre) {
+        Elem<T>::load(x + r * C + ch0, pxa);
+        Elem<T>::load(dy + r * C + ch0, pga);
+        Elem<T>::load(x + (r + BN_RLANES) * C + ch0, pxb);
+        Elem<T>::load(dy + (r + BN_RLANES) * C + ch0, pgb);
+        if (MASK == BN_MASK_FROM_Y) {
+            Elem<T>::load(y + r * C + ch0, pya);
+            Elem<T>::load(y + (r + BN_RLANES) * C + ch0, pyb);
+        }
+    }
     if (threadIdx.x < SLAB) {
         const int c = slab * SLAB + threadIdx.x;
         float P = 0.f, Q = 0.f, S = 0.f, sc = 0.f, sh = 0.f;
@@ -375,8 +413,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2d_kernel(const T* __r
             for (int c = threadIdx.x; c < 2 * C; c += BN_THREADS) param_grads[c] = sums[c];
     }
     __syncthreads();
-    const int ch0 = slab * SLAB + g * V;
-    if (ch0 >= C) return;
+    if (!act) return;
     float P[V], Q[V], S[V], sc[V], sh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -384,8 +421,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2d_kernel(const T* __r
         sc[k] = MASK == BN_MASK_FROM_X ? cs[3 * SLAB + g * V + k] : 0.f;
         sh[k] = MASK == BN_MASK_FROM_X ? cs[4 * SLAB + g * V + k] : 0.f;
     }
-    const long long r0 = (long long)blockIdx.y * rows_per_wg;
-    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
     // in place: xv becomes dx, gv becomes dz
     auto one = [&](float (&xv)[V], float (&gv)[V], const float (&yv)[V]) {
 #pragma unroll
@@ -398,7 +433,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2d_kernel(const T* __r
             gv[k] = dz;
         }
     };
-    long long r = r0 + rl;
+    if (pre) {
+        one(pxa, pga, pya);
+        one(pxb, pgb, pyb);
+        Elem<T>::store(dx + r * C + ch0, pxa);
+        Elem<T>::store(dx + (r + BN_RLANES) * C + ch0, pxb);
+        if (DRES) {
+            Elem<T>::store(dres + r * C + ch0, pga);
+            Elem<T>::store(dres + (r + BN_RLANES) * C + ch0, pgb);
+        }
+        r += 2LL * BN_RLANES;
+    }
     for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {                   // two rows (4 .. 6 independent 16-byte loads) in flight per lane
         float xa[V], ga[V], ya[V], xb[V], gb[V], yb[V];
         Elem<T>::load(x + r * C + ch0, xa);
@@ -509,6 +554,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_dual_kernel(const T* __re
     __shared__ float ss[3 * SLAB];                // scale | scale of the projection | both shifts added
     const int g = threadIdx.x & 7, rl = threadIdx.x >> 3, slab = blockIdx.x;
     const bool lead = blockIdx.y == 0;
+    // (round 5) the first two rows of every lane are requested before the per-channel prologue (see bn_apply2d_kernel)
+    const int ch0 = slab * SLAB + g * V;
+    const bool act = ch0 < C;
+    const long long r0 = (long long)blockIdx.y * rows_per_wg;
+    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
+    long long r = r0 + rl;
+    const bool pre = act && r + BN_RLANES < r1;
+    float pva[V], pda[V], pvb[V], pdb[V];
+    if (pre) {
+        Elem<T>::load(x + r * C + ch0, pva);
+        Elem<T>::load(xd + r * C + ch0, pda);
+        Elem<T>::load(x + (r + BN_RLANES) * C + ch0, pvb);
+        Elem<T>::load(xd + (r + BN_RLANES) * C + ch0, pdb);
+    }
     if (threadIdx.x < SLAB) {
         const int c = slab * SLAB + threadIdx.x;
         float sc = 0.f, sh = 0.f, scd = 0.f, shd = 0.f;
@@ -525,14 +584,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_dual_kernel(const T* __re
         if (d.num_batches && d.sums) d.num_batches[0] += 1;
     }
     __syncthreads();
-    const int ch0 = slab * SLAB + g * V;
-    if (ch0 >= C) return;
+    if (!act) return;
     float sc[V], scd[V], sh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { sc[k] = ss[g * V + k]; scd[k] = ss[SLAB + g * V + k]; sh[k] = ss[2 * SLAB + g * V + k]; }
-    const long long r0 = (long long)blockIdx.y * rows_per_wg;
-    const long long r1 = (r0 + rows_per_wg < R) ? r0 + rows_per_wg : R;
-    long long r = r0 + rl;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            pva[k] = fmaxf(pva[k] * sc[k] + pda[k] * scd[k] + sh[k], 0.f);
+            pvb[k] = fmaxf(pvb[k] * sc[k] + pdb[k] * scd[k] + sh[k], 0.f);
+        }
+        Elem<T>::store(y + r * C + ch0, pva);
+        Elem<T>::store(y + (r + BN_RLANES) * C + ch0, pvb);
+        r += 2LL * BN_RLANES;
+    }
     for (; r + BN_RLANES < r1; r += 2LL * BN_RLANES) {            // two rows (four independent 16-byte loads) in flight per lane
         float va[V], da[V], vb[V], db[V];
         Elem<T>::load(x + r * C + ch0, va);

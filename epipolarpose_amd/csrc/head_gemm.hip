@@ -1519,12 +1519,18 @@ static int launch_gemm_mode(const GemmArgs& a, const GemmPlan& pl, int nphase, h
     // staging ring; the epilogue reuses it for the waves' output slices and, behind them, the BatchNorm-statistics combine area
     // (BNIN: the (scale, shift) table of the A operand's K channels behind the ring)
     constexpr size_t ring = (size_t)Cfg::NSTAGE * Cfg::STAGE_BYTES;
+    // (round 5) a launch whose workgroups run ONE K tile each (K = 64: the 64-channel layers of ResNet layer 1, forward and backward-data) never touches the
+    // second stage of the two-stage loop: it asks for one stage, and three workgroups instead of two fit a CU (registers allow three 4-wave workgroups) --
+    // these launches are a chain of latencies per workgroup (operands from HBM, 16 MFMAs, the epilogue), so residency is what hides them
+    const bool one_tile = !BNIN && !Cfg::STAGGER && Cfg::NSTAGE == 2 && pl.kps <= GBK;
+    const size_t staged = one_tile ? (size_t)Cfg::STAGE_BYTES : ring;
     const size_t lds = BNIN ? ring + (size_t)a.K * sizeof(float2)
-                            : std::max(ring, (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
+                            : std::max(staged, (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
     static_assert(!BNIN || ring >= (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float), "epilogue areas end below the table");
     if (lds > 65536) {
+        constexpr size_t full = std::max(ring, (size_t)Cfg::WM * Cfg::WN * (Cfg::TM * 32 * 128) + (size_t)Cfg::WM * 2 * Cfg::BN * sizeof(float));
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_gemm_kernel<OUT_F32, Cfg, MODE, RED, BNIN>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, BNIN ? (int)(ring + 2048 * sizeof(float2)) : (int)lds);
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, BNIN ? (int)(ring + 2048 * sizeof(float2)) : (int)full);
         if (attr != hipSuccess) return EPI_ERR_LAUNCH;
     }
     const dim3 grid((unsigned)pl.tiles, (unsigned)pl.nsplit, (unsigned)nphase);

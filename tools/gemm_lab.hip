@@ -292,7 +292,8 @@ static void stag_battery() {
     const Shape shapes[] = {{"8192^3          ", 8192, 8192, 8192}, {"4096^3          ", 4096, 4096, 4096}, {"2048^3          ", 2048, 2048, 2048},
                             {"fin.dX 1088->256", 131072, 256, 1088}, {"dc1.dX 2048x2048x4096", 2048, 2048, 4096}, {"dc3 32768x256x1024", 32768, 256, 1024},
                             {"8192x256x2304   ", 8192, 256, 2304},  {"8192x1024x256   ", 8192, 1024, 256},   {"ragged 1000x520x456", 1000, 520, 456},
-                            {"2048x512x2048   ", 2048, 512, 2048},  {"131072x256x64   ", 131072, 256, 64}};
+                            {"2048x512x2048   ", 2048, 512, 2048},  {"131072x256x64   ", 131072, 256, 64},    {"fin.fwd 256->1088", 131072, 1088, 256},
+                            {"131072x64x256   ", 131072, 64, 256}};
     printf("# stag: epi_gemm_bf16, tile 2 = 256x256 staggered loop (round 5), tile 5 = 256x256 lock-step loop (rounds 1-4), tile 1 = 128x128, tile 0 = planner's choice\n");
     printf("# check: a 512 x 512 corner block + the LAST 256 x 256 block against an fp32 reference (bad = elements off by > 1 %% + 0.02); race screen: 6 reruns, checksum of C\n");
     unsigned int* err; CK(hipMalloc(&err, 16));
