@@ -26,8 +26,11 @@ enum {
     F_NOREAD = 32,      // ablation: no fragment reads inside the loop
     F_NOMFMA = 64,      // ablation: no MFMAs
     F_TIME = 128,       // s_memtime at the four slot boundaries, summed per wave
-    F_ALT = 256,        // (stag2) odd waves issue their DMA pieces BEFORE their fragment reads, even waves after: TA and LDS pipe busy at the same time
+    F_ALT = 256,        // odd waves issue their DMA pieces BEFORE their fragment reads, even waves after: TA and LDS pipe busy at the same time
     F_DMA_MID = 512,    // (stag2) DMA pieces between the two halves of the slot's fragment reads
+    F_DMA_FIRST = 1024, // (stag) every wave issues its DMA pieces before its fragment reads
+    F_ALT2 = 2048,      // (stag) waves 0, 1 of a group issue the DMA of all four waves (8 pieces each) BEFORE their reads; waves 2, 3 only read
+    F_SPLIT1 = 4096,    // (stag) DMA pieces: 3 in the READ slot + 1 behind the 8th MFMA of the MFMA slot
 };
 
 __device__ uint4v zero_chunk[1];
@@ -75,6 +78,23 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
     }
     const char* zsrc = reinterpret_cast<const char*>(zero_chunk);
     int ka_run = 0, kb_run = 0;
+    // F_ALT2: this wave also stages the rows of wave wid + 2 (same group)
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);
+    const bool issuer = !(F & F_ALT2) || (wid_u & 3) < 2;
+    const unsigned short* a_ptr2[4];
+    const unsigned short* b_ptr2[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int trow = ((wid + 2) * 4 + ps) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((trow >> 1) & 7)) * 8;
+        a_ptr2[ps] = A + (long long)(m0 + (trow & 255)) * K + ch;
+        b_ptr2[ps] = Bt + (long long)(n0 + (trow & 255)) * K + ch;
+    }
+    auto issue_pair = [&](int ps, int buf, bool is_a) {          // piece ps of the partner wave (F_ALT2)
+        char* dst = smem + buf * STAGE + (is_a ? 0 : A_BYTES) + (wid_u + 2) * 4096 + ps * 1024;
+        const int kk = is_a ? (ka_run < K ? ka_run : 0) : (kb_run < K ? kb_run : 0);
+        glds16((is_a ? a_ptr2[ps] : b_ptr2[ps]) + kk, dst);
+    };
     auto issue_a_piece = [&](int ps, int buf) {
         char* dst = smem + buf * STAGE + __builtin_amdgcn_readfirstlane(wid) * 4096 + ps * 1024;
         if (F & F_FAST) {
@@ -108,18 +128,25 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
     const int a_frag = lds_off(wm * 128 + frow, fhalf), b_frag = lds_off(wn * 64 + frow, fhalf);
 
     // prologue: B(0), A(0), B(1)
+    if (issuer) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) issue_b_piece(ps, 0);
+        for (int ps = 0; ps < 4; ++ps) { issue_b_piece(ps, 0); if (F & F_ALT2) issue_pair(ps, 0, false); }
+    }
     kb_run += 64;
+    if (issuer) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) issue_a_piece(ps, 0);
+        for (int ps = 0; ps < 4; ++ps) { issue_a_piece(ps, 0); if (F & F_ALT2) issue_pair(ps, 0, true); }
+    }
     ka_run += 64;
+    if (issuer) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) issue_b_piece(ps, 1);
+        for (int ps = 0; ps < 4; ++ps) { issue_b_piece(ps, 1); if (F & F_ALT2) issue_pair(ps, 1, false); }
+    }
     kb_run += 64;
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (F & F_ALT2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();
+    const bool dma_first = (F & F_DMA_FIRST) || (F & F_ALT2) || ((F & F_ALT) && (wid_u & 1));
 
     bf16x8 af[4][2], bfr[4][2];
 #pragma unroll
@@ -146,6 +173,11 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
                 const int ps = ks + 1;                         // pieces 2 and 3 of the batch
                 if (is_a) issue_a_piece(ps, buf_dma); else issue_b_piece(ps, buf_dma);
             }
+            if ((F & F_SPLIT1) && !(F & F_NODMA) && ks == 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (is_a) issue_a_piece(3, buf_dma); else issue_b_piece(3, buf_dma);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (!(F & F_NOMFMA)) {
 #pragma unroll
                 for (int ti = 0; ti < 2; ++ti)
@@ -156,30 +188,35 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
         }
         if (!(F & F_NOPRIO)) __builtin_amdgcn_s_setprio(0);
     };
-    constexpr int NREAD = (F & F_SPLIT) ? 2 : 4;             // pieces issued in a READ slot
+    constexpr int NREAD = (F & F_SPLIT) ? 2 : ((F & F_SPLIT1) ? 3 : 4);             // pieces issued in a READ slot
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         const char* a_s = smem + buf * STAGE;
         const char* b_s = a_s + A_BYTES;
         // ---------------- READ(t,0)
-        if (!(F & F_NOREAD)) {
+        auto reads0 = [&]() {
+            if (!(F & F_NOREAD)) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-                    bfr[ks][tj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + tj * 4096)));
+                    for (int tj = 0; tj < 2; ++tj)
+                        bfr[ks][tj] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(b_s + ((b_frag ^ (ks << 5)) + tj * 4096)));
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + ti * 4096)));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(F & F_NODMA)) {
+                    for (int ti = 0; ti < 2; ++ti)
+                        af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + ti * 4096)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto dma0 = [&]() {
+            if (!(F & F_NODMA) && issuer) {
 #pragma unroll
-            for (int ps = 0; ps < NREAD; ++ps) issue_a_piece(ps, buf ^ 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+                for (int ps = 0; ps < NREAD; ++ps) { issue_a_piece(ps, buf ^ 1); if (F & F_ALT2) issue_pair(ps, buf ^ 1, true); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (dma_first) { dma0(); reads0(); } else { reads0(); dma0(); }
         if (!(F & F_LGKM_AFTER)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lap(t_read);
         __builtin_amdgcn_s_barrier();
@@ -189,27 +226,34 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
         mfma_half(0, buf ^ 1, true);
         ka_run += 64;
         __builtin_amdgcn_sched_barrier(0);
-        if (!(F & F_SPLIT)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (group 1's share of B(t+1) must be retired before group 0 reads it)
+        if (F & F_ALT2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (!(F & (F_SPLIT | F_SPLIT1))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (group 1's share of B(t+1) must be retired before group 0 reads it)
         lap(t_mfma);
         __builtin_amdgcn_s_barrier();
         lap(t_bar2);
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- READ(t,1)
-        if (!(F & F_NOREAD)) {
+        auto reads1 = [&]() {
+            if (!(F & F_NOREAD)) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + (2 + ti) * 4096)));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(F & F_NODMA)) {
+                    for (int ti = 0; ti < 2; ++ti)
+                        af[ks][ti] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(a_s + ((a_frag ^ (ks << 5)) + (2 + ti) * 4096)));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto dma1 = [&]() {
+            if (!(F & F_NODMA) && issuer) {
 #pragma unroll
-            for (int ps = 0; ps < NREAD; ++ps) issue_b_piece(ps, buf);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+                for (int ps = 0; ps < NREAD; ++ps) { issue_b_piece(ps, buf); if (F & F_ALT2) issue_pair(ps, buf, false); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (dma_first) { dma1(); reads1(); } else { reads1(); dma1(); }
         if (!(F & F_LGKM_AFTER)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (F & F_SPLIT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (F & F_SPLIT1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         lap(t_read);
         __builtin_amdgcn_s_barrier();
         if (F & F_LGKM_AFTER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -218,7 +262,7 @@ __global__ __launch_bounds__(512) void stag_kernel(const unsigned short* __restr
         mfma_half(1, buf, false);
         kb_run += 64;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (F & F_ALT2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         lap(t_mfma);
         __builtin_amdgcn_s_barrier();
         lap(t_bar2);
@@ -521,17 +565,14 @@ int main(int argc, char** argv) {
         printf("# M %d N %d K %d\n", M, N, K);
 #define RUN(F) run_variant<(F)>(#F, A, B, C, M, N, K, prof, ref, err, reps)
 #define RUN2(F) run_variant<(F), 2>("sched2 " #F, A, B, C, M, N, K, prof, ref, err, reps)
-        RUN(F_FAST);
-        RUN(F_FAST | F_LGKM_AFTER);
-        RUN2(0);
-        RUN2(F_NOPRIO);
-        RUN2(F_ALT);
-        RUN2(F_ALT | F_NOPRIO);
-        RUN2(F_DMA_MID);
-        RUN2(F_DMA_MID | F_NOPRIO);
-        RUN2(F_NODMA);
-        RUN2(F_ALT);
-        RUN(F_FAST);
+        for (int rep = 0; rep < 3; ++rep) {
+            RUN(F_FAST);
+            RUN(F_FAST | F_SPLIT1);
+            RUN(F_FAST | F_SPLIT);
+            RUN(F_FAST | F_SPLIT1 | F_LGKM_AFTER);
+            RUN(F_FAST | F_LGKM_AFTER);
+            RUN(F_FAST | F_SPLIT1 | F_NOPRIO);
+        }
 #undef RUN
 #undef RUN2
     }
