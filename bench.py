@@ -585,6 +585,30 @@ def main():
         ss_line = {"workload": "configs[2]: self-supervised, %d-view epipolar-triangulation pseudo-labels inside the step, batch=%d/GPU"
                                % (args.views, args.batch), "value": round(args.batch * world * args.steps / ss_elapsed, 2), "unit": "images/s",
                    "ms_per_step": round(ss_elapsed / args.steps * 1e3, 3), "final_loss": round(float(ss_loss.item()), 6)}
+        # what this workload adds to the fully-supervised step is ONE launch (decode -> triangulate -> re-project fused: csrc/selfsup.hip); SURVEY 8d: at
+        # the configuration's size its input is 7.5 KB -- launch-latency bound, so the figure that matters is microseconds per step; the HBM fraction of the
+        # triangulation kernels is shown on a bulk batch (tools/bench_kernels.py tri -> profiles/r05_microbench_tri.txt)
+        try:
+            xyz_ss = torch.zeros(args.batch, 3 * args.joints, device=device)
+            for _ in range(3):
+                hip.self_supervision(xyz_ss, ss_meta, args.views)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                hip.self_supervision(xyz_ss, ss_meta, args.views)
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            n_grp = args.batch // args.views
+            nbytes = n_grp * ((args.views * args.joints * 2 + args.views * 12 + args.joints * 3) * 4 + (args.views * 22 + args.views * args.joints * 3) * 4)
+            ss_line["roofline"] = {"kernel": "self_supervision_kernel (the launch this workload adds to configs[1]'s step; the rest of the step is configs[1]'s `roofline`)",
+                                   "bound": "hbm", "achieved": round(nbytes / us * 1e-3, 4), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / us * 1e-3 / 8000.0, 7),
+                                   "traffic": None, "algorithmic_bytes_per_launch": nbytes, "us_per_launch_back_to_back": round(us, 2), "launches_per_step": 1,
+                                   "note": "launch-latency bound at the configuration's size (SURVEY 8d: %d groups = %.1f KB per step); the fraction is reported for "
+                                           "form, the bulk figure is in profiles/r05_microbench_tri.txt" % (n_grp, nbytes / 1e3)}
+        except Exception as e:                   # (a diagnostic: never fail the bench line for it)
+            ss_line["roofline"] = {"error": str(e)}
 
     # the same step fed by the GPU input pipeline: uint8 BGR frames resident in HBM, per batch the reference's augmentation
     # draws + label arithmetic on the host and ONE crop / occlusion / normalisation launch (dataset/synthetic_frames.py); rides along like the SS leg

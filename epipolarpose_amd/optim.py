@@ -2,9 +2,9 @@
 
 ``FusedAdam`` is a ``torch.optim.Optimizer`` with ``torch.optim.Adam``'s arithmetic (no weight decay, no amsgrad:
 what the reference builds in ``lib/utils/utils.py:55-59``) executed by ``epi_adam_step`` in a single kernel launch over
-all parameters.  With ``low_precision_convs=True`` (default) every MIOpen-backed ``nn.Conv2d`` of the model is switched to
+all parameters.  With ``low_precision_convs=True`` (default) every ``nn.Conv2d`` / deconvolution / 1x1 module of the model is switched to
 a bf16 *training copy* of its weight: the fp32 ``weight`` Parameter stays the master (and the ``state_dict`` entry), the
-forward uses a bf16 leaf tensor whose gradient MIOpen produces directly in bf16, and the Adam kernel reads that bf16
+forward uses a bf16 leaf tensor whose gradient the weight-gradient kernels write directly in bf16, and the Adam kernel reads that bf16
 gradient and writes master + copy.  This removes autocast's per-step fp32->bf16 weight casts and bf16->fp32 gradient
 casts (~110 launches, ~0.5 ms per step at batch 32) on top of Adam's own ~25 launches.
 """
