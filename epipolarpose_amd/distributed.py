@@ -114,6 +114,9 @@ class BucketedGradSync:
         #                Each link carries S / N per phase instead of the ring's 2 (N - 1) S / N over one link.
         if collective not in ("allreduce", "direct"):
             raise ValueError("collective must be 'allreduce' or 'direct', got %r" % (collective,))
+        if collective == "direct" and dist.is_initialized() and dist.get_backend() == "gloo" and any(p.is_cuda for p in module.parameters()):
+            # gloo has no point-to-point transfers of device tensors (its all_reduce takes them): the direct form is for RCCL, or for CPU tensors on gloo (the tests)
+            raise ValueError("collective='direct' needs the nccl (RCCL) backend for GPU tensors; gloo only moves CPU tensors point to point")
         self.collective = collective
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
