@@ -2513,7 +2513,10 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
     static const int cand[] = {2, 3, 4, 6, 8, 12, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 1 << 30};
     // the choice depends on the shapes only: remembered per (class, shapes) -- a training step asks for the same four groups every pass
     static std::mutex memo_lock;
-    static std::unordered_map<unsigned long long, int> memo;
+    struct MemoEntry { std::vector<long long> shapes; int T; };     // the shapes the choice was made for: checked on a hit (a key collision recomputes)
+    static std::unordered_map<unsigned long long, MemoEntry> memo;
+    static const size_t MEMO_MAX = 256;                             // a training step asks for four groups; evaluation at many batch sizes must not grow it
+    std::vector<long long> shapes;
     for (int cls = 0; cls < 2; ++cls) {
         const double t_tile = cls ? 0.7 : 1.0, t_fixed = cls ? 3.0 : 4.0;
         // EPI_TN_GROUP_SLOTS=<percent>: the same knob for the grouped launches (measured: 100 / 70 / 50 / 35 -> 6.440 / 6.441 / 6.466 / 6.509 ms: off)
@@ -2525,18 +2528,19 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
         const long long slots = (cls ? 768 : 512) * group_percent / 100;
         unsigned long long key = 1469598103934665603ULL ^ (unsigned long long)(cls + 2 * group_percent + 1000 * (lpt_model ? 1 : 0));
         int members = 0;
+        shapes.assign(1, cls);
         for (int r = 0; r < n; ++r) {
             const GroupRowPlan& row = gp->rows[r];
             if (row.cls != cls) continue;
             ++members;
-            for (unsigned long long v : {(unsigned long long)row.tiles, (unsigned long long)row.ktiles, (unsigned long long)row.n}) { key ^= v; key *= 1099511628211ULL; }
+            for (long long v : {row.tiles, (long long)row.ktiles, row.n}) { key ^= (unsigned long long)v; key *= 1099511628211ULL; shapes.push_back(v); }
         }
         if (members == 0) continue;
         int best_T = -1;
         {
             std::lock_guard<std::mutex> g(memo_lock);
             auto it = memo.find(key);
-            if (it != memo.end()) best_T = it->second;
+            if (it != memo.end() && it->second.shapes == shapes) best_T = it->second.T;
         }
         if (best_T < 0) {
             double best_t = 1e30;
@@ -2575,7 +2579,8 @@ int group_plan(const EpiWgradItem* items, int n, GroupPlan* gp) {
                 if (t < best_t) { best_t = t; best_T = T; }
             }
             std::lock_guard<std::mutex> g(memo_lock);
-            memo[key] = best_T;
+            if (memo.size() >= MEMO_MAX) memo.clear();
+            memo[key] = MemoEntry{shapes, best_T};
         }
         for (int r = 0; r < n; ++r) {
             GroupRowPlan& row = gp->rows[r];

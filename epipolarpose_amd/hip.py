@@ -133,6 +133,19 @@ def lib_path():
     return _LIB_PATH
 
 
+class _Library:
+    """The loaded library plus the names an older A/B build (EPI_LIB_DIR) does not export: using one of those says so by name."""
+
+    def __init__(self, cdll, path, missing):
+        self.__dict__.update(_cdll=cdll, _path=path, _missing=frozenset(missing))
+
+    def __getattr__(self, name):
+        if name in self._missing:
+            raise RuntimeError("%s (loaded through EPI_LIB_DIR) does not export %s: that build predates the entry point -- "
+                               "this code path cannot be part of an A/B run against it" % (self._path, name))
+        return getattr(self._cdll, name)
+
+
 def load():
     """Load the shared library (once).  Raises if it has not been built (python -m epipolarpose_amd.build)."""
     global _lib
@@ -141,15 +154,17 @@ def load():
             raise RuntimeError("libepipolar_hip.so not found at %s -- build it with `python -m epipolarpose_amd.build` "
                                "(there is no CPU fallback)" % _LIB_PATH)
         lib = ctypes.CDLL(_LIB_PATH)
+        missing = []
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name, None)
             if fn is None:
-                if os.environ.get("EPI_LIB_DIR"):      # an older build loaded for an A/B run: entry points added since are simply absent
+                if os.environ.get("EPI_LIB_DIR"):      # an older build loaded for an A/B run: entry points added since are absent, and named on use
+                    missing.append(name)
                     continue
                 raise RuntimeError("%s does not export %s: stale build -- run `python -m epipolarpose_amd.build`" % (_LIB_PATH, name))
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
+        _lib = _Library(lib, _LIB_PATH, missing)
     return _lib
 
 

@@ -189,3 +189,19 @@ def test_refiner_data_alias_resolves_the_reference_import(tmp_path):
     x = np.delete(np.asarray(raw["valid"]["inp"], np.float32).reshape(24, -1), np.s_[18:21], axis=1)
     np.testing.assert_allclose(valid.data, (x - train.data_mean) / train.data_std, rtol=1e-6)
     assert abs(float(train.labels.mean())) < 1e-5                                                       # training targets standardised
+
+
+def test_ab_build_names_the_entry_point_it_lacks():
+    """EPI_LIB_DIR loads an older build for same-box A/B runs; an entry point added since is absent there.  Using it must say which one and why
+    (round-4 advisor: it surfaced as an opaque AttributeError from ctypes)."""
+    from epipolarpose_amd import hip
+
+    class Cdll:
+        epi_version = staticmethod(lambda: b"x")
+
+    lib = hip._Library(Cdll(), "/somewhere/libepipolar_hip.so", ["epi_triangulate_staged"])
+    assert lib.epi_version() == b"x"
+    with pytest.raises(RuntimeError, match="epi_triangulate_staged"):
+        lib.epi_triangulate_staged
+    with pytest.raises(AttributeError):
+        lib.epi_no_such_symbol
