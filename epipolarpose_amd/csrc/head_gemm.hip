@@ -456,7 +456,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::MIN_WAVES) void head_gemm_kernel
     const int tile_id = lid % (int)gridDim.x;
     lid /= (int)gridDim.x;
     const int split_id = lid % (int)gridDim.y, phase = lid / (int)gridDim.y;
-    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    if constexpr (GBM == 256 && GBN == 256) {
+        // One workgroup per CU: the 32 tiles an XCD runs at once are 32 CONSECUTIVE ids.  As a 1 x 32 strip they fetch 1 + 32 operand panels per K tile
+        // through that XCD's L2 (hit rate 48 %); in groups of 4 tile rows, column-major inside a group, they are a 4 x 8 block: 12 panels (81 %).
+        // Measured (tools/w4_lab.hip, 8192^3): the operand feed alone 1.53 -> 1.18 us per K tile, the GEMM +10 .. 13 %.
+        constexpr int GM = 4;
+        const int tiles_m = (p.M + GBM - 1) / GBM, per_group = GM * tiles_n, g = tile_id / per_group, i = tile_id - g * per_group;
+        const int rows = min(GM, tiles_m - g * GM);
+        tile_m = g * GM + i % rows;
+        tile_n = i / rows;
+    }
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
     const int ph = phase >> 1, pw = phase & 1;
     const unsigned short* Bt = p.Bt + (MODE == A_PHASED ? p.ph.bt_off[phase] : 0);
