@@ -33,6 +33,8 @@ enum {
     F_GM8 = 512,        // groups of 8 tile rows (8 x 4)
     F_GM16 = 1024,
     F_BUF = 2048,       // (w4) buffer_load ... lds with an SGPR piece offset and a 32-bit lane offset instead of global_load_lds with a 64-bit lane address
+    F_SWZ4 = 4096,      // (w4, feed experiment, WRONG results) source-side swizzle restricted to bit 2: whole quads of lanes swap, the order inside a quad ascends
+    F_SWZ0 = 8192,      // (w4, feed experiment, WRONG results) no source-side swizzle: every lane group of 8 reads its row in ascending address order
     F_CLOCK = 128,      // wave 0 of every workgroup: s_memtime (shader clock) and s_memrealtime (100 MHz) across the K loop -> cycles per K tile and the clock the loop ran at
 };
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void w4_kernel(const unsigned short* __restric
     // in its slot: chunk (lane&7) ^ ((row>>1)&7), and (row>>1)&7 = 4*(q&1) + (lane>>4) -- two lane offsets, everything else is uniform
     int voff[2];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) voff[par] = (lane >> 3) * ld + (((lane & 7) ^ (4 * par + (lane >> 4))) << 3);
+    for (int par = 0; par < 2; ++par) voff[par] = (lane >> 3) * ld + (((lane & 7) ^ ((4 * par + (lane >> 4)) & ((F & F_SWZ0) ? 0 : (F & F_SWZ4) ? 4 : 7))) << 3);
     const unsigned short* a_w = A + (long long)(m0 + wid * 64) * ld;
     const unsigned short* b_w = Bt + (long long)(n0 + wid * 64) * ld;
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0x7fffffff, 0x00027000);
@@ -647,6 +649,39 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, A, max_el, 1u, mode);
     hipLaunchKernelGGL(fill_bf16, dim3(4096), dim3(256), 0, 0, B, max_el, 2u, mode);
     CK(hipDeviceSynchronize());
+    if (argc > 1 && !strcmp(argv[1], "pmc")) {          // one launch set per variant at 8192^3 for a rocprofv3 --pmc pass (kernel names carry the variant)
+        const int M = 8192, N = 8192, K = 8192, reps = 1;
+#define RUN(F, P3, P0, P1, P2, BP) run_variant<(F), P3, P0, P1, P2, BP>(#F " P " #P3 " " #P0 " " #P1 " " #P2 " bar " #BP, A, B, C, M, N, K, ref, err, sum, reps)
+        RUN(F_GM4, 6, 6, 4, 0, 4);
+        RUN(0, 6, 6, 4, 0, 4);
+        RUN(F_GM4 | F_NOMFMA, 6, 6, 4, 0, 4);
+        RUN(F_GM4 | F_NOMFMA | F_SWZ0, 6, 6, 4, 0, 4);
+        RUN(F_GM4 | F_SWZ0 | F_NODMA, 6, 6, 4, 0, 4);
+        run_vgpr<F_GM4, 4, 4, 4, 4, 4>("vgpr F_GM4", A, B, C, M, N, K, ref, err, sum, reps);
+#undef RUN
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "swz")) {          // source-side swizzle experiment (feed only; results of the SWZ variants are wrong by construction)
+        const int M = 8192, N = 8192, K = 8192, reps = 8;
+#define RUN(F, P3, P0, P1, P2, BP) run_variant<(F), P3, P0, P1, P2, BP>(#F " P " #P3 " " #P0 " " #P1 " " #P2 " bar " #BP, A, B, C, M, N, K, ref, err, sum, reps)
+        for (int rep = 0; rep < 3; ++rep) {
+            RUN(F_CLOCK | F_GM4, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4, 12, 4, 0, 0, 4);
+            RUN(F_CLOCK | F_GM4, 8, 8, 0, 0, 4);
+            RUN(F_CLOCK | F_GM4, 8, 8, 0, 0, 0);
+            RUN(F_CLOCK | F_GM4 | F_DMA_LATE, 8, 8, 0, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA | F_SWZ4, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA | F_SWZ0, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA | F_NOREAD, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA | F_NOREAD | F_SWZ4, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOMFMA | F_NOREAD | F_SWZ0, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOREAD, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_NOREAD | F_SWZ0, 6, 6, 4, 0, 4);
+        }
+#undef RUN
+        return 0;
+    }
     if (argc > 3) {          // row-pitch experiment: K + pad elements per row
         for (int rep = 0; rep < 2; ++rep)
             for (int pad : {0, 64, 192, 0, 64, 192}) {
