@@ -288,7 +288,10 @@ def build_roofline(args, ksum, glue_times, model, images):
                          "share of the step",
                "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                "traffic": None, "algorithmic_flops_per_launch": flops / max(launches, 1e-9), "avg_ms": round(ms / max(launches, 1e-9), 5),
-               "launches_per_step": round(launches, 1), "ms_per_step": round(ms, 4)}
+               "launches_per_step": round(launches, 1), "ms_per_step": round(ms, 4),
+               # context, not the denominator of `frac`: back-to-back MFMAs ALONE on random bf16 operand values hold 1.81 GHz on this chip
+               # (tools/w4_lab.hip, profiles/r05_w4_lab.txt) -- the rate no bf16 GEMM on such operands exceeds here; hipBLASLt's 8192^3 reaches 1613-1662
+               "peak_sustained_mfma_only_random_bf16": 1668.0}
         own_stem = any(k.startswith("stem_conv") for k in fam)       # round 3: the stem runs on the implicit-GEMM kernels and is in the family already
         stem_ms, stem_flops = (0.0, 0.0) if own_stem else stem_conv_ms(model, images)
         out["conv_stack"] = {"what": "every convolution of the network" + ("" if own_stem else " incl. the library 7x7 stem (timed separately after the timed region)"),
