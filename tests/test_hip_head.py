@@ -37,6 +37,8 @@ def close(got, ref, rel=1.2e-2, outliers=0.0):
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 1088, 256), (1000, 200, 128), (4096, 256, 1088), (77, 36, 192), (512, 256, 24), (300, 40, 200),
                                    # 256x256-tile configuration: ragged M and N, K tail, split-K (few tiles) and no split (many tiles)
                                    (5164, 2528, 520), (2000, 2040, 4104), (65536, 256, 512), (2048, 1024, 2048), (700, 456, 576),
+                                   # ... its tiles are ordered in groups of 4 tile rows: 21 (remainder group of 1), 6 (of 2) and 3 tile rows (a lone group of 3)
+                                   (1500, 512, 4096),
                                    # A-stationary kernel (K in {64,128,256}, wide N, many rows): ragged M and N
                                    (16500, 1088, 256), (20000, 520, 128), (16384, 264, 64)])
 def test_gemm_vs_torch(dev, m, n, k):
