@@ -1,7 +1,9 @@
 """Synthetic-occlusion augmentation -- mirror of the reference's ``lib/utils/augmentation.py``.
 
 The reference pastes segmented Pascal-VOC objects over the person patch (``load_occluders`` :9-58, ``occlude_with_objects`` :61-81,
-``paste_over`` :84-114, ``resize_by_factor`` :117-123).  There is no Pascal VOC on the build / GPU boxes, so ``load_occluders`` falls back
+``paste_over`` :84-114, ``resize_by_factor`` :117-123).  ``load_occluders(root)`` reads a Pascal-VOC tree in the reference's on-disk format
+(``Annotations/*.xml``, ``JPEGImages``, ``SegmentationObject``; decoding is PIL's as in the reference, the two OpenCV calls -- the 8 x 8 elliptic
+erosion and the INTER_AREA halving -- are restated).  There is no Pascal VOC on the build / GPU boxes, so without a tree it falls back
 to procedural RGBA occluders with the reference's alpha convention (255 inside the object, 192 on the ring its 8 x 8 erosion removes,
 0 outside) and the same half-size down-scaling; everything downstream is the reference's pipeline: the random draws are made on the host
 in the reference's order (``draw_occlusion``), the resize (box-filter average = ``cv2.resize(INTER_AREA)`` restated) and the float32
@@ -37,10 +39,90 @@ def _procedural_occluder(rng):
     return ((q + 2) // 4).astype(np.uint8)
 
 
+def _ellipse_element(width, height):
+    """The ones of ``cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (width, height))`` as (row offset, column offset) pairs from its anchor, the
+    element's centre (augmentation.py:11; OpenCV: row i spans [c - dx, c + dx], dx = round(c * sqrt(1 - (i - r)^2 / r^2)), r = height // 2,
+    c = width // 2)."""
+    r, c = height // 2, width // 2
+    taps = []
+    for i in range(height):
+        dy = i - r
+        if abs(dy) > r:
+            continue
+        dx = int(np.rint(c * np.sqrt((r * r - dy * dy) / float(r * r)))) if r else 0
+        taps += [(dy, j - c) for j in range(max(c - dx, 0), min(c + dx + 1, width))]
+    return taps
+
+
+def _erode(mask, taps):
+    """``cv2.erode`` of a uint8 [h, w] mask by the element ``taps``: the minimum over the element, pixels outside the image not taking part."""
+    h, w = mask.shape
+    reach = max(max(abs(a), abs(b)) for a, b in taps)
+    framed = np.full((h + 2 * reach, w + 2 * reach), 255, np.uint8)
+    framed[reach:reach + h, reach:reach + w] = mask
+    out = mask.copy()
+    for dy, dx in taps:
+        np.minimum(out, framed[reach + dy:reach + dy + h, reach + dx:reach + dx + w], out=out)
+    return out
+
+
+def _cover(src, dst):
+    """[dst, src] int64: how many 1/dst-ths of source pixel k fall under destination pixel i when ``src`` pixels shrink onto ``dst`` (rows sum to src)."""
+    edges = np.arange(dst + 1, dtype=np.int64) * src                    # destination pixel i covers [i*src, (i+1)*src) in units of 1/dst source pixel
+    lo = np.maximum(edges[:-1, None], np.arange(src, dtype=np.int64)[None, :] * dst)
+    hi = np.minimum(edges[1:, None], (np.arange(src, dtype=np.int64)[None, :] + 1) * dst)
+    return np.maximum(hi - lo, 0)
+
+
+def resize_area(im, new_size):
+    """``cv2.resize(im, new_size, interpolation=cv2.INTER_AREA)`` for a down-scale of a uint8 [h, w, C] image: every destination pixel is the
+    area-weighted mean of the source pixels under it, rounded half up -- the same box filter the crop kernel applies to the drawn factor."""
+    h, w, _ = im.shape
+    nw, nh = int(new_size[0]), int(new_size[1])
+    acc = np.einsum("ik,kjc,lj->ilc", _cover(h, nh), im.astype(np.int64), _cover(w, nw))
+    return ((2 * acc + h * w) // (2 * h * w)).astype(np.uint8)
+
+
+def _read_voc(root):
+    """augmentation.py:13-56: the segmented, non-person, non-difficult, non-truncated objects of a Pascal-VOC tree as half-size RGBA cut-outs."""
+    import xml.etree.ElementTree
+    import PIL.Image
+    element = _ellipse_element(8, 8)
+    ann = os.path.join(root, "Annotations")
+    occluders = []
+    for path in sorted(p for p in (os.path.join(ann, n) for n in os.listdir(ann)) if os.path.isfile(p)):           # list_filepaths :126-129
+        node = xml.etree.ElementTree.parse(path).getroot()
+        if node.find("segmented").text == "0":
+            continue
+        wanted = []
+        for i_obj, obj in enumerate(node.findall("object")):
+            if obj.find("name").text == "person" or obj.find("difficult").text != "0" or obj.find("truncated").text != "0":
+                continue
+            box = obj.find("bndbox")
+            wanted.append((i_obj, [int(box.find(k).text) for k in ("xmin", "ymin", "xmax", "ymax")]))
+        if not wanted:
+            continue
+        name = node.find("filename").text
+        with PIL.Image.open(os.path.join(root, "JPEGImages", name)) as f:
+            image = np.asarray(f)
+        with PIL.Image.open(os.path.join(root, "SegmentationObject", name.replace("jpg", "png"))) as f:
+            labels = np.asarray(f)                                                                                   # palette indices = instance labels
+        for i_obj, (x0, y0, x1, y1) in wanted:
+            mask = np.where(labels[y0:y1, x0:x1] == i_obj + 1, 255, 0).astype(np.uint8)
+            if np.count_nonzero(mask) < 500:                                                                        # :44-46 small objects
+                continue
+            mask[_erode(mask, element) < mask] = 192                                                                # :49-50 softer border
+            rgba = np.concatenate([image[y0:y1, x0:x1], mask[:, :, None]], axis=2)
+            half = np.round(np.array([rgba.shape[1], rgba.shape[0]]) * 0.5).astype(int)                             # resize_by_factor(.., 0.5) :52, :121
+            occluders.append(resize_area(rgba, half))
+    return occluders
+
+
 def load_occluders(pascal_voc_root_path=None, count=16, seed=0):
-    """augmentation.py:9-58.  Without a Pascal-VOC tree (none on the boxes) -> ``count`` procedural occluders, seeded."""
+    """augmentation.py:9-58.  With a Pascal-VOC tree: its occluders, in the reference's order.  Without one (none on the boxes; the reference's
+    default path is the author's disk) -> ``count`` procedural occluders, seeded."""
     if pascal_voc_root_path and os.path.isdir(os.path.join(str(pascal_voc_root_path), "Annotations")):
-        raise NotImplementedError("reading Pascal VOC needs cv2 / PIL, which are not in this image; procedural occluders are used instead")
+        return _read_voc(str(pascal_voc_root_path))
     rng = np.random.default_rng(seed)
     return [_procedural_occluder(rng) for _ in range(count)]
 

@@ -160,6 +160,80 @@ def resize_by_factor(im, factor):
     return resize_area(im, new_size)
 
 
+def structuring_ellipse(ksize):
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, ksize) restated (OpenCV 4.1 ``modules/imgproc/src/morph.dispatch.cpp``: row i of a
+    (w, h) element holds ones on [c - dx, c + dx] with r = h // 2, c = w // 2, dy = i - r, dx = cvRound(c * sqrt((r*r - dy*dy) / r*r));
+    rows with |dy| > r stay empty).  uint8 [h, w].  **Unpinned** like every OpenCV restatement here."""
+    w, h = int(ksize[0]), int(ksize[1])
+    r, c = h // 2, w // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    out = np.zeros((h, w), np.uint8)
+    for i in range(h):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))          # (cvRound: half to even, as rint)
+            out[i, max(c - dx, 0):min(c + dx + 1, w)] = 1
+    return out
+
+
+def erode(mask, kernel):
+    """cv2.erode(mask, kernel) restated for a uint8 [h, w] image: anchor at the element's centre (w // 2, h // 2), pixels outside the image do
+    not take part (``morphologyDefaultBorderValue`` = +max for erosion): out[y, x] = min over the element's ones of
+    mask[y + i - ay, x + j - ax].  Pure-Python loops over the element (<= 64 taps)."""
+    mask = np.asarray(mask, np.uint8)
+    kh, kw = kernel.shape
+    ay, ax = kh // 2, kw // 2
+    h, w = mask.shape
+    pad = np.full((h + kh, w + kw), 255, np.uint8)
+    pad[ay:ay + h, ax:ax + w] = mask
+    out = np.full((h, w), 255, np.uint8)
+    for i in range(kh):
+        for j in range(kw):
+            if kernel[i, j]:
+                out = np.minimum(out, pad[i:i + h, j:j + w])
+    return out
+
+
+def load_occluders(pascal_voc_root_path):
+    """augmentation.py:9-58: every non-person, non-difficult, non-truncated object of every SEGMENTED Pascal-VOC annotation (files in sorted
+    order, :126-129), cut out with its instance mask (label i_obj + 1 of SegmentationObject), dropped below 500 mask pixels, the mask set to 192
+    where an 8 x 8 elliptic erosion removes it, RGBA, halved with INTER_AREA.  Decoding is PIL's, as in the reference (:39-40)."""
+    import os
+    import xml.etree.ElementTree
+    import PIL.Image
+    occluders = []
+    element = structuring_ellipse((8, 8))
+    ann_dir = os.path.join(pascal_voc_root_path, "Annotations")
+    paths = sorted(p for p in (os.path.join(ann_dir, n) for n in os.listdir(ann_dir)) if os.path.isfile(p))
+    for annotation_path in paths:
+        xml_root = xml.etree.ElementTree.parse(annotation_path).getroot()
+        if xml_root.find("segmented").text == "0":
+            continue
+        boxes = []
+        for i_obj, obj in enumerate(xml_root.findall("object")):
+            is_person = obj.find("name").text == "person"
+            is_difficult = obj.find("difficult").text != "0"
+            is_truncated = obj.find("truncated").text != "0"
+            if not is_person and not is_difficult and not is_truncated:
+                bndbox = obj.find("bndbox")
+                boxes.append((i_obj, [int(bndbox.find(s).text) for s in ("xmin", "ymin", "xmax", "ymax")]))
+        if not boxes:
+            continue
+        im_filename = xml_root.find("filename").text
+        im = np.asarray(PIL.Image.open(os.path.join(pascal_voc_root_path, "JPEGImages", im_filename)))
+        labels = np.asarray(PIL.Image.open(os.path.join(pascal_voc_root_path, "SegmentationObject", im_filename.replace("jpg", "png"))))
+        for i_obj, (xmin, ymin, xmax, ymax) in boxes:
+            object_mask = (labels[ymin:ymax, xmin:xmax] == i_obj + 1).astype(np.uint8) * 255
+            object_image = im[ymin:ymax, xmin:xmax]
+            if np.count_nonzero(object_mask) < 500:
+                continue
+            eroded = erode(object_mask, element)
+            object_mask[eroded < object_mask] = 192
+            object_with_mask = np.concatenate([object_image, object_mask[..., np.newaxis]], axis=-1)
+            occluders.append(resize_by_factor(object_with_mask, 0.5))
+    return occluders
+
+
 def paste_over(im_src, im_dst, center):
     """augmentation.py:84-114: alpha-blend the RGBA ``im_src`` onto the uint8 RGB ``im_dst`` in place (float32 arithmetic, the
     assignment into the uint8 array truncates)."""
