@@ -32,7 +32,7 @@ struct PatchArgs {
     int max_occ;
 };
 
-// One pixel of occluder image `src` [sh][sw][4] resized to (dw, dh) <= (sw, sh) by box-filter averaging (cv2.resize INTER_AREA restated with
+// One pixel of occluder image `src` [sh][sw][4] resized DOWN to (dw, dh) <= (sw, sh) by box-filter averaging (cv2.resize INTER_AREA restated with
 // exact integer arithmetic; the test oracle restates the same rule): destination pixel (px, py) covers [px*sw, (px+1)*sw) x [py*sh, (py+1)*sh) in
 // units of 1/dw x 1/dh source pixels.
 __device__ __forceinline__ void occluder_pixel(const unsigned char* __restrict__ src, int sh, int sw, int dh, int dw, int px, int py, int (&rgba)[4]) {
@@ -55,6 +55,35 @@ __device__ __forceinline__ void occluder_pixel(const unsigned char* __restrict__
     const long long den = (long long)sh * sw;
 #pragma unroll
     for (int c = 0; c < 4; ++c) rgba[c] = (int)((2 * acc[c] + den) / (2 * den));
+}
+
+// One pixel of `src` resized UP to (dw, dh) >= (sw, sh): cv2.resize INTER_LINEAR on uint8 restated (OpenCV 4.1 resize.cpp: the coordinate tables of
+// cv::resize, HResizeLinear<uchar, int, short, 2048>, the 8-bit VResizeLinear).  x: fx = float((px + 0.5) * (sw / dw) - 0.5), sx = floor(fx), fx -= sx,
+// (sx, fx) = (0, 0) left of the image and (sw - 1, 0) from its last column on; y: no border rule, the two rows are clamped into the image instead;
+// weights short(round-half-even(w * 2048)) of the float32 values; ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// augmentation.py:122 -- patches larger than 256 px (im_scale_factor > 1: the 384 px configuration).
+__device__ __forceinline__ void occluder_pixel_linear(const unsigned char* __restrict__ src, int sh, int sw, int dh, int dw, int px, int py, int (&rgba)[4]) {
+    float fx = (float)(((double)px + 0.5) * ((double)sw / (double)dw) - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= sw - 1) { sx = sw - 1; fx = 0.f; }
+    float fy = (float)(((double)py + 0.5) * ((double)sh / (double)dh) - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));
+    const int b0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = (int)rintf(__fmul_rn(fy, 2048.f));
+    const int x1 = min(sx + 1, sw - 1), y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+    const unsigned char* q00 = src + ((long long)y0 * sw + sx) * 4;
+    const unsigned char* q01 = src + ((long long)y0 * sw + x1) * 4;
+    const unsigned char* q10 = src + ((long long)y1 * sw + sx) * 4;
+    const unsigned char* q11 = src + ((long long)y1 * sw + x1) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r0 = q00[c] * a0 + q01[c] * a1, r1 = q10[c] * a0 + q11[c] * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        rgba[c] = v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
 }
 
 __device__ __forceinline__ int round_half_even(double v) { return (int)__double2ll_rn(v); }   // cvRound / saturate_cast<int>(double)
@@ -138,7 +167,9 @@ __global__ __launch_bounds__(256) void patch_crop_kernel(PatchArgs p) {
             const int dw = pl[5 * k + 1], dh = pl[5 * k + 2], ox = x - pl[5 * k + 3], oy = y - pl[5 * k + 4];
             if ((unsigned)ox >= (unsigned)dw || (unsigned)oy >= (unsigned)dh) continue;
             int rgba[4];
-            occluder_pixel(p.occ_bank + p.occ_offset[idx], p.occ_hw[2 * idx], p.occ_hw[2 * idx + 1], dh, dw, ox, oy, rgba);
+            const int sh = p.occ_hw[2 * idx], sw = p.occ_hw[2 * idx + 1];
+            if (dw > sw || dh > sh) occluder_pixel_linear(p.occ_bank + p.occ_offset[idx], sh, sw, dh, dw, ox, oy, rgba);          // factor > 1: INTER_LINEAR (:122)
+            else occluder_pixel(p.occ_bank + p.occ_offset[idx], sh, sw, dh, dw, ox, oy, rgba);                                     // INTER_AREA
             const float alpha = __fdiv_rn((float)rgba[3], 255.f), rest = __fsub_rn(1.f, alpha);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

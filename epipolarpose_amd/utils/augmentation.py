@@ -144,18 +144,6 @@ class OccluderBank:
         return self.bank, self.offset, self.hw
 
 
-_warned_upscale = False
-
-
-def _warn_upscale_once(factor):
-    global _warned_upscale
-    if not _warned_upscale:
-        import warnings
-        warnings.warn("epipolarpose_amd: occluder scale factor %.2f > 1 (patch larger than 256 px): the reference's bilinear up-scale is not "
-                      "implemented, occluders are pasted at native size (documented deviation)" % factor)
-        _warned_upscale = True
-
-
 def draw_occlusion(patch_hw, bank_hw, np_rng=np.random, py_rng=random):
     """The random draws of ``occlude_with_objects`` (augmentation.py:61-81) in the reference's order, turned into what the kernel needs:
     int32 [MAX_OCCLUDERS, 5] rows (occluder index | -1, pasted width, pasted height, x0, y0)."""
@@ -168,13 +156,9 @@ def draw_occlusion(patch_hw, bank_hw, np_rng=np.random, py_rng=random):
         factor = np_rng.uniform(0.2, 1.0) * im_scale_factor
         center = np_rng.uniform([0, 0], width_height)
         h, w = int(bank_hw[idx][0]), int(bank_hw[idx][1])
-        if factor <= 1.0:                                    # resize_by_factor :121: new size = round(size * factor), INTER_AREA
-            w, h = (int(v) for v in np.round(np.array([w, h]) * factor).astype(int))
-        else:
-            # KNOWN DEVIATION (patches larger than 256 px only, e.g. the 384 px configuration: im_scale_factor = 1.5): the reference up-scales
-            # the occluder with INTER_LINEAR here (resize_by_factor :122); the crop kernel has the INTER_AREA box filter only, so the occluder is
-            # pasted at its native size -- up to 1.5x smaller than the reference's.  The oracle restates the same omission.
-            _warn_upscale_once(factor)
+        # resize_by_factor :121-123: new size = round(size * factor); the kernel resizes with INTER_AREA when that shrinks the occluder and with
+        # INTER_LINEAR when it grows it (factor > 1: patches larger than 256 px, e.g. the 384 px configuration's im_scale_factor = 1.5)
+        w, h = (int(v) for v in np.round(np.array([w, h]) * factor).astype(int))
         if w < 1 or h < 1:
             continue
         c = np.round(center).astype(np.int32)                # paste_over :101-103

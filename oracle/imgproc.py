@@ -115,8 +115,8 @@ def normalized_patch(cvimg, c_x, c_y, bb_width, bb_height, patch_width, patch_he
 # convention: 255 inside, 192 on the eroded border ring, 0 outside).
 # ``cv2.resize(..., INTER_AREA)`` is third-party code that is not installed: restated as the exact box-filter average over the
 # source area each destination pixel covers (integer arithmetic: coverage in units of 1 / (dst_w * dst_h) source pixels, rounded
-# half up) -- **parity unpinned** like the warpAffine layer.  Up-scaling (factor > 1: patches larger than 256 px) is not restated:
-# the occluder is pasted at its native size.
+# half up) -- **parity unpinned** like the warpAffine layer.  Up-scaling (factor > 1: patches larger than 256 px, i.e. configs[4]'s 384 px)
+# is ``cv2.resize(..., INTER_LINEAR)`` on uint8: OpenCV 4.1 ``modules/imgproc/src/resize.cpp`` restated (``resize_linear`` below), unpinned as well.
 # ------------------------------------------------------------------------------------------------------------------
 def do_augmentation(np_rng, py_rng, scale_factor=0.25, rot_factor=30, color_factor=0.2, do_flip_aug=False, rot_aug_rate=0.6,
                     flip_aug_rate=0.5):
@@ -152,11 +152,44 @@ def resize_area(im, new_size):
     return ((2 * acc + den) // (2 * den)).astype(np.uint8)
 
 
+def resize_linear(im, new_size):
+    """``cv2.resize(im, new_size, interpolation=cv2.INTER_LINEAR)`` for uint8 [h, w, C] (OpenCV 4.1 ``resize.cpp``: ``cv::resize`` table set-up +
+    ``HResizeLinear<uchar, int, short, 2048>`` + the 8-bit ``VResizeLinear``), restated:
+      x: fx = float32((dx + 0.5) * (sw / dw) - 0.5), sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= sw - 1 -> (sw - 1, 0);
+         weights short(round((1 - fx) * 2048)), short(round(fx * 2048)) (float32 products, round half to even);
+      y: the same without the border rule -- the two ROWS are clamped into the image instead;
+      horizontal pass in int32, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2."""
+    im = np.asarray(im, np.uint8)
+    sh, sw, _ = im.shape
+    dw, dh = int(new_size[0]), int(new_size[1])
+
+    def table(s, d, zero_at_border):
+        f = ((np.arange(d, dtype=np.float64) + 0.5) * (float(s) / d) - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        f = f - i0.astype(np.float32)
+        if zero_at_border:
+            lo, hi = i0 < 0, i0 >= s - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            i0 = np.where(lo, 0, np.where(hi, s - 1, i0))
+        w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        w1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return i0, w0, w1
+    sx, a0, a1 = table(sw, dw, True)
+    sy, b0, b1 = table(sh, dh, False)
+    src = im.astype(np.int64)
+    rows = src[:, sx] * a0[None, :, None] + src[:, np.minimum(sx + 1, sw - 1)] * a1[None, :, None]          # [sh, dw, C], scale 2048
+    r0, r1 = rows[np.clip(sy, 0, sh - 1)], rows[np.clip(sy + 1, 0, sh - 1)]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def resize_by_factor(im, factor):
-    """augmentation.py:117-123 for factor <= 1 (INTER_AREA); factor > 1 returns the image unchanged (see the section header)."""
+    """augmentation.py:117-123: INTER_AREA for factor <= 1, INTER_LINEAR above."""
     new_size = tuple(np.round(np.array([im.shape[1], im.shape[0]]) * factor).astype(int))
-    if factor > 1.0 or new_size[0] < 1 or new_size[1] < 1:
-        return im.copy() if factor > 1.0 else im[:0, :0].copy()
+    if factor > 1.0:
+        return resize_linear(im, new_size)
+    if new_size[0] < 1 or new_size[1] < 1:
+        return im[:0, :0].copy()
     return resize_area(im, new_size)
 
 

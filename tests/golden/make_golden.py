@@ -487,6 +487,12 @@ def gen_pipeline():
     np.random.seed(21)
     out["occlude/im"], out["occlude/seed"] = im, np.int64(21)
     out["occlude/out"] = aug.occlude_with_objects(im, occluders)
+    # configs[4]'s patch size: im_scale_factor = 1.5, so part of the draws GROW the occluder (resize_by_factor's INTER_LINEAR branch, :122)
+    im384 = rng.integers(0, 256, (384, 384, 3)).astype(np.uint8)
+    random.seed(22)
+    np.random.seed(22)
+    out["occlude384/im"], out["occlude384/seed"] = im384, np.int64(22)
+    out["occlude384/out"] = aug.occlude_with_objects(im384, occluders)
     # get_single_patch_sample on two synthetic frames, with and without occluders
     sc = SyntheticScenes(n_group=2, n_view=2, num_joints=17, seed=31, augment=False)
     frames = {}

@@ -79,3 +79,20 @@ def test_crop_patches_kernel_vs_oracle(dtype, channels_last):
             np.testing.assert_allclose(got, want, rtol=2 ** -8, atol=2 ** -8)
     patch_bgr, t0 = img_utils.generate_patch_image_cv(frames[0], cx[0], cy[0], bw[0], bh[0], 64, 64, False, 1.0, 0.0)
     np.testing.assert_array_equal(patch_bgr, o_img.generate_patch_image(frames[0], cx[0], cy[0], bw[0], bh[0], 64, 64, False, 1.0, 0.0)[0])
+
+
+def test_resize_linear_restatement_properties():
+    """cv2.resize(INTER_LINEAR) on uint8 as the oracle restates it (the occluder up-scale of patches larger than 256 px, augmentation.py:122): same size is
+    the identity, constants stay constant, a 2x up-scale takes the closed-form fixed-point blend (left border clamped, weights 0.75 / 0.25)."""
+    from oracle import imgproc as o_img
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, (9, 7, 4)).astype(np.uint8)
+    assert np.array_equal(o_img.resize_linear(im, (7, 9)), im)
+    assert (o_img.resize_linear(np.full((6, 9, 4), 137, np.uint8), (13, 11)) == 137).all()
+    up = o_img.resize_linear(im, (14, 9))                                   # x only: 7 -> 14 columns
+    src = im.astype(np.int64)
+    assert np.array_equal(up[:, 0], im[:, 0]) and np.array_equal(up[:, 13], im[:, 6])
+    want = (src[:, 0] * 1536 + src[:, 1] * 512)                           # column 1: fx = 0.25 -> weights 1536, 512 of 2048; vertical weights (2048, 0)
+    assert np.array_equal(up[:, 1], ((((2048 * (want >> 4)) >> 16) + 2) >> 2).astype(np.uint8))
+    assert np.array_equal(o_img.resize_by_factor(im, 1.5), o_img.resize_linear(im, (10, 14)))      # round(7 * 1.5) = 10 (half to even), round(9 * 1.5) = 14
+    assert np.array_equal(o_img.resize_by_factor(im, 0.5), o_img.resize_area(im, (4, 4)))

@@ -46,6 +46,12 @@ def test_oracle_paste_over_and_occlusion_match_reference(golden):
     got = o_img.occlude_with_objects(g["occlude/im"], occluders, np.random.RandomState(seed), random.Random(seed))
     np.testing.assert_array_equal(got, g["occlude/out"])
     assert (got != g["occlude/im"]).any(axis=2).mean() > 0.02
+    # 384 px (configs[4]): the reference's occlude_with_objects with draws that GROW the occluder -- resize_by_factor's INTER_LINEAR branch (:122)
+    seed = int(g["occlude384/seed"])
+    draws = o_img.draw_occlusion(g["occlude384/im"].shape, len(occluders), np.random.RandomState(seed), random.Random(seed))
+    assert any(f > 1.0 for _, f, _ in draws) and any(f <= 1.0 for _, f, _ in draws)
+    got = o_img.occlude_with_objects(g["occlude384/im"], occluders, np.random.RandomState(seed), random.Random(seed))
+    np.testing.assert_array_equal(got, g["occlude384/out"])
 
 
 def test_resize_area_properties():
@@ -57,7 +63,7 @@ def test_resize_area_properties():
     np.testing.assert_array_equal(half, want.astype(np.uint8))
     flat = np.full((7, 11, 3), 93, np.uint8)
     assert (o_img.resize_area(flat, (5, 3)) == 93).all()                                                  # weights sum to the area
-    assert o_img.resize_by_factor(im, 0.5).shape == (6, 9, 4) and o_img.resize_by_factor(im, 1.7).shape == im.shape
+    assert o_img.resize_by_factor(im, 0.5).shape == (6, 9, 4) and o_img.resize_by_factor(im, 1.7).shape == (20, 31, 4)      # round(12 * 1.7), round(18 * 1.7): grown with INTER_LINEAR
 
 
 def _scene():

@@ -72,8 +72,10 @@ def test_erosion_and_area_resize_restatements_agree_between_product_and_oracle()
 
 
 @pytest.mark.gpu
-def test_crop_kernel_pastes_the_voc_bank_like_the_oracle(golden):
-    """epi_crop_patches_occluded with the bank read from the VOC tree against the oracle's occlude_with_objects on the same draws (uint8 stage: bytes exact)."""
+@pytest.mark.parametrize("patch", [256, 384])
+def test_crop_kernel_pastes_the_voc_bank_like_the_oracle(golden, patch):
+    """epi_crop_patches_occluded with the bank read from the VOC tree against the oracle's occlude_with_objects on the same draws (uint8 stage: bytes exact).
+    256 px: every occluder is shrunk (INTER_AREA); 384 px (configs[4]): im_scale_factor 1.5, so four draws in ten GROW it (INTER_LINEAR, augmentation.py:122)."""
     import torch
     from epipolarpose_amd import hip
     from epipolarpose_amd.utils import augmentation as aug
@@ -83,7 +85,7 @@ def test_crop_kernel_pastes_the_voc_bank_like_the_oracle(golden):
     bank = aug.OccluderBank(occluders, dev)
     assert bank.count == 3 and bank.hw_host.tolist() == [[40, 46], [26, 56], [38, 52]]
     rng = np.random.default_rng(11)
-    n, size, patch = 6, 300, 256
+    n, size = 8, patch + 44
     frames = rng.integers(0, 256, (n, size, size, 3)).astype(np.uint8)
     buf = torch.from_numpy(frames.reshape(-1)).to(dev)
     offs = torch.arange(n, dtype=torch.int64, device=dev) * (size * size * 3)
@@ -97,6 +99,9 @@ def test_crop_kernel_pastes_the_voc_bank_like_the_oracle(golden):
         trans.append(t)
     assert ((place[:, :, 0] >= 0).sum(axis=1) >= 1).all()
     assert set(place[:, :, 0][place[:, :, 0] >= 0].tolist()) == {0, 1, 2}                                          # every occluder of the tree is used
+    used = place[place[:, :, 0] >= 0]
+    grown = (used[:, 1] > bank.hw_host[used[:, 0], 1]) | (used[:, 2] > bank.hw_host[used[:, 0], 0])
+    assert grown.any() == (patch > 256) and (~grown).any()
     raw = hip.crop_patches(buf, offs, hw, torch.from_numpy(np.stack(trans)).to(dev), patch, patch, occluders=bank.tensors(),
                            placements=torch.from_numpy(place).to(dev)).cpu().numpy()
     for i in range(n):
