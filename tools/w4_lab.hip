@@ -35,6 +35,7 @@ enum {
     F_BUF = 2048,       // (w4) buffer_load ... lds with an SGPR piece offset and a 32-bit lane offset instead of global_load_lds with a 64-bit lane address
     F_SWZ4 = 4096,      // (w4, feed experiment, WRONG results) source-side swizzle restricted to bit 2: whole quads of lanes swap, the order inside a quad ascends
     F_SWZ0 = 8192,      // (w4, feed experiment, WRONG results) no source-side swizzle: every lane group of 8 reads its row in ascending address order
+    F_ROWMAP = 16384,   // (w4) piece ps of wave w stages rows ps*32 + w*8 .. +7 (the four waves' pieces of one index form one 32-row block) instead of w*64 + ps*8 .. +7
     F_CLOCK = 128,      // wave 0 of every workgroup: s_memtime (shader clock) and s_memrealtime (100 MHz) across the K loop -> cycles per K tile and the clock the loop ran at
 };
 
@@ -88,9 +89,17 @@ __global__ __launch_bounds__(256) void w4_kernel(const unsigned short* __restric
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0x7fffffff, 0x00027000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bt), 0, 0x7fffffff, 0x00027000);
     const int a_s = (m0 + wid * 64) * ld * 2, b_s = (n0 + wid * 64) * ld * 2;          // (bytes; this laboratory's matrices stay below 2 GB)
+    const unsigned short* a_r = A + (long long)(m0 + wid * 8) * ld;
+    const unsigned short* b_r = Bt + (long long)(n0 + wid * 8) * ld;
     auto issue_piece = [&](int q, int buf, int k_run) {
         const bool is_b = q >= 8;
         const int ps = q & 7;
+        if (F & F_ROWMAP) {
+            char* dst = smem + buf * STAGE + (is_b ? A_BYTES : 0) + ps * 4096 + wid * 1024;
+            const unsigned short* src = (is_b ? b_r : a_r) + (long long)(ps * 32) * ld + k_run;
+            glds16(src + voff[wid & 1], dst);
+            return;
+        }
         char* dst = smem + buf * STAGE + (is_b ? A_BYTES : 0) + wid * 8192 + ps * 1024;
         if (F & F_BUF) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rs_b : rs_a, (__attribute__((address_space(3))) void*)dst, 16, voff[ps & 1] * 2,
@@ -666,6 +675,10 @@ int main(int argc, char** argv) {
 #define RUN(F, P3, P0, P1, P2, BP) run_variant<(F), P3, P0, P1, P2, BP>(#F " P " #P3 " " #P0 " " #P1 " " #P2 " bar " #BP, A, B, C, M, N, K, ref, err, sum, reps)
         for (int rep = 0; rep < 3; ++rep) {
             RUN(F_CLOCK | F_GM4, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_ROWMAP, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_ROWMAP, 8, 8, 0, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_ROWMAP | F_NOMFMA, 6, 6, 4, 0, 4);
+            RUN(F_CLOCK | F_GM4 | F_ROWMAP | F_NOMFMA | F_NOREAD, 6, 6, 4, 0, 4);
             RUN(F_CLOCK | F_GM4, 12, 4, 0, 0, 4);
             RUN(F_CLOCK | F_GM4, 8, 8, 0, 0, 4);
             RUN(F_CLOCK | F_GM4, 8, 8, 0, 0, 0);
