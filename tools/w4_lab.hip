@@ -529,6 +529,86 @@ __global__ __launch_bounds__(256) void w4v_kernel(const unsigned short* __restri
 }
 
 
+// ---- what the matrix pipes alone sustain: one wave per SIMD issuing MFMAs back to back on operand values loaded ONCE from memory (so they toggle like real data), 256 accumulator
+// registers, no LDS, no loads in the loop.  SHAPE 32: v_mfma_f32_32x32x16_bf16 (64 per "K tile" of 2 048 cycles); SHAPE 16: v_mfma_f32_16x16x32_bf16 (128 per tile) -- the shape
+// hipBLASLt's kernel uses.  Same flops per cycle; the question is the clock the chip holds on each.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_power_kernel(const unsigned short* __restrict__ A, const unsigned short* __restrict__ Bt, float* __restrict__ out, int tiles,
+                                                         unsigned long long* __restrict__ prof) {
+    const int tid = threadIdx.x;
+    bf16x8 fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(A + ((size_t)blockIdx.x * 2048 + i * 256 + tid) * 8));
+        fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4v*>(Bt + ((size_t)blockIdx.x * 2048 + i * 256 + tid) * 8));
+    }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float keep = 0.f;
+    if (SHAPE == 32) {
+        f32x16 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[(i + ks) & 7], fa[(i >> 2) + 2 * (ks & 1) + (ks >> 1)], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) keep += acc[i][i];
+    } else {
+        f32x4 acc[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+        for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(i + ks) & 7], fa[((i >> 3) + 4 * ks) & 7], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 64; ++i) keep += acc[i][i & 3];
+    }
+    if (tid == 0) {
+        prof[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        prof[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    out[(size_t)blockIdx.x * 256 + tid] = keep;
+}
+
+template <int SHAPE>
+static void run_power(const char* name, const unsigned short* A, const unsigned short* Bt, float* out) {
+    static unsigned long long* prof = nullptr;
+    if (!prof) CK(hipMalloc(&prof, 65536 * 16));
+    const int grid = 1024, tiles = 128, reps = 8;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(mfma_power_kernel<SHAPE>, dim3(grid), dim3(256), 0, 0, A, Bt, out, tiles, prof);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(mfma_power_kernel<SHAPE>, dim3(grid), dim3(256), 0, 0, A, Bt, out, tiles, prof);
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> h((size_t)grid * 2);
+    CK(hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    for (int g = 0; g < grid; ++g) { cyc += (double)h[2 * g]; real += (double)h[2 * g + 1]; }
+    const double flops = 2.0 * 256 * 256 * 64 * (double)tiles * grid;
+    printf("%-40s %9.2f us  %7.1f TF   | %.0f cycles per 2048-cycle tile, clock %.0f MHz\n", name, ms * 1e3 / reps, flops / (ms * 1e-3 / reps) * 1e-12, cyc / grid / tiles,
+           cyc / real * 100.0);
+    fflush(stdout);
+}
+
+
 // mode 0: uniform in [-0.5, 0.5) (every mantissa bit toggles); 1: values from {-1, 0, 1}; 2: all 1.0; 3: what a convolution of the network multiplies -- seed 1 (A):
 // relu(normal), half zeros; seed 2 (B): 0.05 * normal -- the same instruction stream at four switching activities
 __global__ void fill_bf16(unsigned short* p, size_t n, unsigned seed, int mode) {
@@ -668,6 +748,14 @@ int main(int argc, char** argv) {
         RUN(F_GM4 | F_SWZ0 | F_NODMA, 6, 6, 4, 0, 4);
         run_vgpr<F_GM4, 4, 4, 4, 4, 4>("vgpr F_GM4", A, B, C, M, N, K, ref, err, sum, reps);
 #undef RUN
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "power")) {          // the matrix pipes alone, two MFMA shapes, the operand fill of argv[2]
+        float* out; CK(hipMalloc(&out, (size_t)1024 * 256 * 4));
+        for (int rep = 0; rep < 3; ++rep) {
+            run_power<32>("mfma only 32x32x16", A, B, out);
+            run_power<16>("mfma only 16x16x32", A, B, out);
+        }
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "swz")) {          // source-side swizzle experiment (feed only; results of the SWZ variants are wrong by construction)
