@@ -62,10 +62,17 @@ def test_eight_ranks_on_one_device_bucketed_path(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_same_device_worker.py"), "--out", out, "--layers", "18",
            "--image", "64", "--batch", "4"]
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    for attempt in range(2):
+        # (nine processes rendezvous over loopback; once in ~20 runs of the suite the launch itself failed -- one relaunch on a fresh port, output kept)
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        if res.returncode == 0:
+            break
+        with open(os.path.join(ROOT, "gpurun_out", "eight_ranks_launch_failure_%d.txt" % attempt), "w") as f:
+            f.write(res.stdout[-20000:] + "\n==== stderr ====\n" + res.stderr[-20000:])
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     reps = [json.load(open(out + ".rank%d" % r)) for r in range(8)]
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "eight_ranks_one_device_r18.json"), "w") as f:
         json.dump(reps, f, indent=1)
     assert all(r["params_identical_across_ranks"] for r in reps)
@@ -117,26 +124,49 @@ def test_stock_ddp_wrapper_sees_finished_gradients():
         torch.cuda.synchronize()
         return {k.replace("module.", ""): p.grad.detach().float().clone() for k, p in m.named_parameters()}
 
-    plain_a, plain_b = grads(copy.deepcopy(base)), grads(copy.deepcopy(base))
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
-    try:
-        ddp = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
-        grads(ddp)                       # (the first pass builds the reducer's bucket order)
-        wrapped = grads(ddp)
-    finally:
-        if created:
-            dist.destroy_process_group()
-    assert set(wrapped) == set(plain_a)
+    from epipolarpose_amd import hip
 
     def cos(a, b):
         a, b = a.reshape(-1).double(), b.reshape(-1).double()
         return float(a @ b / (a.norm() * b.norm() + 1e-300))
+
+    plain_a, plain_b = grads(copy.deepcopy(base)), grads(copy.deepcopy(base))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    det_before = hip.set_deterministic(False)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
+        grads(ddp)                       # (the first pass builds the reducer's bucket order)
+        wrapped_runs = [grads(ddp) for _ in range(3)]
+        # the same under the library's deterministic mode (ordered sums): plain runs repeat bit for bit there, so a DDP-wrapped run must repeat too --
+        # a gradient copied while its kernel or its slab sum was still running cannot (tools/debug_ddp_flake.py: 150 of 150 runs identical)
+        hip.set_deterministic(True)
+        det_plain = grads(copy.deepcopy(base))
+        assert all(torch.equal(det_plain[k], v) for k, v in grads(copy.deepcopy(base)).items())
+        ddp_det = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
+        grads(ddp_det)
+        det_first = grads(ddp_det)
+        for _ in range(4):
+            again = grads(ddp_det)
+            differ = [k for k in det_first if not torch.equal(again[k], det_first[k])]
+            assert not differ, differ[:5]
+        # (the wrapped network reduces every weight gradient at once on the main stream, the plain one in grouped launches: another summation order)
+        det_worst = min((cos(det_first[k], det_plain[k]), k) for k in det_plain)
+        assert det_worst[0] >= 0.9999, det_worst
+    finally:
+        hip.set_deterministic(bool(det_before))
+        if created:
+            dist.destroy_process_group()
+    assert set(wrapped_runs[0]) == set(plain_a)
     noise = min(cos(plain_a[k], plain_b[k]) for k in plain_a)
-    worst = min((cos(wrapped[k], plain_a[k]), k) for k in plain_a)
-    # a gradient copied before its kernel (or its slab sum) had finished is garbage or half a sum: cosine far below the run-to-run level
-    assert worst[0] >= min(0.99, noise - 0.02), (worst, noise)
-    for k in plain_a:
-        ratio = float(wrapped[k].norm() / (plain_a[k].norm() + 1e-30))
-        assert 0.9 <= ratio <= 1.1, (k, ratio)
+    # With atomics, two runs of the SAME code differ (this network: min cosine 0.994 .. 0.997 over 150 runs, and once in a few hundred a bf16 rounding
+    # flip in an early layer moves a layer-4 gradient to 0.95: DESIGN section 5, "ill-conditioning").  A gradient copied before its kernel (or its slab sum)
+    # had finished is garbage or half a sum in EVERY run: the median run must clear the bar, every run a loose one.
+    worst = sorted(min((cos(w[k], plain_a[k]), k) for k in plain_a) for w in wrapped_runs)
+    assert worst[1][0] >= min(0.99, noise - 0.02), (worst, noise)
+    assert worst[0][0] >= 0.8, (worst, noise)
+    for wrapped in wrapped_runs:
+        for k in plain_a:
+            ratio = float(wrapped[k].norm() / (plain_a[k].norm() + 1e-30))
+            assert 0.85 <= ratio <= 1.15, (k, ratio)
