@@ -15,9 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+# Collection order of the GPU suite: parity against the oracle / the live-reference goldens first (the rows of SURVEY section 8a in the order of the
+# hot path: criterion, self-supervision, head, network, evaluation, data pipeline, refiner), then the fp32 torch comparisons of the convolution
+# kernels, then the structural checks of the package against itself (deterministic reruns, update-in-backward, the multi-process choreography).
+# Under the driver's `-x` a structural failure can then no longer blank the parity record.
+_ORDER = ["test_hip_integral", "test_hip_selfsup", "test_hip_head", "test_hip_network", "test_hip_eval", "test_hip_pipeline", "test_imgproc",
+          "test_voc_occluders", "test_h36m_files", "test_refiner", "test_hip_train_loop", "test_hip_conv", "test_hip_precise",
+          "test_hip_deterministic", "test_hip_step_in_backward", "test_hip_distributed"]
+
+
 def pytest_collection_modifyitems(config, items):
-    """GPU tests fail loudly (never skip silently) when selected on a box without a GPU or the extension."""
-    return
+    """Stable sort by the file order above (files not listed keep their alphabetical place in front of the structural group)."""
+    def rank(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _ORDER.index(name) if name in _ORDER else _ORDER.index("test_hip_conv") - 0.5
+    items.sort(key=rank)
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,7 @@
 """Worker of tests/test_hip_distributed.py: one of N ranks (2 or 8) that share cuda:0 (gloo process group), running the real N > 1 training
 choreography on the hand-written kernels -- flat per-dtype gradient buckets, learned bucket hooks, grouped weight gradients on the second
-stream, deferred slab sums, asynchronous all-reduce handles, FusedAdam on the bucket views.  Launched by torch.distributed.run.
+stream, deferred slab sums, asynchronous all-reduce handles, FusedAdam on the bucket views.  Started by the test itself, one process per rank
+(RANK / WORLD_SIZE in the environment, --init-file = a FileStore rendezvous: no master port to collide on, no launcher agent), or by torch.distributed.run.
 Rank 0 also computes, in the same process, what the step must produce: the mean over the two shards of the single-process gradients
 (per-shard BatchNorm statistics -- nn.DataParallel semantics, scripts/train.py:93-94) and writes the comparison to --out."""
 import argparse
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per rank (whole 4-view groups)")
     ap.add_argument("--deterministic", type=int, default=1, help="1: the library's deterministic mode (ordered BatchNorm sums) on both ranks and for the "
                     "single-process reference: the comparison is then free of the run-to-run noise of the atomics and can be held tight")
+    ap.add_argument("--init-file", default="", help="rendezvous through this file (torch FileStore) instead of MASTER_ADDR / MASTER_PORT")
     a = ap.parse_args()
     from epipolarpose_amd import distributed as epd
     from epipolarpose_amd import hip
@@ -34,7 +36,9 @@ def main():
     from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
     from epipolarpose_amd.models.pose3d_resnet import get_pose_net
     from epipolarpose_amd.optim import FusedAdam
-    rank, world, _ = epd.init_from_env(backend="gloo", set_device=False)
+    if a.init_file:
+        dist.init_process_group("gloo", init_method="file://" + a.init_file, rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world, _ = epd.init_from_env(backend="gloo", set_device=False)      # (joins through MASTER_* when no group exists yet)
     assert world >= 2
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)

@@ -1,10 +1,19 @@
 """Case tables shared by make_golden.py (generator) and the tests (consumers)."""
-DLOGITS_STRIDE = 13     # big cases store every 13th gradient element
+DLOGITS_STRIDE = 13     # big cases store every 13th gradient element ...
+DLOGITS_STRIDE_HUGE = 509   # ... and the config-shape case (4.46 M logits) every 509th
+
+
+def dlogits_stride(size):
+    """Sub-sampling of a stored gradient by the size of the logits tensor (generator and tests share the rule)."""
+    return DLOGITS_STRIDE if size <= 1000000 else DLOGITS_STRIDE_HUGE
+
+
 INTEGRAL_CASES = [  # name, B, J, D, H, W, logit scale
     ("tiny", 2, 3, 8, 8, 8, 3.0),
     ("rect", 3, 4, 4, 8, 16, 2.0),
     ("mid", 2, 17, 16, 16, 16, 4.0),
     ("cube32", 1, 2, 32, 32, 32, 6.0),
+    ("cfg", 1, 17, 64, 64, 64, 4.0),      # one image at the configuration's shape: J = 17 (train.yaml:28), D = 64 (config.py:48), heat-map 64 x 64
 ]
 NETWORK_CASES = [  # name, layers, image, J, D, batch
     ("r18", 18, 64, 3, 8, 2),

@@ -5,7 +5,6 @@ loss normalisation lib/core/integral_loss.py:29,45).  The synchronised gradients
 shards of single-process gradients; the parameters must be bit-identical on both ranks after three steps."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -15,12 +14,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+def _run_ranks(world, tmp_path, worker_args, timeout, extra_env=None):
+    """One process per rank started directly (RANK / WORLD_SIZE / LOCAL_RANK in the environment), rendezvous through a FileStore in tmp_path: no master
+    port that another socket could take between choosing and binding it, no launcher agent process.  -> (return codes, tail of every rank's output)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", WORLD_SIZE=str(world), **(extra_env or {}))
+    store = str(tmp_path / "rendezvous")
+    procs, logs = [], []
+    for rank in range(world):
+        log = open(str(tmp_path / ("rank%d.log" % rank)), "w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_same_device_worker.py"), "--init-file", store] + worker_args,
+                                      env=dict(env, RANK=str(rank), LOCAL_RANK=str(rank)), cwd=ROOT, stdout=log, stderr=subprocess.STDOUT))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait(timeout=timeout))
+    finally:
+        for p in procs:                         # (a rank that died leaves the others in a collective: end exactly the processes started here)
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    tails = []
+    for rank, log in enumerate(logs):
+        log.seek(0)
+        tails.append("---- rank %d ----\n%s" % (rank, log.read()[-2500:]))
+        log.close()
+    return codes, "\n".join(tails)
 
 
 FLOORS = {18: (0.999, 0.9999), 50: (0.999, 0.9999)}     # (min, median) cosine over all parameters; measured 0.999996 / 1.0 for both (call r04f)
@@ -29,12 +48,8 @@ FLOORS = {18: (0.999, 0.9999), 50: (0.999, 0.9999)}     # (min, median) cosine o
 @pytest.mark.parametrize("layers", [18, 50])
 def test_two_ranks_on_one_device_bucketed_path(tmp_path, layers):
     out = str(tmp_path / "report.json")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_same_device_worker.py"), "--out", out, "--layers", str(layers),
-           "--image", "64" if layers == 18 else "128"]
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    codes, tail = _run_ranks(2, tmp_path, ["--out", out, "--layers", str(layers), "--image", "64" if layers == 18 else "128"], timeout=600)
+    assert codes == [0, 0], tail
     r0, r1 = (json.load(open(out + ".rank%d" % r)) for r in range(2))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "two_ranks_one_device_r%d.json" % layers), "w") as f:
@@ -58,20 +73,9 @@ def test_eight_ranks_on_one_device_bucketed_path(tmp_path):
     carries the collectives): parameters bit-identical on all eight ranks after three steps, the synchronised gradients of step 1 = the mean over the eight
     shards of single-process gradients."""
     out = str(tmp_path / "report.json")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_same_device_worker.py"), "--out", out, "--layers", "18",
-           "--image", "64", "--batch", "4"]
+    codes, tail = _run_ranks(8, tmp_path, ["--out", out, "--layers", "18", "--image", "64", "--batch", "4"], timeout=900, extra_env={"OMP_NUM_THREADS": "1"})
+    assert codes == [0] * 8, tail
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for attempt in range(2):
-        # (nine processes rendezvous over loopback; once in ~20 runs of the suite the launch itself failed -- one relaunch on a fresh port, output kept)
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-        if res.returncode == 0:
-            break
-        with open(os.path.join(ROOT, "gpurun_out", "eight_ranks_launch_failure_%d.txt" % attempt), "w") as f:
-            f.write(res.stdout[-20000:] + "\n==== stderr ====\n" + res.stderr[-20000:])
-    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     reps = [json.load(open(out + ".rank%d" % r)) for r in range(8)]
     with open(os.path.join(ROOT, "gpurun_out", "eight_ranks_one_device_r18.json"), "w") as f:
         json.dump(reps, f, indent=1)
@@ -84,7 +88,7 @@ def test_eight_ranks_on_one_device_bucketed_path(tmp_path):
     assert all(l == l and l < 10 for r in reps for l in r["losses"])
 
 
-def test_stock_ddp_wrapper_sees_finished_gradients():
+def test_stock_ddp_wrapper_sees_finished_gradients(tmp_path):
     """torch's DistributedDataParallel registers its reducer as a post-hook of every AccumulateGrad node and copies the gradient
     into its buckets INSIDE the backward pass.  A weight gradient that is still in flight on the second stream (or unreduced in slabs) at that moment would
     be copied half-written.  The glue looks at acc->post_hooks() (gradient_consumed_after_backward) and keeps such gradients on the main stream with an
@@ -130,23 +134,21 @@ def test_stock_ddp_wrapper_sees_finished_gradients():
         a, b = a.reshape(-1).double(), b.reshape(-1).double()
         return float(a @ b / (a.norm() * b.norm() + 1e-300))
 
-    plain_a, plain_b = grads(copy.deepcopy(base)), grads(copy.deepcopy(base))
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
-    det_before = hip.set_deterministic(False)
+        dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "rendezvous"), rank=0, world_size=1)
+    # Judged in the library's deterministic mode only (ordered sums): plain runs repeat bit for bit there, so a DDP-wrapped run must repeat too -- a
+    # gradient copied while its kernel or its slab sum was still running is garbage or half a sum and cannot (tools/debug_ddp_flake.py: 150 of 150 runs
+    # identical).  (Rounds 2-5 also compared the atomics mode against a plain run of itself; that arm measured the run-to-run noise of the atomics, not the
+    # wrapper, and is gone.)
+    det_before = hip.set_deterministic(True)
     try:
-        ddp = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
-        grads(ddp)                       # (the first pass builds the reducer's bucket order)
-        wrapped_runs = [grads(ddp) for _ in range(3)]
-        # the same under the library's deterministic mode (ordered sums): plain runs repeat bit for bit there, so a DDP-wrapped run must repeat too --
-        # a gradient copied while its kernel or its slab sum was still running cannot (tools/debug_ddp_flake.py: 150 of 150 runs identical)
-        hip.set_deterministic(True)
         det_plain = grads(copy.deepcopy(base))
         assert all(torch.equal(det_plain[k], v) for k, v in grads(copy.deepcopy(base)).items())
         ddp_det = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(base), device_ids=[0], bucket_cap_mb=4)
-        grads(ddp_det)
+        grads(ddp_det)                   # (the first pass builds the reducer's bucket order)
         det_first = grads(ddp_det)
+        assert set(det_first) == set(det_plain)
         for _ in range(4):
             again = grads(ddp_det)
             differ = [k for k in det_first if not torch.equal(again[k], det_first[k])]
@@ -154,19 +156,10 @@ def test_stock_ddp_wrapper_sees_finished_gradients():
         # (the wrapped network reduces every weight gradient at once on the main stream, the plain one in grouped launches: another summation order)
         det_worst = min((cos(det_first[k], det_plain[k]), k) for k in det_plain)
         assert det_worst[0] >= 0.9999, det_worst
+        for k in det_plain:
+            ratio = float(det_first[k].norm() / (det_plain[k].norm() + 1e-30))
+            assert 0.99 <= ratio <= 1.01, (k, ratio)
     finally:
         hip.set_deterministic(bool(det_before))
         if created:
             dist.destroy_process_group()
-    assert set(wrapped_runs[0]) == set(plain_a)
-    noise = min(cos(plain_a[k], plain_b[k]) for k in plain_a)
-    # With atomics, two runs of the SAME code differ (this network: min cosine 0.994 .. 0.997 over 150 runs, and once in a few hundred a bf16 rounding
-    # flip in an early layer moves a layer-4 gradient to 0.95: DESIGN section 5, "ill-conditioning").  A gradient copied before its kernel (or its slab sum)
-    # had finished is garbage or half a sum in EVERY run: the median run must clear the bar, every run a loose one.
-    worst = sorted(min((cos(w[k], plain_a[k]), k) for k in plain_a) for w in wrapped_runs)
-    assert worst[1][0] >= min(0.99, noise - 0.02), (worst, noise)
-    assert worst[0][0] >= 0.8, (worst, noise)
-    for wrapped in wrapped_runs:
-        for k in plain_a:
-            ratio = float(wrapped[k].norm() / (plain_a[k].norm() + 1e-30))
-            assert 0.85 <= ratio <= 1.15, (k, ratio)

@@ -6,6 +6,22 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+REPORT = {}
+
+
+@pytest.fixture(autouse=True)
+def deterministic_sums():
+    """Every test of this file runs in the library's deterministic mode (ordered BatchNorm sums, hip.set_deterministic): two runs of the same code are then
+    bit-identical, so the comparisons below need no run-to-run yardstick (rounds 2-5 judged them against the noise of the fp32 atomics)."""
+    import json
+    import os
+    from epipolarpose_amd import hip
+    was = hip.set_deterministic(True)
+    yield
+    hip.set_deterministic(was)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "step_in_backward.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
 
 
 def _train(model, data, steps, early, boundary=None, late=None):
@@ -75,7 +91,7 @@ def test_step_in_backward_is_bit_identical_on_a_deterministic_network():
 def test_step_in_backward_on_the_pose_network():
     """PoseResNet-18 on the hand-written kernels (bf16 training copies, packed backward operands, deferred slab sums, weight gradients
     on the second stream): three steps with the update of layers 2-4 + head inside the backward pass against three plain steps.
-    BatchNorm sums by atomics make two runs of the SAME code differ slightly, so the yardstick is that run-to-run difference."""
+    Deterministic mode: two plain runs are bit-identical, and the early update is the same arithmetic on the same gradients -- bit-identical too."""
     base, data = _conditioned_pose_net(seed=1)
 
     def run(early):
@@ -92,20 +108,18 @@ def test_step_in_backward_on_the_pose_network():
     a, _ = run(False)
     a2, _ = run(False)
     b, mb = run(True)
-    # Summed absolute differences over each PART of the network (the late part: stem + layer1, the early part: everything else): Adam moves
-    # every element by ~lr per step whatever its gradient, so single elements whose tiny gradient changes sign between two runs differ by
-    # up to 2 * steps * lr -- per-parameter maxima (and means over a 64-element BatchNorm weight) would measure that; a part that was NOT
-    # updated, or updated twice, differs by the whole step in (almost) every element
     _, late_modules = base.step_in_backward_split()
     late_names = {n for n, p_ in base.named_parameters() if any(p_ is q for m_ in late_modules for q in m_.parameters())}
     start = {k: v.detach().float() for k, v in base.named_parameters()}
+    assert all(torch.equal(a[k], a2[k]) for k in a)                      # the plain path repeats itself
     for part in ("late", "early"):
         keys = [k for k in a if (k in late_names) == (part == "late")]
         assert keys
         diff = sum(float((a[k] - b[k]).abs().sum()) for k in keys)
-        noise = sum(float((a[k] - a2[k]).abs().sum()) for k in keys)
         step = sum(float((a[k] - start[k]).abs().sum()) for k in keys)
-        assert step > 0 and diff <= 3.0 * noise + 0.1 * step, (part, diff, noise, step)
+        REPORT["pose_network/" + part] = {"diff": diff, "step": step, "not_identical": [k for k in keys if not torch.equal(a[k], b[k])][:8]}
+        # a part that was NOT updated, or updated twice, differs by the whole step in (almost) every element
+        assert step > 0 and diff == 0.0, (part, diff, step, REPORT["pose_network/" + part]["not_identical"])
     for k in a:
         assert float((b[k] - start[k]).abs().max()) > 0 or float((a[k] - start[k]).abs().max()) == 0, k
     # the bf16 training copies follow their masters
@@ -114,11 +128,18 @@ def test_step_in_backward_on_the_pose_network():
             assert torch.equal(mod.weight_lp.detach(), mod.weight.detach().to(torch.bfloat16)), type(mod)
 
 
+# Deterministic mode: the figure is the same in every run of one build (measured 0.0094 of the four-step update, call r06a).  It is not zero because the
+# bucket path keeps the gradients of the bf16 training copies in a bf16 bucket (one more rounding before Adam, which moves an element by ~lr whatever the
+# size of its gradient); a bucket that left before its gradient was final, or a part updated twice, is the whole step.
+BUCKETED_BAR = 0.03
+
+
 def test_bucketed_grad_sync_with_second_stream_and_deferred_sums():
     """The N > 1 gradient path on one GPU (world size 1: buckets, hooks, flat gradient views -- no collective): from the second step on
     only the last gradient of each bucket keeps its hook, every other weight gradient runs on the second stream with deferred slab sums,
     and the hook must see finished gradients (it joins the stream and sums the slabs first).  Four steps with the bucket path against
-    four plain steps, same yardstick as above (summed differences against the run-to-run difference)."""
+    four plain steps in deterministic mode: the plain path repeats itself bit for bit; the bucket path sums the same weight-gradient slabs at another moment
+    (at the bucket's hook instead of after the pass) and holds part of the gradients in bf16 (BUCKETED_BAR)."""
     from epipolarpose_amd.core.function import train_step
     from epipolarpose_amd.core.integral_loss import SmoothL1JointLocationLoss
     from epipolarpose_amd.distributed import BucketedGradSync
@@ -151,7 +172,8 @@ def test_bucketed_grad_sync_with_second_stream_and_deferred_sums():
         return {k: v.detach().float().clone() for k, v in m.named_parameters()}
     a, a2, b = run(False), run(False), run(True)
     start = {k: v.detach().float() for k, v in base.named_parameters()}
+    assert all(torch.equal(a[k], a2[k]) for k in a)
     diff = sum(float((a[k] - b[k]).abs().sum()) for k in a)
-    noise = sum(float((a[k] - a2[k]).abs().sum()) for k in a)
     step = sum(float((a[k] - start[k]).abs().sum()) for k in a)
-    assert step > 0 and diff <= 3.0 * noise + 0.1 * step, (diff, noise, step)
+    REPORT["bucketed"] = {"diff": diff, "step": step, "not_identical": [k for k in a if not torch.equal(a[k], b[k])][:8]}
+    assert step > 0 and diff <= BUCKETED_BAR * step, (diff, step, REPORT["bucketed"]["not_identical"])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from det_weights import seeded_array
-from make_golden_cases import INTEGRAL_CASES, DLOGITS_STRIDE
+from make_golden_cases import INTEGRAL_CASES, dlogits_stride
 from oracle import geometry, inference, integral, triangulation
 
 
@@ -23,21 +23,31 @@ def test_softmax_integral_and_losses(golden, case):
     name, b, j, d, h, w, sc = case
     logits = case_logits(g, *case)
     xyz = integral.softmax_integral(logits, j, w, h, d)
-    np.testing.assert_allclose(xyz, g[name + "/xyz"], atol=2e-6)       # reference is fp32
+    # The pin proper: the reference's code run on float64 tensors (make_golden.py) -- the oracle restates that arithmetic to rounding.  The reference's
+    # float32 run is itself some way from it (2e-6 for the small cases, 1.8e-5 in the coordinates and 2.9e-4 of the largest gradient element at the
+    # configuration's shape "cfg": fp32 sums over 262 144 voxels): the oracle is held to the float32 run by that distance plus a margin.
+    np.testing.assert_allclose(xyz, g[name + "/xyz64"], atol=1e-12)
+    np.testing.assert_allclose(xyz, g[name + "/xyz"], atol=1.5 * np.abs(g[name + "/xyz"] - g[name + "/xyz64"]).max() + 2e-6)       # reference is fp32
     for kind in integral.LOSS_KINDS:
         for norm in (False, True):
             key = "%s/%s/norm%d" % (name, kind, int(norm))
             loss, _ = integral.joint_location_loss(logits, g[name + "/gt"], g[name + "/wt"], j, kind, norm)
-            np.testing.assert_allclose(loss, g[key + "/loss"], rtol=2e-5, atol=1e-7)
             dl = integral.joint_location_loss_backward(logits, g[name + "/gt"], g[name + "/wt"], j, kind, norm)
             ref = g[key + "/dlogits"]
             if ref.ndim == 1:
-                dl = dl.reshape(-1)[::DLOGITS_STRIDE]
+                dl = dl.reshape(-1)[::dlogits_stride(dl.size)]
             scale = np.abs(ref).max()
-            np.testing.assert_allclose(dl, ref, atol=2e-5 * scale + 1e-8)   # (fp32 autograd noise floor)
+            own = 0.0                                       # the float32 reference's distance from its float64 run
+            if key + "/loss64" in g:
+                np.testing.assert_allclose(loss, g[key + "/loss64"], rtol=1e-11, atol=1e-14)
+                np.testing.assert_allclose(dl, g[key + "/dlogits64"], atol=1e-11 * scale + 1e-18)
+                own = np.abs(ref - g[key + "/dlogits64"]).max()
+            np.testing.assert_allclose(loss, g[key + "/loss"], rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(dl, ref, atol=1.5 * own + 2e-5 * scale + 1e-8)   # (fp32 autograd noise floor)
     if name + "/decode256" in g:
         dec = integral.get_joint_location_result(256, 256, logits)
-        np.testing.assert_allclose(dec, g[name + "/decode256"], atol=1e-3)   # fp32 coords * 256
+        own_xyz = float(np.abs(g[name + "/xyz"] - g[name + "/xyz64"]).max())
+        np.testing.assert_allclose(dec, g[name + "/decode256"], atol=256 * (1.5 * own_xyz + 4e-6))   # fp32 coords * 256
 
 
 def test_label_codec(golden):
