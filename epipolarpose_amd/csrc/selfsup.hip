@@ -615,12 +615,25 @@ EPI_HD __forceinline__ int tri_ls_ne(const TI (&uu)[NV][2], const TI (&PP)[NV][1
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (v < nv) {
-            const double p8 = (double)PP[v][8], p9 = (double)PP[v][9], p10 = (double)PP[v][10], p11 = (double)PP[v][11];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const double uq = (double)uu[v][q];
-                const double a0 = uq * p8 - (double)PP[v][4 * q], a1 = uq * p9 - (double)PP[v][4 * q + 1], a2 = uq * p10 - (double)PP[v][4 * q + 2];
-                const double b = (double)PP[v][4 * q + 3] - uq * p11;                                         // triangulation.py:138-148
+                double a0, a1, a2, b;
+                if constexpr (std::is_same<TI, float>::value) {
+                    // float32 storage (round 6): the rows themselves in float32 with ONE rounding each (fma) -- a perturbation of a row by 2^-24 of its size,
+                    // i.e. by less than the storage rounding of the key point it is built from (measured against float64 rows on 4 352 noisy 4-view joints:
+                    // 7e-5 mm) -- and only the sums of their products, where cond(A)^2 bites, in float64 (a product of two floats is exact there).
+                    // 32 conversions and 72 float64 FMAs per item instead of 56 and 104.
+                    const float uq = uu[v][q];
+                    a0 = (double)fmaf(uq, PP[v][8], -PP[v][4 * q]);
+                    a1 = (double)fmaf(uq, PP[v][9], -PP[v][4 * q + 1]);
+                    a2 = (double)fmaf(uq, PP[v][10], -PP[v][4 * q + 2]);
+                    b = (double)fmaf(-uq, PP[v][11], PP[v][4 * q + 3]);                                        // triangulation.py:138-148
+                } else {
+                    const double uq = (double)uu[v][q];
+                    a0 = uq * (double)PP[v][8] - (double)PP[v][4 * q]; a1 = uq * (double)PP[v][9] - (double)PP[v][4 * q + 1];
+                    a2 = uq * (double)PP[v][10] - (double)PP[v][4 * q + 2];
+                    b = (double)PP[v][4 * q + 3] - uq * (double)PP[v][11];                                     // triangulation.py:138-148
+                }
                 n[0] = fma(a0, a0, n[0]); n[1] = fma(a0, a1, n[1]); n[2] = fma(a0, a2, n[2]);
                 n[3] = fma(a1, a1, n[3]); n[4] = fma(a1, a2, n[4]); n[5] = fma(a2, a2, n[5]);
                 r[0] = fma(a0, b, r[0]); r[1] = fma(a1, b, r[1]); r[2] = fma(a2, b, r[2]);
@@ -772,7 +785,10 @@ EPI_HD __forceinline__ int tri_dlt_gram(const TI (&u)[NV][2], const TI (&P)[NV][
             for (int r = 0; r < 2; ++r) {
                 double m[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) m[c] = (double)u[v][r] * (double)P[v][8 + c] - (double)P[v][4 * r + c];   // cv2.triangulatePoints rows
+                for (int c = 0; c < 4; ++c) {                                                                         // cv2.triangulatePoints rows
+                    if constexpr (std::is_same<TI, float>::value) m[c] = (double)fmaf(u[v][r], P[v][8 + c], -P[v][4 * r + c]);   // (float32 storage: see tri_ls_ne)
+                    else m[c] = (double)u[v][r] * (double)P[v][8 + c] - (double)P[v][4 * r + c];
+                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -857,8 +873,11 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
                                                           int* __restrict__ status) {
     typedef typename TriCompute<S, METHOD>::type T;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)G * J) return;
-    const int g = (int)(t / J), j = (int)(t - (long long)g * J);
+    const long long total = (long long)G * J;
+    if (t >= total) return;
+    // (round 6: a 64-bit division per item was ~100 instructions of the ~600 a linear solve takes; item counts below 2^31 divide in 32 bits)
+    const int g = total < (1ll << 31) ? (int)((unsigned)t / (unsigned)J) : (int)(t / J), j = (int)(t - (long long)g * J);
+    const long long view_items = total;                                 // items of one view: sample s = v * G + g, img_utils.py:197-202
     // inputs stay in the storage type for the mixed-precision iterative solver (it converts at every use: 56 registers instead of 112)
     typedef typename std::conditional<std::is_same<S, float>::value && METHOD != TRI_POLY, float, T>::type TIN;
     TIN u[NV][2], P[NV][12];
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
     for (int v = 0; v < NV; ++v) {
         if (v < V) {
             const long long s = (long long)v * G + g;                  // img_utils.py:197-202
-            const S* kp = kps + (s * J + j) * kstride;
+            const S* kp = kps + (v * view_items + t) * kstride;         // == (s * J + j) * kstride
             const S* pp = Pm + s * 12;
             u[v][0] = (TIN)kp[0]; u[v][1] = (TIN)kp[1];
 #pragma unroll
@@ -920,13 +939,18 @@ void triangulate_staged_kernel(const S* __restrict__ kps, int kstride, const S* 
     const int g_lo = (int)(t0 / J), g_hi = (int)((t0 + n_items - 1) / J), ng = g_hi - g_lo + 1;
     constexpr int VEC = 16 / (int)sizeof(S);                                // elements per 16-byte access (12 is a multiple of it)
     const bool live = tid < n_items;
-    const int g = live ? (int)(t / J) : g_lo, j = live ? (int)(t - (long long)g * J) : 0;
+    // (group, joint) of this thread's item without a 64-bit division (round 6: ~100 of the ~600 instructions of a linear solve): the item is
+    // rel = r0 + tid past the first item of group g_lo, rel < 256 + J, and rel / J = (rel * ceil(2^16 / J)) >> 16 exactly while rel * J < 2^16
+    const int r0 = (int)(t0 - (long long)g_lo * J), rel = live ? r0 + tid : r0;
+    const int gl = (256 + J) * J < 65536 ? (int)(((unsigned)rel * (unsigned)((65536 + J - 1) / J)) >> 16) : rel / J;
+    const int g = g_lo + gl, j = rel - gl * J;
+    const long long t_item = live ? t : t0;
     // the key points first: their latency overlaps the staging of the projection matrices
     TIN u[NV][2], P[NV][12];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if (v < V) {
-            const S* kp = kps + (((long long)v * G + g) * J + j) * kstride;
+            const S* kp = kps + ((long long)v * total + t_item) * kstride;          // == (((long long)v * G + g) * J + j) * kstride
             if (kstride == 2) {
                 typedef S vec2 __attribute__((ext_vector_type(2)));
                 const vec2 q = *reinterpret_cast<const vec2*>(kp);
@@ -936,10 +960,11 @@ void triangulate_staged_kernel(const S* __restrict__ kps, int kstride, const S* 
     }
     {
         const int per_view = ng * 12 / VEC;                                 // 16-byte vectors per view block
-        for (int i = tid; i < V * per_view; i += 256) {
-            const int v = i / per_view, e = i - v * per_view;
-            const uint4v w = *reinterpret_cast<const uint4v*>(Pm + ((long long)v * G + g_lo) * 12 + (long long)e * VEC);
-            *reinterpret_cast<uint4v*>(Pl + ((size_t)v * ng_max * 12) + (size_t)e * VEC) = w;
+        // one wave per view (views 4 apart share a wave): no per-element division, 64 x 16 contiguous bytes per instruction
+        for (int v = tid >> 6; v < V; v += 4) {
+            const S* src = Pm + ((long long)v * G + g_lo) * 12;
+            S* dst = Pl + (size_t)v * ng_max * 12;
+            for (int e = tid & 63; e < per_view; e += 64) *reinterpret_cast<uint4v*>(dst + (size_t)e * VEC) = *reinterpret_cast<const uint4v*>(src + (size_t)e * VEC);
         }
     }
     __syncthreads();

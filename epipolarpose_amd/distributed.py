@@ -68,17 +68,24 @@ def broadcast_module(module, src=0, optimizer=None):
 
 class _DirectHandle:
     """One bucket of the "direct" collective in flight (BucketedGradSync._start_collective): wait() finishes the scatter phase and reduces this rank's
-    slice (fp32 sum in rank order -- the same result on every backend), start_gather() / wait_gather() send it to every peer and collect theirs."""
+    slice (fp32 sum in rank order -- the same result on every backend -- scaled by 1 / world BEFORE the one rounding back to the bucket's dtype),
+    start_gather() / wait_gather() send it to every peer and collect theirs."""
 
-    def __init__(self, flat, slices, recv, works, me, n):
-        self.flat, self.slices, self.recv, self.works, self.me, self.n = flat, slices, recv, works, me, n
+    def __init__(self, flat, slices, recv, acc, works, me, n):
+        self.flat, self.slices, self.recv, self.acc, self.works, self.me, self.n = flat, slices, recv, acc, works, me, n
         self.gather = []
 
     def wait(self):
         for w in self.works:
             w.wait()
-        self.recv[self.me].copy_(self.slices[self.me])
-        self.slices[self.me].copy_(self.recv.float().sum(0))
+        # slice by slice into ONE fp32 accumulator of slice size (1 / world of the bucket; round 5 materialised recv.float(): world x the slice in fp32 per
+        # bucket and step) -- add_ promotes the bf16 operand inside the kernel, no copy is made
+        acc = self.acc
+        acc.zero_()
+        for r in range(self.n):
+            acc.add_(self.slices[self.me] if r == self.me else self.recv[r])
+        acc.mul_(1.0 / self.n)
+        self.slices[self.me].copy_(acc)
 
     def start_gather(self):
         ops = []
@@ -125,6 +132,7 @@ class BucketedGradSync:
             # half the xGMI traffic); same parameter order as the optimizer's
             self.params = [copies.get(i, p) for i, p in enumerate(self.params)]
         self.buckets = []          # (flat tensor, [params], [views])
+        self._direct_bufs = {}     # id(flat) -> (receive buffer, fp32 slice accumulator) of the "direct" collective
         self._pending = {}
         self._handles = []
         # sum in the collective, scale afterwards (one small kernel per bucket): ReduceOp.AVG would save those kernels on
@@ -278,13 +286,17 @@ class BucketedGradSync:
         # direct, phase 1 (scatter): slice j of my bucket -> rank j; the slices of MY index arrive from everybody
         n, me = self.world, dist.get_rank()
         slices = flat.view(n, -1)
-        recv = torch.empty_like(slices)
+        # receive buffer (bucket size, bucket dtype) and the fp32 accumulator of this rank's slice: allocated once per bucket, reused every step
+        bufs = self._direct_bufs.get(id(flat))
+        if bufs is None:
+            bufs = self._direct_bufs[id(flat)] = (torch.empty_like(slices), torch.empty(slices.shape[1], dtype=torch.float32, device=flat.device))
+        recv, acc = bufs
         ops = []
         for peer in range(n):
             if peer != me:
                 ops.append(dist.P2POp(dist.isend, slices[peer], peer))
                 ops.append(dist.P2POp(dist.irecv, recv[peer], peer))
-        self._handles.append(_DirectHandle(flat, slices, recv, dist.batch_isend_irecv(ops), me, n))
+        self._handles.append(_DirectHandle(flat, slices, recv, acc, dist.batch_isend_irecv(ops), me, n))
 
     def _make_hook(self, bi):
         def hook(param):
@@ -343,7 +355,7 @@ class BucketedGradSync:
             if isinstance(h, _DirectHandle):
                 h.wait_gather()
         self._handles = []
-        if self.world > 1 and not self._avg:
+        if self.world > 1 and not self._avg and self.collective != "direct":      # (the direct form averaged in fp32 before its one rounding)
             inv = 1.0 / self.world
             for flat, _, _ in self.buckets:
                 flat.mul_(inv)

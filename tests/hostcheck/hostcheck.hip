@@ -76,6 +76,16 @@ extern "C" void hostcheck_triangulate2(int method, const double* u1, const doubl
         else if (method == 3) st = epi::tri_iterative_mixed<2, double>(u, P, 2, tol, max_iter, x);      // the bulk (fp32-storage) variants, fed float64 inputs here
         else if (method == 4) st = epi::tri_dlt_gram<2>(u, P, 2, x);
         else if (method == 6) st = epi::tri_ls_ne<2, double>(u, P, 2, x);                                  // round 5: the float32-storage LS (float64 normal equations)
+        else if (method == 7 || method == 8) {
+            // round 6: the float32-storage instantiations themselves (rows built in float32, sums of products in float64) on the inputs ROUNDED to float32,
+            // as the bulk kernels hold them
+            float uf[2][2], Pf[2][12];
+            for (int v = 0; v < 2; ++v) {
+                uf[v][0] = (float)u[v][0]; uf[v][1] = (float)u[v][1];
+                for (int k = 0; k < 12; ++k) Pf[v][k] = (float)P[v][k];
+            }
+            st = method == 7 ? epi::tri_ls_ne<2, float>(uf, Pf, 2, x) : epi::tri_dlt_gram<2, float>(uf, Pf, 2, x);
+        }
         else st = epi::tri_iterative_ne<2>(u, P, 2, tol, max_iter, x);
         X[3 * i] = x[0]; X[3 * i + 1] = x[1]; X[3 * i + 2] = x[2];
         status[i] = st;

@@ -388,10 +388,14 @@ def _make_unit_pair(kind):
 
 # rel-L2 of the bf16 unit against the fp32 torch unit, per tensor class (measured on MI355X in deterministic mode -- the same figures in every run --
 # tools/probe_unit_node.py -> profiles/r06_unit_node_probe.txt): a dropped shortcut gradient, a missing stage or a wrong statistic is O(1).
-# The BatchNorm parameter gradients are sums over 256 .. 1024 positions of terms of either sign that bf16 activations round one by one
-# (measured up to 0.094 on bn2.bias); outputs, input gradients, weight gradients and running estimates stay below 0.03.
+#   output 0.003-0.005 | running estimates <= 0.002 | input gradient 0.044-0.065 | convolution weight gradients 0.042-0.072 |
+#   BatchNorm parameter gradients 0.020-0.094 (sums over 256 .. 1024 positions of terms of either sign that bf16 activations round one by one)
 def _unit_oracle_bar(key):
-    return 0.15 if key.startswith("grad:") and ("bn" in key or "downsample.1" in key) else 0.05
+    if key == "y":
+        return 0.02
+    if key.startswith("stat:"):
+        return 0.01
+    return 0.15 if ("bn" in key or "downsample.1" in key) else 0.12
 
 
 @pytest.mark.parametrize("kind", list(_UNIT_KINDS))

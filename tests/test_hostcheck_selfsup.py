@@ -58,7 +58,7 @@ def test_bulk_variants_match_reference_golden(golden, hostlib, noise):
     path's 1e-2 mm of the live reference AND reproduce its status codes; the normal-equation and Gram variants are float64 throughout."""
     g = golden("triangulation")
     u, ps = g["u/noise%d" % noise], g["P"]
-    worst = 0.0
+    worst, worst32 = 0.0, 0.0
     for va, vb in ((0, 1), (0, 3), (1, 2)):
         for grp in range(3):
             tag = "noise%d/v%d%d/g%d" % (noise, va, vb, grp)
@@ -74,7 +74,18 @@ def test_bulk_variants_match_reference_golden(golden, hostlib, noise):
             x, st = _tri(hostlib, 6, u[va, grp], u[vb, grp], ps[va], ps[vb])        # round 5: LS through float64 normal equations (the fp32-storage path)
             np.testing.assert_allclose(x, g[tag + "/ls_x"], atol=1e-4)
             assert (st == 1).all()
-    print("mixed-precision iterative solver: worst |x - reference| = %.2e mm (noise %d px)" % (worst, noise))
+            # round 6: the float32-storage instantiations (inputs rounded to float32, rows built in float32 with one rounding, sums of products in
+            # float64): inside the fp32 path's 1e-2 mm of the live reference, and within 1e-3 mm of the all-float64 arithmetic on the SAME rounded inputs
+            u32 = lambda a: np.asarray(a, np.float32).astype(np.float64)        # noqa: E731
+            for m_new, m_wide, key in ((7, 6, "/ls_x"), (8, 4, "/eigen_x")):
+                xn, stn = _tri(hostlib, m_new, u[va, grp], u[vb, grp], ps[va], ps[vb])
+                xw, _ = _tri(hostlib, m_wide, u32(u[va, grp]), u32(u[vb, grp]), u32(ps[va]), u32(ps[vb]))
+                worst32 = max(worst32, float(np.abs(xn - xw).max()))
+                np.testing.assert_allclose(xn, g[tag + key], atol=1e-2)
+                np.testing.assert_allclose(xn, xw, atol=1e-3)
+                assert (stn == 1).all()
+    print("mixed-precision iterative solver: worst |x - reference| = %.2e mm (noise %d px); float32-row LS / DLT against float64 rows on the same "
+          "inputs: %.2e mm" % (worst, noise, worst32))
 
 
 def test_device_status_codes_behind_cameras(golden, hostlib):
