@@ -1191,9 +1191,10 @@ static int launch_tri(const void* kps, int kstride, const void* P, int G, int V,
     const int ng_max = 255 / J + 2;
     const size_t lds = ((size_t)V * ng_max * 12 + 768) * sizeof(T);
     const bool aligned = ((reinterpret_cast<uintptr_t>(kps) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(X)) & 15u) == 0;
-    // measured on MI355X, 2^20 groups x 4 views x 17 joints, float32 storage (profiles/r05_microbench_tri.txt): LS 0.271 ms staged / 0.316 per item, DLT 0.351 /
-    // 0.382, iterative 0.897 / 0.770 -- the iterative solver's ten rounds want the per-item kernel's occupancy, the single-solve methods the staged loads
-    const bool want_staged = g_tri_staged == 2 || (g_tri_staged == 1 && (METHOD == TRI_LS || METHOD == TRI_DLT));
+    // measured on MI355X, 2^20 groups x 4 views x 17 joints, float32 storage (profiles/r06_microbench_tri.txt): LS 0.217 ms staged / 0.244 per item, DLT 0.286 /
+    // 0.256, iterative 0.890 / 0.753 -- all three are bound by their VALU work (+560 VALU cycles per wave from LS to DLT = +0.069 ms, exactly the chip's rate);
+    // the staged form's two barriers and LDS round trips pay only for the shortest solve
+    const bool want_staged = g_tri_staged == 2 || (g_tri_staged == 1 && METHOD == TRI_LS);
     if (want_staged && aligned && lds <= 65536 && total >= 256) {
 #define EPI_TRI_LAUNCH(NVV)                                                                                               \
     hipLaunchKernelGGL((triangulate_staged_kernel<T, NVV, METHOD>), dim3(grid), dim3(256), lds, st, (const T*)kps, kstride, (const T*)P, \
@@ -1231,7 +1232,7 @@ static int tri_entry(const void* kps, int kstride, const void* P, int dtype, int
 
 using namespace epi;
 
-// 1 (default): bulk launches (>= 256 items, 16-byte aligned operands) of the single-solve methods (ls, dlt) take triangulate_staged_kernel; 2: of every method;
+// 1 (default): bulk launches (>= 256 items, 16-byte aligned operands) of the linear solve (ls) take triangulate_staged_kernel; 2: of every method;
 // 0: always the per-item kernel.  Returns the previous value.
 extern "C" int epi_triangulate_staged(int on) {
     const int before = g_tri_staged;

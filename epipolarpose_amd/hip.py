@@ -433,13 +433,16 @@ def triangulate(kps, proj, n_view, method="iterative", tolerance=3.0e-5, max_ite
     g = b // n_view
     dt = EPI_F64 if kps.dtype == torch.float64 else EPI_F32
     x = torch.empty((g, j, 3), dtype=kps.dtype, device=kps.device)
-    status = torch.empty((g, j), dtype=torch.int32, device=kps.device)
+    status = torch.empty((g, j), dtype=torch.int32, device=kps.device) if method != "ls" else None
     with _on(kps.device):
         if method == "iterative":
             st = lib.epi_triangulate_iterls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, tolerance, max_iter, _ptr(x),
                                             _ptr(status), _stream())
         elif method == "ls":
-            st = lib.epi_triangulate_ls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
+            # the linear solve has no failure mode: its status is all ones (triangulation.py:97 returns np.ones(len(u1), dtype=bool)) -- a broadcast constant
+            # instead of 68 bytes per group written by the kernel beside the 940 it has to move (the C entry point still fills a status array it is given)
+            status = torch.ones((), dtype=torch.int32, device=kps.device).expand(g, j)
+            st = lib.epi_triangulate_ls(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), None, _stream())
         elif method == "dlt":
             st = lib.epi_triangulate_dlt(_ptr(kps), stride, _ptr(proj), dt, g, n_view, j, _ptr(x), _ptr(status), _stream())
         elif method == "poly":

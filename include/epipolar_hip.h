@@ -140,7 +140,7 @@ int epi_triangulate_ls(const void* kps, int kps_stride, const void* P, int dtype
                        void* X, int32_t* status, epi_stream_t stream);
 int epi_triangulate_dlt(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                         void* X, int32_t* status, epi_stream_t stream);
-/* Bulk launches (>= 256 (group, joint) items, 16-byte aligned kps / P / X) of the single-solve triangulators (ls, dlt) run a staged kernel:
+/* Bulk launches (>= 256 (group, joint) items, 16-byte aligned kps / P / X) of the linear solve (ls) run a staged kernel:
  * the projection matrices of a workgroup's groups through LDS with 16-byte loads, one (u, v) vector load per view, 16-byte result stores --
  * the same arithmetic as the per-item kernel.  epi_triangulate_staged: 0 always the per-item kernel, 1 the default above, 2 the staged
  * kernel for every method (the parity tests run both on the same inputs), negative only queries; returns the previous setting. */
@@ -150,7 +150,9 @@ int epi_triangulate_staged(int on);
  * matrices (:196-204), the matches moved onto the closest exactly-epipolar pair (cv2.correctMatches, :210;
  * Hartley & Sturm / HZ Alg. 12.1, the degree-6 polynomial solved by real-root isolation in float64), then
  * the dlt solve above on the corrected matches (:220).  The reference's fallback to an 8-point F when the
- * correction returns NaN (:213-217) is not implemented: such points get status 0. */
+ * correction returns NaN (:213-217) lives one level up: this entry point gives such points status 0 and the host-side
+ * mirror (epipolarpose_amd/utils/triangulation.py:polynomial_triangulation) re-runs them with epi_fundamental_8point +
+ * epi_correct_matches as the reference does. */
 int epi_triangulate_poly(const void* kps, int kps_stride, const void* P, int dtype, int G, int V, int J,
                          void* X, int32_t* status, epi_stream_t stream);
 
