@@ -133,7 +133,7 @@ extern "C" int epi_adam_step_clipped(const void* table, const void* chunks, int 
                                      long long step, float max_norm, float* norm_sq, epi_stream_t stream) {
     if (!table || !chunks || !norm_sq || nchunks <= 0 || step < 1 || !(max_norm > 0.f)) return EPI_ERR_INVALID_ARGUMENT;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    float* part = epi::deterministic() ? epi::det_scratch((size_t)nchunks) : nullptr;      // (the BatchNorm half: the optimizer runs behind the backward chain on its stream)
+    float* part = epi::deterministic() ? epi::det_scratch((size_t)nchunks, (hipStream_t)stream) : nullptr;
     hipLaunchKernelGGL(epi::grad_sumsq_kernel, dim3(nchunks), dim3(epi::ADAM_THREADS), 0, (hipStream_t)stream,
                        (const epi::AdamTensor*)table, (const int2*)chunks, norm_sq, part);
     EPI_CHECK_LAUNCH();

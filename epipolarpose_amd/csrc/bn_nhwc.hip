@@ -528,7 +528,7 @@ static int launch_stats(const T* x, long long R, int C, float* sums, int ncopies
     reduce_blocking(R, C, &rpw, &rgrid, 8 * Elem<T>::VEC);
     float* part = nullptr;
     if (deterministic()) {
-        part = det_scratch((size_t)rgrid.y * 2 * C, column_sums);
+        part = det_scratch((size_t)rgrid.y * 2 * C, st);
         if (!part) return EPI_ERR_WORKSPACE;
     }
     hipLaunchKernelGGL(bn_stats_kernel<T>, rgrid, dim3(BN_THREADS), 0, st, x, R, C, rpw, sums, ncopies, part);
@@ -758,7 +758,7 @@ static int bn_act_bwd_impl(const void* dy, const void* x, const void* y, long lo
     if (!reduced) {
         float* part = nullptr;
         if (deterministic()) {           // per-row-block partial sums, added in index order (csrc/capi.hip)
-            part = det_scratch((size_t)rgrid.y * 2 * C);
+            part = det_scratch((size_t)rgrid.y * 2 * C, st);
             if (!part) return EPI_ERR_WORKSPACE;
         }
 #define EPI_BN_RED(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), rgrid, dim3(BN_THREADS), 0, st, dys, xs, ys, R, C, sc, sh, mean, rstd, rpw, dbeta_dgamma, part)

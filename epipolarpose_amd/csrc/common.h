@@ -22,7 +22,7 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 // Deterministic mode (epi_set_deterministic, csrc/capi.hip): every cross-workgroup floating-point sum runs in a FIXED order -- no fp32 atomics.
 bool deterministic();
-float* det_scratch(size_t floats, bool column_sums = false);      // device scratch for per-workgroup partial sums (null: not enabled / too small)
+float* det_scratch(size_t floats, hipStream_t stream);      // the stream's device scratch for per-workgroup partial sums (null: not enabled / too small)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

@@ -360,7 +360,7 @@ def _run_unit(m, x, fp32=False):
     return out
 
 
-def _make_unit_pair(kind):
+def _make_unit_pair(kind, batch=4, size=16):
     import copy
     from epipolarpose_amd.models import pose3d_resnet as P
     dev = torch.device("cuda:0")
@@ -382,7 +382,7 @@ def _make_unit_pair(kind):
     staged = P.ResidualUnit(inpl, planes, plan, stride, unit_node=False).to(dev).to(memory_format=torch.channels_last)
     assert staged._unit is None and staged._fused
     staged.load_state_dict(copy.deepcopy(unit.state_dict()))
-    x = _rand((4, inpl, 16, 16), torch.Generator().manual_seed(4)).to(dev).contiguous(memory_format=torch.channels_last)
+    x = _rand((batch, inpl, size, size), torch.Generator().manual_seed(4)).to(dev).contiguous(memory_format=torch.channels_last)
     return unit, staged, _torch_unit(unit, plan, inpl, planes, stride), x
 
 
