@@ -58,17 +58,17 @@ __device__ __forceinline__ void occluder_pixel(const unsigned char* __restrict__
 }
 
 // One pixel of `src` resized UP to (dw, dh) >= (sw, sh): cv2.resize INTER_LINEAR on uint8 restated (OpenCV 4.1 resize.cpp: the coordinate tables of
-// cv::resize, HResizeLinear<uchar, int, short, 2048>, the 8-bit VResizeLinear).  x: fx = float((px + 0.5) * (sw / dw) - 0.5), sx = floor(fx), fx -= sx,
+// cv::resize, HResizeLinear<uchar, int, short, 2048>, the 8-bit VResizeLinear).  x: fx = float((px + 0.5) * (1 / (dw / sw)) - 0.5), sx = floor(fx), fx -= sx,
 // (sx, fx) = (0, 0) left of the image and (sw - 1, 0) from its last column on; y: no border rule, the two rows are clamped into the image instead;
 // weights short(round-half-even(w * 2048)) of the float32 values; ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
 // augmentation.py:122 -- patches larger than 256 px (im_scale_factor > 1: the 384 px configuration).
 __device__ __forceinline__ void occluder_pixel_linear(const unsigned char* __restrict__ src, int sh, int sw, int dh, int dw, int px, int py, int (&rgba)[4]) {
-    float fx = (float)(((double)px + 0.5) * ((double)sw / (double)dw) - 0.5);
+    float fx = (float)(((double)px + 0.5) * (1.0 / ((double)dw / (double)sw)) - 0.5);     // scale = 1. / inv_scale as cv::resize computes it
     int sx = (int)floorf(fx);
     fx -= (float)sx;
     if (sx < 0) { sx = 0; fx = 0.f; }
     if (sx >= sw - 1) { sx = sw - 1; fx = 0.f; }
-    float fy = (float)(((double)py + 0.5) * ((double)sh / (double)dh) - 0.5);
+    float fy = (float)(((double)py + 0.5) * (1.0 / ((double)dh / (double)sh)) - 0.5);
     const int sy = (int)floorf(fy);
     fy -= (float)sy;
     const int a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, fx), 2048.f)), a1 = (int)rintf(__fmul_rn(fx, 2048.f));

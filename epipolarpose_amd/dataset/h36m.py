@@ -15,6 +15,7 @@ Checked against the LIVE reference class on the same files: tests/golden/make_h3
 JPEG decoding is PIL's libjpeg, the reference's is OpenCV's: both IJG-compatible decoders, not guaranteed bit-identical to each other (unpinned, as every
 OpenCV primitive here: DESIGN section 5).
 """
+import collections
 import copy
 import os
 import pickle
@@ -86,6 +87,32 @@ class _Meta:
         self.meta = meta
 
 
+class FrameCache:
+    """Decoded frames in HBM, least recently used out first, under a byte budget (a ~3 MB frame per record: the full H36M training set is hundreds of
+    thousands of them -- an unbounded dict would end in an out-of-memory error after a few hundred thousand items)."""
+
+    def __init__(self, max_bytes=8 << 30):
+        self.max_bytes, self.bytes = int(max_bytes), 0
+        self._items = collections.OrderedDict()
+
+    def get(self, path, device):
+        hit = self._items.get(path)
+        if hit is not None:
+            self._items.move_to_end(path)
+            return hit
+        bgr = decode_bgr(path)
+        hit = (torch.from_numpy(bgr.reshape(-1)).to(device), bgr.shape[:2])
+        self._items[path] = hit
+        self.bytes += hit[0].numel()
+        while self.bytes > self.max_bytes and len(self._items) > 1:
+            _, (old, _) = self._items.popitem(last=False)
+            self.bytes -= old.numel()
+        return hit
+
+    def __len__(self):
+        return len(self._items)
+
+
 class H36MFrames:
     """Frames of a per-camera ``db`` (``n_view`` lists of ``n_group`` records, the same frame at the same position in each) decoded into HBM.
 
@@ -93,10 +120,18 @@ class H36MFrames:
     ``frame_offset_host`` int64 [B], ``frame_hw_host`` int32 [B, 2], ``joints`` [B, J, 3] (u, v, root-relative depth in mm: ``db['joints_3d']``),
     ``joints_vis`` [B, J, 3] (z column scaled by ``z_weight``, h36m.py:61-62), ``scenes.meta`` (center_x .. projection_matrix)."""
 
-    def __init__(self, per_cam_db, root, z_weight=1.0, device=None):
+    def __init__(self, per_cam_db, root, z_weight=1.0, device=None, groups=None, max_bytes=64 << 30):
+        """groups: a range / slice of frame positions to decode (a WINDOW of the data set: the loader is then rebuilt per window); max_bytes: refuse to
+        decode more than this into HBM (the whole H36M training set does not fit any budget: ~3 MB x 4 cameras x hundreds of thousands of frames)."""
         self.device = device or torch.device("cuda", torch.cuda.current_device())
+        if groups is not None:
+            per_cam_db = [list(cam[groups] if isinstance(groups, slice) else [cam[i] for i in groups]) for cam in per_cam_db]
         self.n_view, self.n_group = len(per_cam_db), len(per_cam_db[0])
         assert all(len(c) == self.n_group for c in per_cam_db), "every camera must list the same frames"
+        est = self.n_view * self.n_group * 3 * 1000 * 1000             # H36M frames are ~1000 x 1000 x 3 bytes
+        if est > max_bytes:
+            raise ValueError("H36MFrames: %d frames (~%.0f GiB decoded) exceed the %.0f GiB budget -- decode a window (groups=range(a, b)) per pass "
+                             "or raise max_bytes" % (self.n_view * self.n_group, est / 2.0 ** 30, max_bytes / 2.0 ** 30))
         recs = [rec for cam in per_cam_db for rec in cam]
         b = len(recs)
         self.records = recs
@@ -121,6 +156,7 @@ class H36MFrames:
 
 class H36M_Integral(EvalMixin, Dataset):
     """lib/dataset/h36m.py:19-88 on the GPU input pipeline (see the module docstring)."""
+    items_use_device = True          # __getitem__ launches the crop kernel: iterate in-process (scripts/train.py gives such a data set num_workers = 0)
 
     def __init__(self, cfg, root, image_set, is_train, device=None):
         self.cfg, self.root, self.image_set, self.is_train = cfg, root, image_set, is_train
@@ -137,19 +173,14 @@ class H36M_Integral(EvalMixin, Dataset):
             self.occluders = load_occluders(cfg.DATASET.VOC)
         self.db, self.db_length = build_db(read_annotations(root, image_set), self.num_cams, bool(cfg.DATASET.TRI), is_train)
         self._device = device
-        self._frame_cache = {}
+        self._frame_cache = FrameCache(int(getattr(cfg.DATASET, "FRAME_CACHE_BYTES", 8 << 30)))
 
     def __len__(self):
         return self.db_length
 
     def _frame(self, path):
         """(uint8 CUDA tensor of the decoded frame, (h, w)), decoded and uploaded at first use."""
-        hit = self._frame_cache.get(path)
-        if hit is None:
-            bgr = decode_bgr(path)
-            dev = self._device or torch.device("cuda", torch.cuda.current_device())
-            hit = self._frame_cache[path] = (torch.from_numpy(bgr.reshape(-1)).to(dev), bgr.shape[:2])
-        return hit
+        return self._frame_cache.get(path, self._device or torch.device("cuda", torch.cuda.current_device()))
 
     def host_sample(self, the_db):
         """The host side of ``get_data``: the augmentation draw (img_utils.py:257-261, from the module RNG states like the reference), the crop affine,
@@ -193,11 +224,12 @@ class H36M_Integral(EvalMixin, Dataset):
             return {"cam_1": self.get_data(rec_1), "cam_2": self.get_data(rec_2)}
         return self.get_data(copy.deepcopy(self.db[idx]))
 
-    def frame_store(self, device=None):
-        """The whole data set decoded into HBM for ``synthetic_frames.FramePatchLoader`` (needs the per-camera record lists: ``DATASET.TRI`` training)."""
+    def frame_store(self, device=None, groups=None, max_bytes=64 << 30):
+        """The data set -- or the window ``groups`` of its frame positions -- decoded into HBM for ``synthetic_frames.FramePatchLoader`` (needs the
+        per-camera record lists: ``DATASET.TRI`` training).  More than ``max_bytes`` of decoded frames is refused (H36MFrames)."""
         if not self.tri:
             raise ValueError("frame_store needs the per-camera db (is_train and DATASET.TRI)")
-        return H36MFrames(self.db, self.root, z_weight=self.cfg.DATASET.Z_WEIGHT, device=device or self._device)
+        return H36MFrames(self.db, self.root, z_weight=self.cfg.DATASET.Z_WEIGHT, device=device or self._device, groups=groups, max_bytes=max_bytes)
 
 
 def h36m(cfg, root=None, image_set="valid", is_train=False, **kwargs):

@@ -155,7 +155,7 @@ def resize_area(im, new_size):
 def resize_linear(im, new_size):
     """``cv2.resize(im, new_size, interpolation=cv2.INTER_LINEAR)`` for uint8 [h, w, C] (OpenCV 4.1 ``resize.cpp``: ``cv::resize`` table set-up +
     ``HResizeLinear<uchar, int, short, 2048>`` + the 8-bit ``VResizeLinear``), restated:
-      x: fx = float32((dx + 0.5) * (sw / dw) - 0.5), sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= sw - 1 -> (sw - 1, 0);
+      x: fx = float32((dx + 0.5) * (1 / (dw / sw)) - 0.5), sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= sw - 1 -> (sw - 1, 0);
          weights short(round((1 - fx) * 2048)), short(round(fx * 2048)) (float32 products, round half to even);
       y: the same without the border rule -- the two ROWS are clamped into the image instead;
       horizontal pass in int32, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2."""
@@ -164,7 +164,8 @@ def resize_linear(im, new_size):
     dw, dh = int(new_size[0]), int(new_size[1])
 
     def table(s, d, zero_at_border):
-        f = ((np.arange(d, dtype=np.float64) + 0.5) * (float(s) / d) - 0.5).astype(np.float32)
+        # (cv::resize: inv_scale = (double)d / s, scale = 1. / inv_scale -- NOT (double)s / d, which can differ in the last bit and flip a floor)
+        f = ((np.arange(d, dtype=np.float64) + 0.5) * (1.0 / (float(d) / float(s))) - 0.5).astype(np.float32)
         i0 = np.floor(f).astype(np.int64)
         f = f - i0.astype(np.float32)
         if zero_at_border:

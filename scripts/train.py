@@ -137,12 +137,17 @@ def main(argv=None):
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, num_replicas=world, rank=rank,
                                                                   shuffle=config.TRAIN.SHUFFLE)
+    # A data set whose items are made ON THE DEVICE (dataset/h36m.py H36M_Integral: the patch comes from the crop kernel) is iterated in this process:
+    # a forked DataLoader worker cannot initialise HIP again behind model.cuda() ("Cannot re-initialize CUDA in forked subprocess"), and the work the
+    # reference gives its 8 cv2 workers (train.py:142) is one kernel launch here.  Host-only data sets keep config.WORKERS.
+    def workers_for(ds_obj):
+        return 0 if getattr(ds_obj, "items_use_device", False) else config.WORKERS
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=max(1, items_per_batch),
                                                shuffle=config.TRAIN.SHUFFLE and sampler is None, sampler=sampler,
-                                               num_workers=config.WORKERS, pin_memory=True, drop_last=world > 1,
+                                               num_workers=workers_for(train_dataset), pin_memory=True, drop_last=world > 1,
                                                collate_fn=dataset.view_major_collate)
     valid_loader = torch.utils.data.DataLoader(valid_dataset, batch_size=config.TEST.BATCH_SIZE, shuffle=False,
-                                               num_workers=config.WORKERS, pin_memory=True)
+                                               num_workers=workers_for(valid_dataset), pin_memory=True)
 
     best_model = False
     for epoch in range(config.TRAIN.BEGIN_EPOCH, config.TRAIN.END_EPOCH):

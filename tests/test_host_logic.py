@@ -200,3 +200,42 @@ def test_trace_step_sequence_tool(tmp_path):
     body = [l.split() for l in text[2:]]
     assert [l[-1] for l in body] == ["a_kernel<1>", "b_kernel", "c_kernel", "marker_kernel"]
     assert float(body[2][2]) == 5.0 and int(body[0][4]) == 4             # c_kernel's gap on its own queue; workgroups = grid / block
+
+
+def test_h36m_frame_cache_is_bounded_lru(monkeypatch):
+    """the per-path frame cache of dataset/h36m.py evicts least recently used frames under a byte budget, and a data set whose
+    items are made on the device tells scripts/train.py to iterate it in-process (no forked workers behind model.cuda())."""
+    import importlib
+    h36m = importlib.import_module("epipolarpose_amd.dataset.h36m")     # (the package also exports a factory FUNCTION of that name)
+    decoded = []
+
+    def fake_decode(path):
+        decoded.append(path)
+        return np.full((10, 10, 3), len(decoded), np.uint8)             # 300 bytes per frame
+    monkeypatch.setattr(h36m, "decode_bgr", fake_decode)
+    cache = h36m.FrameCache(max_bytes=1000)                             # room for three frames
+    cpu = torch.device("cpu")
+    for p in ("a", "b", "c"):
+        cache.get(p, cpu)
+    assert len(cache) == 3 and cache.bytes == 900
+    cache.get("a", cpu)                                                 # a is the most recent now
+    cache.get("d", cpu)                                                 # evicts b
+    assert len(cache) == 3 and decoded == ["a", "b", "c", "d"]
+    cache.get("a", cpu)
+    cache.get("c", cpu)
+    assert decoded == ["a", "b", "c", "d"]                              # hits
+    cache.get("b", cpu)                                                 # decoded again, evicts d
+    assert decoded[-1] == "b" and len(cache) == 3 and cache.bytes == 900
+    frame, hw = cache.get("b", cpu)
+    assert hw == (10, 10) and frame.numel() == 300
+    assert h36m.H36M_Integral.items_use_device is True
+    src = open(os.path.join(ROOT, "scripts", "train.py")).read()
+    assert "items_use_device" in src and "num_workers=workers_for(train_dataset)" in src and "num_workers=workers_for(valid_dataset)" in src
+
+
+def test_h36m_frame_store_refuses_more_than_its_budget():
+    import importlib
+    h36m = importlib.import_module("epipolarpose_amd.dataset.h36m")
+    per_cam = [[{"image": "x.jpg"}] * 10 for _ in range(4)]
+    with pytest.raises(ValueError, match="exceed"):
+        h36m.H36MFrames(per_cam, "/nowhere", device=torch.device("cpu"), max_bytes=50 * 1000 * 1000)
