@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256, (std::is_same<S, float>::value && METHOD == TR
     const long long total = (long long)G * J;
     if (t >= total) return;
     // (round 6: a 64-bit division per item was ~100 instructions of the ~600 a linear solve takes; item counts below 2^31 divide in 32 bits)
-    const int g = total < (1ll << 31) ? (int)((unsigned)t / (unsigned)J) : (int)(t / J), j = (int)(t - (long long)g * J);
+    const int g = total < (1ll << 31) ? (int)((unsigned)t / (unsigned)J) : (int)(t / J);
     const long long view_items = total;                                 // items of one view: sample s = v * G + g, img_utils.py:197-202
     // inputs stay in the storage type for the mixed-precision iterative solver (it converts at every use: 56 registers instead of 112)
     typedef typename std::conditional<std::is_same<S, float>::value && METHOD != TRI_POLY, float, T>::type TIN;
@@ -943,7 +943,7 @@ void triangulate_staged_kernel(const S* __restrict__ kps, int kstride, const S* 
     // rel = r0 + tid past the first item of group g_lo, rel < 256 + J, and rel / J = (rel * ceil(2^16 / J)) >> 16 exactly while rel * J < 2^16
     const int r0 = (int)(t0 - (long long)g_lo * J), rel = live ? r0 + tid : r0;
     const int gl = (256 + J) * J < 65536 ? (int)(((unsigned)rel * (unsigned)((65536 + J - 1) / J)) >> 16) : rel / J;
-    const int g = g_lo + gl, j = rel - gl * J;
+    const int g = g_lo + gl;
     const long long t_item = live ? t : t0;
     // the key points first: their latency overlaps the staging of the projection matrices
     TIN u[NV][2], P[NV][12];
