@@ -224,24 +224,38 @@ def stem_conv_ms(model, images, reps=5):
     return a.elapsed_time(b) / reps, 2.0 * 2 * x.shape[0] * y.shape[2] * y.shape[3] * 64 * 147
 
 
-def event_pair_overhead_ms(device, reps=400):
-    """What a HIP event pair adds to the duration it reports for ONE launch: the median elapsed time of pairs recorded around a one-element kernel, in the
-    same pattern as the instrumented steps (pair, launch, pair, launch ... on the launch stream).  A kernel that does nothing has no duration of its
-    own; what the pair reports for it -- the dispatch latency between the start event's timestamp and the kernel, and the end event's -- is what it adds
-    to every real launch.  (Round 5's BatchNorm block said 1.47 ms / 0.475 from event pairs beside 1.23 ms / 0.60 in the rocprofv3 kernel table of the
-    same command: 120 short launches x ~2 us.)"""
-    x = torch.zeros(64, device=device)
-    for _ in range(50):
-        x.add_(1.0)
+def event_pair_overhead_ms(device, reps=256):
+    """What a HIP event pair adds to the duration it reports for ONE launch of a busy queue, measured in this run: the same `reps` kernels (a 64 MB fill,
+    ~11 us: the size of a typical launch of the step) are enqueued twice behind a few milliseconds of queued fills (the host runs ahead, the GPU sets
+    the pace) -- once with a pair around every launch (sum of the pairs' elapsed times), once back to back between ONE outer pair.  The back-to-back arm
+    is what rocprofv3's kernel table reports (its durations tile a busy queue: 6.01 of 6.08 ms of a step have a kernel running); the difference per
+    launch is the pair's own cost.  tools/probe_event_pair_overhead.py: 2.2 us for kernels of 7 us and more, rising to 4.8 us under a 1.7 us kernel
+    (round 5's BatchNorm block: 1.47 ms from event pairs beside 1.23 ms in the rocprofv3 table of the same command = 106 pairs x 2.3 us)."""
+    buf = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    big = torch.empty(1 << 29, dtype=torch.uint8, device=device)
+
+    def head():                                   # ~8 ms of queued work: the 3 x reps enqueue calls below take the host 2-4 ms
+        for _ in range(80):
+            big.fill_(0)
+    for _ in range(20):
+        buf.fill_(1)
     torch.cuda.synchronize()
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    head()
     for a, b in pairs:
         a.record()
-        x.add_(1.0)
+        buf.fill_(1)
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in pairs)
-    return ts[len(ts) // 2]
+    with_pairs = sum(a.elapsed_time(b) for a, b in pairs)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    head()
+    s.record()
+    for _ in range(reps):
+        buf.fill_(1)
+    e.record()
+    torch.cuda.synchronize()
+    return max(0.0, (with_pairs - s.elapsed_time(e)) / reps)
 
 
 def build_roofline(args, ksum, glue_times, model, images, pair_ms=0.0):
@@ -343,8 +357,9 @@ def build_roofline(args, ksum, glue_times, model, images, pair_ms=0.0):
     out["measured"] = ("HIP events on the launch stream around every launch, over `steps` additional steps of the same workload right after "
                        "the timed region (recording them inside it makes the step host-bound and would falsify `value`); in these steps the "
                        "weight gradients run on the main stream too, so that every figure is the kernel's own duration; every pair's own overhead "
-                       "(event_pair_overhead_us, measured in this run around a one-element kernel) is subtracted per launch, which is what makes the "
-                       "figures agree with the rocprofv3 kernel table of the same command (profiles/)")
+                       "(event_pair_overhead_us, measured in this run: 64 MB fills in a busy queue with a pair around each against the same "
+                       "kernels back to back) is subtracted per launch, which is what makes the figures agree with the rocprofv3 kernel table of the "
+                       "same command (profiles/)")
     out["event_pair_overhead_us"] = round(pair_ms * 1e3, 3)
     out["note"] = "traffic: not measured in this run (PMC passes are separate rocprofv3 runs: profiles/*pmc*)"
     default_workload = (args.workload == "fs" and args.layers == 50 and args.image == 256 and args.batch == 32 and args.views == 4 and
@@ -413,7 +428,7 @@ def refiner_leg(args, device):
             "train_ms_per_step": round(train_ms, 4), "train_samples_per_s": round(64 / (train_ms * 1e-3), 1), "final_loss": round(float(loss.item()), 6)}
 
 
-PMC_FILE = "profiles/r05_pmc_step_families.json"
+PMC_FILE = "profiles/r06_pmc_step_families.json"
 
 
 def pmc_traffic(default_workload):
