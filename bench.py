@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--allreduce", choices=["default", "ring", "direct"], default="default",
                     help="gradient collective at N > 1 (SURVEY section 5: xGMI is point-to-point): default = one all-reduce per bucket, algorithm and "
                          "channels chosen by RCCL; ring = the same with NCCL_ALGO=Ring pinned before the communicator exists; direct = reduce-scatter + "
-                         "all-gather as grouped point-to-point transfers, one per peer / xGMI link (epipolarpose_amd/distributed.py)")
+                         "all-gather as grouped point-to-point transfers, one per peer / xGMI link (epipolarpose_amd/distributed.py) -- EXPERIMENTAL: tested on "
+                         "gloo with CPU tensors only, it has never run on RCCL (no multi-GPU node has been available)")
     ap.add_argument("--force-grad-sync", action="store_true", help="diagnostic: run the N>1 gradient-bucket path at N=1 (copies "
                     "into the flat buckets, no collective) to price its overhead on one GPU")
     ap.add_argument("--refiner-leg", action="store_true", help="also time the refiner MLP beside the step (configs[4] names it: post-lift refinement of "

@@ -46,9 +46,10 @@ const char* epi_status_string(int status);
 /* Deterministic mode -- the reference's CUDNN.DETERMINISTIC key (lib/core/config.py:21, scripts/train.py:80: torch.backends.cudnn.deterministic).
  * on = 1: every cross-workgroup floating-point sum of the library runs in a fixed order (no fp32 atomics): the GEMM launches withhold their fused
  * BatchNorm statistics / BatchNorm-backward sums (*_done = 0: the caller's own pass runs), and those passes write per-workgroup partial sums to a
- * library-owned 32 MB scratch (allocated by the first enabling call) that a second kernel adds in index order.  The caller must keep all BatchNorm
- * passes (epi_bn_act_*) on ONE stream while it is on, and all epi_column_sums_* calls on one stream (they have their own half of the scratch).  on = 0: atomics (default).  on < 0: query.  Returns the previous setting (-1: the
- * scratch could not be allocated).  Bit-identical reruns of a training step: tests/test_hip_deterministic.py. */
+ * library-owned 16 MB scratch PER (device, stream) (allocated at the first use on that pair) that a second kernel adds in index order -- launches
+ * of one stream are ordered and never share the scratch in time, launches of different streams have their own.  on = 0: atomics (default).
+ * on < 0: query.  Returns the previous setting (-1: the scratch could not be allocated).  Bit-identical reruns of a training step:
+ * tests/test_hip_deterministic.py. */
 int epi_set_deterministic(int on);
 
 /* ------------------------------------------------------------------------------------------------
