@@ -321,6 +321,13 @@ def _direct_worker(rank, world, port, tmp):
     x, y = torch.randn(4 * world, 6), torch.randn(4 * world, 4)
     xs, ys = x[4 * rank:4 * rank + 4], y[4 * rank:4 * rank + 4]
     out = {}
+    # every rank's LOCAL gradients (no exchange), gathered: the exact mean the collectives have to deliver
+    local = _MixedNet()
+    (((local(xs) - ys) ** 2).sum() / 4).backward()
+    mine = torch.cat([p.grad.double().reshape(-1) for p in local.parameters()])
+    every = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    out["exact_mean"] = torch.stack(every).mean(0)
     for mode in ("allreduce", "direct"):
         model = _MixedNet()
         sync = epd.BucketedGradSync(model, bucket_bytes=1 << 9, collective=mode)     # small buckets: several collectives per dtype, ragged sizes
@@ -349,3 +356,14 @@ def test_direct_collective_matches_allreduce(tmp_path, world):
     for a, b in zip(res[0]["direct"], res[0]["allreduce"]):
         tol = dict(rtol=2e-2, atol=2e-3) if a.dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(a.float(), b.float(), **tol)
+    # round 6: the direct form adds the N slices in fp32, scales by 1 / N and rounds ONCE -- a bf16 gradient is the exact mean of the (bf16) local gradients
+    # rounded to bf16 (to one unit in the last place: the fp32 sum itself rounds), not the twice-rounded value of round 5; fp32 gradients to fp32 accuracy
+    exact, off = res[0]["exact_mean"], 0
+    for g in res[0]["direct"]:
+        e = exact[off:off + g.numel()].reshape(g.shape)
+        off += g.numel()
+        if g.dtype == torch.bfloat16:
+            half_ulp = e.abs() * 2.0 ** -8            # (round to nearest: at most 2^-8 relative -- reached just above a power of two; two roundings could double it)
+            assert ((g.double() - e).abs() <= 1.001 * half_ulp + 1e-12).all(), float(((g.double() - e).abs() / (half_ulp + 1e-300)).max())
+        else:
+            torch.testing.assert_close(g.double(), e, rtol=1e-5, atol=1e-7)
